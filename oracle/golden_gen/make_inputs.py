@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Writes the raw input files of every golden case into oracle/_ref/cases/<case>/in/.
+
+Inputs come from poppy_amd/synth.py (integer-defined), so the tests can regenerate them
+on any box; only the reference OUTPUTS are committed as fixtures (see pack.py).
+The same case table is imported by the tests (tests/golden_cases.py re-exports CASES).
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+from poppy_amd import synth  # noqa: E402
+
+CASES_DIR = os.path.join(ROOT, "oracle", "_ref", "cases")
+
+_DT = {np.dtype(np.uint8): "u8", np.dtype(np.float32): "f32", np.dtype(np.int32): "i32", np.dtype(np.float64): "f64"}
+
+
+def write_in(case, name, arr):
+    arr = np.ascontiguousarray(arr)
+    d = os.path.join(CASES_DIR, case, "in")
+    os.makedirs(d, exist_ok=True)
+    shp = "x".join(str(s) for s in arr.shape)
+    arr.tofile(os.path.join(d, f"{name}.{_DT[arr.dtype]}.{shp}.bin"))
+
+
+# ---- case tables (single source of truth for generator AND tests) --------------------------
+BSTAGE = {
+    # name: (w, h, npts, ratios[(shape, mask)], levels)
+    "b_64x48": (64, 48, 12, [(0.0, 0.0), (1 / 60, 1 / 60), (0.25, 0.25), (0.5, 0.5), (1.0, 1.0)], 64),
+    "b_256x256": (256, 256, 60, [(1 / 60, 1 / 60), (0.5, 0.5), (0.9, 0.7)], 64),
+    "b_509x381": (509, 381, 150, [(0.5, 0.5), (0.3, 0.3)], 64),
+    "b_1920x1080": (1920, 1080, 440, [(0.5, 0.5)], 64),
+}
+ORB = {
+    # name: (w, h, [nfeatures])
+    "o_256x256": (256, 256, [300, 516]),
+    "o_640x480": (640, 480, [500]),
+    "o_1920x1080": (1920, 1080, [516]),
+}
+MATCH = {
+    # name: (w, h, n, tolerance, seed)
+    "m_640x480": (640, 480, 200, 1.0, 31),
+    "m_1920x1080": (1920, 1080, 513, 1.0, 32),
+    "m_tol2": (800, 600, 120, 2.0, 33),
+}
+ASTAGE = {
+    # name: (w, h, nframes, phase, levels)
+    "a_256x256_chain": (256, 256, 6, -1.0, 64),
+    "a_256x256_phase": (256, 256, 1, 0.5, 64),
+    "a_512x384_chain": (512, 384, 4, -1.0, 64),
+}
+
+
+def bstage_inputs(name):
+    w, h, n, ratios, levels = BSTAGE[name]
+    c1 = synth.textured_bgr(w, h, 21)
+    c2 = synth.textured_bgr(w, h, 22)
+    gabor2 = synth.unit_field(w, h, 11)
+    p1, p2 = synth.point_pairs(w, h, n, seed=5)
+    return dict(c1=c1, c2=c2, gabor2=gabor2, pts1=p1, pts2=p2,
+                ratios=np.array(ratios, dtype=np.float64).ravel(), levels=np.array([levels], dtype=np.float64))
+
+
+def orb_inputs(name):
+    w, h, nf = ORB[name]
+    g1 = synth.textured_gray(w, h, 7)
+    g2 = np.roll(synth.textured_gray(w, h, 7), (h // 100 + 1, w // 50 + 1), axis=(0, 1))
+    return dict(g1=g1, g2=np.ascontiguousarray(g2), nfeatures=np.array(nf, dtype=np.float64))
+
+
+def match_inputs(name):
+    w, h, n, tol, seed = MATCH[name]
+    p1, p2 = synth.point_pairs(w, h, n, seed=seed, dup=3, oob=2)
+    p1, p2 = p1[:-4], p2[:-4]                       # no corners: Matcher::prepare adds them
+    rng = synth.XorShift64Star(seed + 100)          # break the 1:1 order so greedy NN has work to do
+    perm = np.arange(len(p2))
+    for i in range(len(perm) - 1, 0, -1):
+        j = rng.uniform(0, i + 1)
+        perm[i], perm[j] = perm[j], perm[i]
+    return dict(pts1=p1, pts2=np.ascontiguousarray(p2[perm]), cfg=np.array([w, h, tol], dtype=np.float64))
+
+
+def astage_inputs(name):
+    w, h, nframes, phase, levels = ASTAGE[name]
+    a, b = synth.gen_pair(w, h)
+    return dict(img1=a, img2=b, cfg=np.array([nframes, phase, levels], dtype=np.float64))
+
+
+def prims_inputs():
+    rng = synth.XorShift64Star(77)
+    w, h = 320, 200
+    pts = np.array([[rng.uniform(0, 4 * w) / 4.0, rng.uniform(0, 4 * h) / 4.0] for _ in range(65)], dtype=np.float32)
+    polys = np.array([[rng.uniform(-20, w + 20), rng.uniform(-20, h + 20), rng.uniform(-20, w + 20), rng.uniform(-20, h + 20),
+                       rng.uniform(-20, w + 20), rng.uniform(-20, h + 20)] for _ in range(40)], dtype=np.int32)
+    src = synth.textured_bgr(w, h, 41)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    mx = (xx * np.float32(1.03) + yy * np.float32(0.05) - np.float32(7.3)).astype(np.float32)
+    my = (yy * np.float32(0.97) - xx * np.float32(0.02) + np.float32(4.6)).astype(np.float32)
+    mx[0, 0] = np.float32(1e12); my[0, 1] = np.float32(-1e12); mx[1, 0] = np.float32(np.nan)   # x86 cvRound indefinite
+    mats = np.array([[1 + (rng.uniform(0, 200) - 100) / 500.0, (rng.uniform(0, 200) - 100) / 700.0, (rng.uniform(0, 200) - 100) / 3.0,
+                      (rng.uniform(0, 200) - 100) / 700.0, 1 + (rng.uniform(0, 200) - 100) / 500.0, (rng.uniform(0, 200) - 100) / 3.0,
+                      (rng.uniform(0, 200) - 100) / 1e6, (rng.uniform(0, 200) - 100) / 1e6, 1.0] for _ in range(20)], dtype=np.float32)
+    mats[3] = 0            # singular -> zero inverse
+    return dict(subdiv_pts=pts, subdiv_rect=np.array([w, h], dtype=np.float64), polys=polys,
+                remap_src=src, remap_mx=mx, remap_my=my, mats33=mats)
+
+
+def all_cases():
+    out = []
+    out += [("bstage", n, bstage_inputs) for n in BSTAGE]
+    out += [("orb", n, orb_inputs) for n in ORB]
+    out += [("match", n, match_inputs) for n in MATCH]
+    out += [("astage", n, astage_inputs) for n in ASTAGE]
+    out += [("prims", "p_prims", lambda _n: prims_inputs())]
+    return out
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for mode, name, fn in all_cases():
+        if only and name not in only:
+            continue
+        for k, v in fn(name).items():
+            write_in(name, k, v)
+        print(mode, name)
