@@ -467,6 +467,12 @@ static void dump_prims() {
         memcpy(&inv[i * 9], iv.data, 36);
     }
     write_raw("mats33_inv", "f32", { mats.rows, 3, 3 }, inv.data(), inv.size() * 4);
+
+    // Gaussian taps the hot path uses (soft-float getGaussianKernel): baked into oracle/ and the kernels
+    dump_mat("gauss_k9_s1", getGaussianKernel(9, 1.0, CV_32F));
+    dump_mat("gauss_k17_s2", getGaussianKernel(17, 2.0, CV_32F));
+    dump_mat("gauss_k7_s2", getGaussianKernel(7, 2.0, CV_32F));
+    dump_mat("gauss_k23_s1", getGaussianKernel(23, 1.0, CV_32F));
 }
 
 int main(int argc, char** argv) {

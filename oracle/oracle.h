@@ -1,0 +1,97 @@
+// oracle/ — CPU restatement of the reference's morph hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+// The product (poppy_amd/, include/) never includes, links or calls anything in here.
+//
+// Every function restates, in plain scalar C++ with no OpenCV, the arithmetic of the
+// reference routine it cites (paths relative to /root/reference; OCV = third/opencv-4.6.0/modules).
+// Parity pins: tests/test_oracle_golden.py checks each stage against fixtures captured from the
+// compiled reference (tests/golden/manifest.json -> provenance) and against the known-answer
+// data OpenCV's own tests hold (Subdiv2D 65 pts -> 105 triangles).
+//
+// Build: make -C oracle   (g++ -O2 -ffp-contract=off, no -march: float ops must round like the
+// SSE3-baseline reference build — one rounding per multiply and per add, never fused).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+namespace oracle {
+
+struct Pt { float x, y; };
+struct IPt { int x, y; };
+
+template <typename T> struct Image {
+    int w = 0, h = 0, c = 1;
+    std::vector<T> d;
+    Image() {}
+    Image(int w_, int h_, int c_ = 1) : w(w_), h(h_), c(c_), d((size_t)w_ * h_ * c_) {}
+    T* row(int y) { return d.data() + (size_t)y * w * c; }
+    const T* row(int y) const { return d.data() + (size_t)y * w * c; }
+    size_t size() const { return d.size(); }
+};
+typedef Image<uint8_t> ImageU8;
+typedef Image<float> ImageF;
+typedef Image<int32_t> ImageI;
+
+// ---- rounding helpers (x86 semantics) ------------------------------------------------------
+int cv_round(double v);          // cvRound(double): cvtsd2si, round-half-even, "indefinite" INT_MIN when out of range
+int cv_round_f(float v);         // cvRound(float):  cvtss2si
+int border_reflect101(int p, int len);
+
+// ---- geometry.cpp ---------------------------------------------------------------------------
+void clip_points(std::vector<Pt>& pts, int cols, int rows);
+void make_uniq(const std::vector<Pt>& pts, std::vector<Pt>& out);
+void morph_points(const std::vector<Pt>& a, const std::vector<Pt>& b, std::vector<Pt>& out, float s);
+
+// Incremental Delaunay triangulation with the quad-edge bookkeeping of cv::Subdiv2D, so that
+// the triangle LIST ORDER equals Subdiv2D::getTriangleList().  Returns false if a point lies
+// outside [0,w) x [0,h) (the reference throws there).
+bool delaunay_triangles(int w, int h, const std::vector<Pt>& pts, std::vector<float>& tri6);
+
+void triangle_indices(const std::vector<float>& tri6, const std::vector<Pt>& points, std::vector<int>& idx3);
+void triangle_int_points(const std::vector<int>& idx3, const std::vector<Pt>& points, std::vector<IPt>& out);
+
+// fillConvexPoly(img, 3 pts, Scalar(value), LINE_8, shift 0) on a 32SC1 image
+void fill_triangle(ImageI& img, const IPt* v, int32_t value);
+void paint_triangles(ImageI& img, const std::vector<IPt>& tris);
+
+bool invert33(const float* m, float* out);          // cv::invert 3x3 CV_32F (double cofactors)
+void solve_homography(const IPt* src1, const IPt* src2, float* H);
+void morph_homography(const float* H, float ratio, float* M1, float* M2);
+
+// ---- warp.cpp --------------------------------------------------------------------------------
+void create_map(const ImageI& triMap, const std::vector<float>& mats, ImageF& mapx, ImageF& mapy);
+void remap_bilinear(const ImageU8& src, const ImageF& mapx, const ImageF& mapy, ImageU8& dst);
+const int16_t* bilinear_tab();   // [1024][4]
+
+// ---- blend.cpp -------------------------------------------------------------------------------
+void u8_to_f32(const ImageU8& src, ImageF& dst);            // convertTo(CV_32F, 1/255)
+void f32_to_u8(const ImageF& src, ImageU8& dst);            // convertTo(CV_8U, 255)
+void blend_mask(const ImageF& gabor2, double maskRatio, ImageF& mask);
+void pyr_down(const ImageF& src, ImageF& dst);
+void pyr_up(const ImageF& src, ImageF& dst, int dw, int dh);
+void laplacian_blend(const ImageF& l, const ImageF& r, const ImageF& mask, int levels, ImageF& out);
+void gaussian_blur_f32(const ImageF& src, const float* k, int ksize, ImageF& dst);
+void median3_f32(const ImageF& src, ImageF& dst);
+void unsharp_mask(const ImageF& src, float radius, float amount, float threshold, ImageF& dst,
+                  ImageF* blurOut = nullptr, ImageF* medOut = nullptr);
+extern const float kGauss9Sigma1[9];
+
+// ---- frame.cpp -------------------------------------------------------------------------------
+struct FrameDebug {
+    std::vector<Pt> morphed, uniq;
+    std::vector<float> tri6, H, M1, M2;
+    std::vector<int> idx3;
+    std::vector<IPt> triMorph;
+    ImageI triMap;
+    ImageF mapx1, mapy1, mapx2, mapy2, lbmask, lapBlend, unsharp;
+    ImageU8 trImg1, trImg2;
+};
+// morph_images() (src/algo.cpp:178-273).  Returns 0 on success, <0 if the reference would throw.
+int morph_images(const ImageU8& c1, const ImageU8& c2, const ImageF& gabor2,
+                 const std::vector<Pt>& pts1, const std::vector<Pt>& pts2,
+                 double shapeRatio, double maskRatio, int levels,
+                 ImageU8& out, std::vector<Pt>& morphedPoints, FrameDebug* dbg = nullptr);
+
+}  // namespace oracle

@@ -1,0 +1,104 @@
+// oracle/oracle_api.cpp — flat C entry points so tests/ and bench.py's cpu_baseline leg can drive
+// the oracle through ctypes.  TEST INFRASTRUCTURE; nothing in the product links this.
+#include "oracle.h"
+#include <cstring>
+
+using namespace oracle;
+
+static ImageU8 wrap_u8(const uint8_t* p, int w, int h, int c) { ImageU8 m(w, h, c); memcpy(m.d.data(), p, m.d.size()); return m; }
+static ImageF wrap_f(const float* p, int w, int h, int c) { ImageF m(w, h, c); memcpy(m.d.data(), p, m.d.size() * 4); return m; }
+static std::vector<Pt> wrap_pts(const float* p, int n) { std::vector<Pt> v(n); if (n) memcpy(v.data(), p, (size_t)n * 8); return v; }
+template <typename T> static void put(T* dst, const std::vector<T>& v) { if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * sizeof(T)); }
+static void put_img(float* dst, const ImageF& m) { if (dst) memcpy(dst, m.d.data(), m.d.size() * 4); }
+static void put_img(uint8_t* dst, const ImageU8& m) { if (dst) memcpy(dst, m.d.data(), m.d.size()); }
+
+extern "C" {
+
+int orc_round_f(float v) { return cv_round_f(v); }
+
+void orc_clip_points(float* pts, int n, int cols, int rows) {
+    auto v = wrap_pts(pts, n); clip_points(v, cols, rows); memcpy(pts, v.data(), (size_t)n * 8);
+}
+int orc_make_uniq(const float* pts, int n, float* out) {
+    std::vector<Pt> o; make_uniq(wrap_pts(pts, n), o); put((Pt*)out, o); return (int)o.size();
+}
+void orc_morph_points(const float* a, const float* b, int n, float s, float* out) {
+    std::vector<Pt> o; morph_points(wrap_pts(a, n), wrap_pts(b, n), o, s); put((Pt*)out, o);
+}
+int orc_delaunay(int w, int h, const float* pts, int n, float* tri6, int maxTris) {
+    std::vector<float> t;
+    if (!delaunay_triangles(w, h, wrap_pts(pts, n), t)) return -1;
+    int nt = (int)t.size() / 6;
+    if (nt > maxTris) return -2;
+    put(tri6, t);
+    return nt;
+}
+int orc_triangle_indices(const float* tri6, int nt, const float* pts, int n, int* idx3) {
+    std::vector<float> t(tri6, tri6 + (size_t)nt * 6); std::vector<int> o;
+    triangle_indices(t, wrap_pts(pts, n), o); put(idx3, o); return (int)o.size() / 3;
+}
+void orc_triangle_int_points(const int* idx3, int nt, const float* pts, int n, int* out) {
+    std::vector<int> id(idx3, idx3 + (size_t)nt * 3); std::vector<IPt> o;
+    triangle_int_points(id, wrap_pts(pts, n), o); if (!o.empty()) memcpy(out, o.data(), o.size() * 8);
+}
+void orc_paint_triangles(int w, int h, const int* tris, int nt, int32_t* map) {
+    ImageI img(w, h);
+    std::vector<IPt> t((size_t)nt * 3); if (nt) memcpy(t.data(), tris, t.size() * 8);
+    paint_triangles(img, t);
+    memcpy(map, img.d.data(), img.d.size() * 4);
+}
+int orc_invert33(const float* m, float* out) { return invert33(m, out) ? 1 : 0; }
+void orc_homographies(const int* t1, const int* t2, int nt, float ratio, float* H, float* M1, float* M2) {
+    for (int t = 0; t < nt; ++t) {
+        solve_homography((const IPt*)t1 + t * 3, (const IPt*)t2 + t * 3, H + t * 9);
+        morph_homography(H + t * 9, ratio, M1 + t * 9, M2 + t * 9);
+    }
+}
+void orc_create_map(const int32_t* triMap, int w, int h, const float* mats, int nt, float* mapx, float* mapy) {
+    ImageI tm(w, h); memcpy(tm.d.data(), triMap, tm.d.size() * 4);
+    std::vector<float> m(mats, mats + (size_t)nt * 9);
+    ImageF mx, my; create_map(tm, m, mx, my); put_img(mapx, mx); put_img(mapy, my);
+}
+void orc_remap(const uint8_t* src, int sw, int sh, int c, const float* mapx, const float* mapy, int w, int h, uint8_t* dst) {
+    ImageU8 d; remap_bilinear(wrap_u8(src, sw, sh, c), wrap_f(mapx, w, h, 1), wrap_f(mapy, w, h, 1), d); put_img(dst, d);
+}
+void orc_bilinear_tab(int16_t* out) { memcpy(out, bilinear_tab(), 1024 * 4 * 2); }
+void orc_u8_to_f32(const uint8_t* s, int n, float* d) { ImageF o; u8_to_f32(wrap_u8(s, n, 1, 1), o); put_img(d, o); }
+void orc_f32_to_u8(const float* s, int n, uint8_t* d) { ImageU8 o; f32_to_u8(wrap_f(s, n, 1, 1), o); put_img(d, o); }
+void orc_blend_mask(const float* gabor2, int w, int h, double maskRatio, float* mask) {
+    ImageF m; blend_mask(wrap_f(gabor2, w, h, 3), maskRatio, m); put_img(mask, m);
+}
+void orc_pyr_down(const float* s, int w, int h, int c, float* d) { ImageF o; pyr_down(wrap_f(s, w, h, c), o); put_img(d, o); }
+void orc_pyr_up(const float* s, int w, int h, int c, int dw, int dh, float* d) { ImageF o; pyr_up(wrap_f(s, w, h, c), o, dw, dh); put_img(d, o); }
+void orc_laplacian_blend(const float* l, const float* r, const float* mask, int w, int h, int levels, float* out) {
+    ImageF o; laplacian_blend(wrap_f(l, w, h, 3), wrap_f(r, w, h, 3), wrap_f(mask, w, h, 1), levels, o); put_img(out, o);
+}
+void orc_unsharp(const float* s, int w, int h, float amount, float threshold, float* out, float* blur, float* med) {
+    ImageF o, b, m; unsharp_mask(wrap_f(s, w, h, 3), 1.f, amount, threshold, o, &b, &m);
+    put_img(out, o); put_img(blur, b); put_img(med, m);
+}
+
+// Whole frame.  Optional debug outputs may be null.  tri buffers must hold maxTris entries.
+int orc_morph_images(const uint8_t* c1, const uint8_t* c2, const float* gabor2, int w, int h,
+                     const float* p1, const float* p2, int n, double shape, double mask, int levels,
+                     uint8_t* out, float* morphedPts,
+                     int maxTris, int* nTris, float* tri6, int* idx3, float* Hm, float* M1, float* M2,
+                     int32_t* triMap, float* mapx1, float* mapy1, float* mapx2, float* mapy2,
+                     uint8_t* trImg1, uint8_t* trImg2, float* lbmask, float* lapBlend, float* unsharpOut) {
+    FrameDebug dbg; ImageU8 o; std::vector<Pt> mp;
+    int rc = morph_images(wrap_u8(c1, w, h, 3), wrap_u8(c2, w, h, 3), wrap_f(gabor2, w, h, 3),
+                          wrap_pts(p1, n), wrap_pts(p2, n), shape, mask, levels, o, mp, &dbg);
+    if (rc) return rc;
+    put_img(out, o); put((Pt*)morphedPts, mp);
+    int nt = (int)dbg.idx3.size() / 3;
+    if (nTris) *nTris = nt;
+    if (nt <= maxTris) { put(idx3, dbg.idx3); put(Hm, dbg.H); put(M1, dbg.M1); put(M2, dbg.M2); }
+    if ((int)dbg.tri6.size() / 6 <= maxTris) put(tri6, dbg.tri6);
+    if (triMap) memcpy(triMap, dbg.triMap.d.data(), dbg.triMap.d.size() * 4);
+    put_img(mapx1, dbg.mapx1); put_img(mapy1, dbg.mapy1); put_img(mapx2, dbg.mapx2); put_img(mapy2, dbg.mapy2);
+    put_img(trImg1, dbg.trImg1); put_img(trImg2, dbg.trImg2);
+    put_img(lbmask, dbg.lbmask); put_img(lapBlend, dbg.lapBlend); put_img(unsharpOut, dbg.unsharp);
+    return 0;
+}
+
+}  // extern "C"

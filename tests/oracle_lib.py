@@ -1,0 +1,232 @@
+"""ctypes binding of oracle/liboracle.so for the tests (and bench.py's cpu_baseline leg).
+
+The oracle is test infrastructure: nothing under poppy_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            build()
+        _lib = C.CDLL(so)
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def clip_points(pts, cols, rows):
+    p = _f(pts).copy()
+    lib().orc_clip_points(_vp(p), len(p), cols, rows)
+    return p
+
+
+def make_uniq(pts):
+    p = _f(pts)
+    out = np.empty_like(p)
+    n = lib().orc_make_uniq(_vp(p), len(p), _vp(out))
+    return out[:n].copy()
+
+
+def morph_points(a, b, s):
+    a, b = _f(a), _f(b)
+    out = np.empty_like(a)
+    lib().orc_morph_points(_vp(a), _vp(b), len(a), C.c_float(s), _vp(out))
+    return out
+
+
+def delaunay(w, h, pts, max_tris=None):
+    p = _f(pts)
+    max_tris = max_tris or 2 * len(p) + 16
+    out = np.empty((max_tris, 6), np.float32)
+    n = lib().orc_delaunay(w, h, _vp(p), len(p), _vp(out), max_tris)
+    if n < 0:
+        raise ValueError("delaunay failed: %d" % n)
+    return out[:n].copy()
+
+
+def triangle_indices(tri6, pts):
+    t, p = _f(tri6), _f(pts)
+    out = np.empty((len(t), 3), np.int32)
+    n = lib().orc_triangle_indices(_vp(t), len(t), _vp(p), len(p), _vp(out))
+    return out[:n].copy()
+
+
+def triangle_int_points(idx3, pts):
+    idx = np.ascontiguousarray(idx3, np.int32)
+    p = _f(pts)
+    out = np.empty((len(idx), 3, 2), np.int32)
+    lib().orc_triangle_int_points(_vp(idx), len(idx), _vp(p), len(p), _vp(out))
+    return out
+
+
+def paint_triangles(w, h, tris):
+    t = np.ascontiguousarray(tris, np.int32).reshape(-1, 6)
+    out = np.empty((h, w), np.int32)
+    lib().orc_paint_triangles(w, h, _vp(t), len(t), _vp(out))
+    return out
+
+
+def invert33(m):
+    m = _f(m).reshape(-1, 9)
+    out = np.empty_like(m)
+    for i in range(len(m)):
+        lib().orc_invert33(_vp(m[i]), _vp(out[i]))
+    return out.reshape(-1, 3, 3)
+
+
+def homographies(t1, t2, ratio):
+    a = np.ascontiguousarray(t1, np.int32).reshape(-1, 6)
+    b = np.ascontiguousarray(t2, np.int32).reshape(-1, 6)
+    n = len(a)
+    H, M1, M2 = (np.empty((n, 3, 3), np.float32) for _ in range(3))
+    lib().orc_homographies(_vp(a), _vp(b), n, C.c_float(ratio), _vp(H), _vp(M1), _vp(M2))
+    return H, M1, M2
+
+
+def create_map(tri_map, mats):
+    tm = np.ascontiguousarray(tri_map, np.int32)
+    m = _f(mats).reshape(-1, 9)
+    h, w = tm.shape
+    mx, my = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    lib().orc_create_map(_vp(tm), w, h, _vp(m), len(m), _vp(mx), _vp(my))
+    return mx, my
+
+
+def remap(src, mapx, mapy):
+    s = np.ascontiguousarray(src, np.uint8)
+    sh, sw = s.shape[:2]
+    c = s.shape[2] if s.ndim == 3 else 1
+    mx, my = _f(mapx), _f(mapy)
+    h, w = mx.shape
+    out = np.empty((h, w, c) if s.ndim == 3 else (h, w), np.uint8)
+    lib().orc_remap(_vp(s), sw, sh, c, _vp(mx), _vp(my), w, h, _vp(out))
+    return out
+
+
+def bilinear_tab():
+    out = np.empty((1024, 4), np.int16)
+    lib().orc_bilinear_tab(_vp(out))
+    return out
+
+
+def u8_to_f32(a):
+    a = np.ascontiguousarray(a, np.uint8)
+    out = np.empty(a.shape, np.float32)
+    lib().orc_u8_to_f32(_vp(a), a.size, _vp(out))
+    return out
+
+
+def f32_to_u8(a):
+    a = _f(a)
+    out = np.empty(a.shape, np.uint8)
+    lib().orc_f32_to_u8(_vp(a), a.size, _vp(out))
+    return out
+
+
+def blend_mask(gabor2, mask_ratio):
+    g = _f(gabor2)
+    h, w = g.shape[:2]
+    out = np.empty((h, w), np.float32)
+    lib().orc_blend_mask(_vp(g), w, h, C.c_double(mask_ratio), _vp(out))
+    return out
+
+
+def _shape3(a):
+    h, w = a.shape[:2]
+    c = a.shape[2] if a.ndim == 3 else 1
+    return w, h, c
+
+
+def pyr_down(a):
+    a = _f(a)
+    w, h, c = _shape3(a)
+    out = np.empty(((h + 1) // 2, (w + 1) // 2, c) if a.ndim == 3 else ((h + 1) // 2, (w + 1) // 2), np.float32)
+    lib().orc_pyr_down(_vp(a), w, h, c, _vp(out))
+    return out
+
+
+def pyr_up(a, dw, dh):
+    a = _f(a)
+    w, h, c = _shape3(a)
+    out = np.empty((dh, dw, c) if a.ndim == 3 else (dh, dw), np.float32)
+    lib().orc_pyr_up(_vp(a), w, h, c, dw, dh, _vp(out))
+    return out
+
+
+def laplacian_blend(l, r, mask, levels):
+    l, r, m = _f(l), _f(r), _f(mask)
+    h, w = m.shape
+    out = np.empty((h, w, 3), np.float32)
+    lib().orc_laplacian_blend(_vp(l), _vp(r), _vp(m), w, h, levels, _vp(out))
+    return out
+
+
+def unsharp(a, amount, threshold):
+    a = _f(a)
+    h, w = a.shape[:2]
+    out, blur, med = (np.empty((h, w, 3), np.float32) for _ in range(3))
+    lib().orc_unsharp(_vp(a), w, h, C.c_float(amount), C.c_float(threshold), _vp(out), _vp(blur), _vp(med))
+    return out, blur, med
+
+
+def morph_images(c1, c2, gabor2, p1, p2, shape, mask, levels=64, debug=False):
+    c1 = np.ascontiguousarray(c1, np.uint8)
+    c2 = np.ascontiguousarray(c2, np.uint8)
+    g = _f(gabor2)
+    p1, p2 = _f(p1), _f(p2)
+    h, w = c1.shape[:2]
+    n = len(p1)
+    out = np.empty((h, w, 3), np.uint8)
+    mp = np.empty((n, 2), np.float32)
+    max_tris = 2 * n + 16
+    ntri = C.c_int(0)
+    d = {}
+    if debug:
+        d = dict(tri6=np.zeros((max_tris, 6), np.float32), idx3=np.zeros((max_tris, 3), np.int32),
+                 H=np.zeros((max_tris, 3, 3), np.float32), M1=np.zeros((max_tris, 3, 3), np.float32),
+                 M2=np.zeros((max_tris, 3, 3), np.float32), triMap=np.zeros((h, w), np.int32),
+                 mapx1=np.zeros((h, w), np.float32), mapy1=np.zeros((h, w), np.float32),
+                 mapx2=np.zeros((h, w), np.float32), mapy2=np.zeros((h, w), np.float32),
+                 trImg1=np.zeros((h, w, 3), np.uint8), trImg2=np.zeros((h, w, 3), np.uint8),
+                 lbmask=np.zeros((h, w), np.float32), lapBlend=np.zeros((h, w, 3), np.float32),
+                 unsharp=np.zeros((h, w, 3), np.float32))
+    g_ = lambda k: _vp(d[k]) if debug else None
+    rc = lib().orc_morph_images(_vp(c1), _vp(c2), _vp(g), w, h, _vp(p1), _vp(p2), n,
+                                C.c_double(shape), C.c_double(mask), levels, _vp(out), _vp(mp),
+                                max_tris, C.byref(ntri), g_("tri6"), g_("idx3"), g_("H"), g_("M1"), g_("M2"),
+                                g_("triMap"), g_("mapx1"), g_("mapy1"), g_("mapx2"), g_("mapy2"),
+                                g_("trImg1"), g_("trImg2"), g_("lbmask"), g_("lapBlend"), g_("unsharp"))
+    if rc:
+        raise ValueError("oracle morph_images failed: %d" % rc)
+    if debug:
+        nt = ntri.value
+        for k in ("idx3", "H", "M1", "M2"):
+            d[k] = d[k][:nt]
+        d["ntri"] = nt
+        return out, mp, d
+    return out, mp
