@@ -1,0 +1,127 @@
+/* poppy_hip.h — C ABI of the MI355X-native morph hot path (libpoppy_hip.so).
+ *
+ * Drop-in boundary for kallaballa/Poppy's feature-match -> dense-warp -> blend path.  Every entry
+ * point names the reference interface it replaces (paths relative to the reference tree; OCV =
+ * third/opencv-4.6.0/modules).  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Conventions
+ *   - images are 8-bit BGR, row stride in BYTES given explicitly (cv::Mat::step); float images are
+ *     tightly packed; point sets are float pairs (cv::Point2f).
+ *   - every function returns POPPY_OK (0) or a negative poppy_status; poppy_hip_last_error(ctx)
+ *     returns the message.  Nothing here calls exit() or throws across the boundary (the reference
+ *     does: src/poppy.hpp:162,229).
+ *   - one ctx per GPU, used from one host thread at a time; different ctx are independent.
+ *   - there is NO CPU fallback: without a usable gfx950 device poppy_hip_create() fails.
+ */
+#ifndef POPPY_HIP_H_
+#define POPPY_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct poppy_hip_ctx poppy_hip_ctx;
+
+typedef enum {
+    POPPY_OK = 0,
+    POPPY_E_ARG = -1,        /* bad argument (size mismatch, null pointer, ...)                       */
+    POPPY_E_DEVICE = -2,     /* HIP error / no gfx950 device                                           */
+    POPPY_E_RANGE = -3,      /* a point fell outside the image where the reference throws StsOutOfRange
+                                (OCV/imgproc/src/subdivision2d.cpp:287)                                */
+    POPPY_E_STATE = -4,      /* call order violated (e.g. render before pair_begin)                    */
+    POPPY_E_NOMATCH = -5,    /* no point pairs: caller should use poppy_hip_dissolve (src/poppy.hpp:125) */
+    POPPY_E_UNSUPPORTED = -6 /* stage outside this round's scope (fails loudly, never falls back)      */
+} poppy_status;
+
+/* Mirror of poppy::Settings (src/settings.hpp:14-27), passed by value instead of a global singleton. */
+typedef struct {
+    int number_of_frames;    /* 60  */
+    double match_tolerance;  /* 1.0 */
+    int max_keypoints;       /* 300 */
+    int pyramid_levels;      /* 64  */
+    int enable_radial_mask;  /* 0   */
+} poppy_settings;
+
+void poppy_settings_default(poppy_settings* s);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings);     /* replaces poppy::init, src/poppy.hpp:30-44 */
+void poppy_hip_destroy(poppy_hip_ctx* ctx);
+const char* poppy_hip_last_error(const poppy_hip_ctx* ctx);
+const char* poppy_hip_create_error(void);          /* message of the last failed poppy_hip_create() */
+
+/* ---- per-frame operator (inner boundary) ----------------------------------------------------
+ * poppy::morph_images(img1,img2,corrected1,corrected2,gabor2,gf1,gf2,dst,last,morphedPoints,
+ *                     srcPoints1,srcPoints2,shapeRatio,maskRatio,linear)   src/algo.hpp:26, src/algo.cpp:178-273
+ * Host buffers in, host buffers out, synchronous: this is the parity-test entry point.
+ * morphed_pts (n x 2) may be NULL.                                                               */
+int poppy_hip_morph_images(poppy_hip_ctx* ctx,
+                           const uint8_t* corrected1, size_t stride1,
+                           const uint8_t* corrected2, size_t stride2,
+                           const float* gabor2_f32x3, int width, int height,
+                           const float* src_points1, const float* src_points2, int n_points,
+                           double shape_ratio, double mask_ratio,
+                           uint8_t* dst, size_t dst_stride, float* morphed_pts);
+
+/* ---- resident pair API (throughput path; frames stay in HBM) ---------------------------------
+ * pair_load : uploads corrected1/2 + gabor2 and the matched point sets once per pair
+ *             (state that poppy::morph keeps in locals, src/poppy.hpp:114-157).
+ * render    : one morph_images step on the resident pair.  chain != 0 reproduces the default CLI
+ *             loop body (src/poppy.hpp:177-219): srcPoints1 <- morphedPoints and corrected1 <- frame.
+ *             dst may be NULL (frame stays on the device; poppy_hip_frame_device() exposes it).      */
+int poppy_hip_pair_load(poppy_hip_ctx* ctx,
+                        const uint8_t* corrected1, size_t stride1,
+                        const uint8_t* corrected2, size_t stride2,
+                        const float* gabor2_f32x3, int width, int height,
+                        const float* src_points1, const float* src_points2, int n_points);
+/* same, but the three images are already device pointers (tight rows) of this ctx's GPU */
+int poppy_hip_pair_load_device(poppy_hip_ctx* ctx, const void* d_corrected1, const void* d_corrected2,
+                               const void* d_gabor2_f32x3, int width, int height,
+                               const float* src_points1, const float* src_points2, int n_points);
+int poppy_hip_render(poppy_hip_ctx* ctx, double shape_ratio, double mask_ratio, int chain,
+                     uint8_t* dst, size_t dst_stride);
+int poppy_hip_pair_reset(poppy_hip_ctx* ctx);                 /* back to the state right after pair_load */
+const void* poppy_hip_frame_device(poppy_hip_ctx* ctx);       /* device pointer of the last frame (u8x3, tight) */
+int poppy_hip_sync(poppy_hip_ctx* ctx);                       /* wait for all queued work of this ctx */
+void* poppy_hip_stream(poppy_hip_ctx* ctx);                   /* the hipStream_t all kernels of this ctx run on */
+
+/* Reference frame scheduler (src/poppy.hpp:181-210): shape (= color) ratio of frame j.
+ * phase < 0 : default chained mode; 0 <= phase < 1 : phase mode (one frame).                          */
+double poppy_frame_ratio(int j, int number_of_frames, double phase);
+
+/* Whole frame loop of poppy::morph on the resident pair (src/poppy.hpp:177-235).  Each finished
+ * frame is handed to `write` (the Twriter::write(cv::Mat&) of the reference); the pointer is valid
+ * only during the call.  write may be NULL (frames stay on the device: benchmark mode).              */
+typedef void (*poppy_write_cb)(void* user, const uint8_t* bgr, int width, int height, size_t stride);
+int poppy_hip_morph_frames(poppy_hip_ctx* ctx, double phase, poppy_write_cb write, void* user);
+
+/* No-match fallback  img2*phase + img1*(1-phase)  (src/poppy.hpp:125-134; u8 addWeighted,
+ * OCV/core/src/arithm.simd.hpp:1705-1755).                                                          */
+int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, const uint8_t* img2, size_t stride2,
+                       int width, int height, double phase, uint8_t* dst, size_t dst_stride);
+
+/* ---- diagnostics: copy an intermediate of the LAST frame to the host (parity tests) -----------
+ * names: "triMap"(i32 HxW) "trImg1" "trImg2"(u8 HxWx3) "lbmask"(f32 HxW) "lapBlend" "unsharp"(f32 HxWx3)
+ * "unsharp" is only available after poppy_hip_set_debug(ctx, 1).                                       */
+int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
+int poppy_hip_debug_fetch(poppy_hip_ctx* ctx, const char* name, void* host_dst, size_t bytes);
+int poppy_hip_debug_triangles(poppy_hip_ctx* ctx, int* n_tris, int* idx3, float* M1, float* M2, int max_tris);
+
+/* Host-only part of one frame (no GPU touched): mesh planning of morph_images, src/algo.cpp:184-228 +
+ * the matrix inversions of create_map (:154-157).  Outputs may be NULL.  Used by the CPU test suite.  */
+int poppy_plan_frame(int width, int height, const float* src_points1, const float* src_points2, int n_points,
+                     double shape_ratio, int max_tris, int* n_tris, int* idx3, int* tri_xy,
+                     float* M1, float* M2, float* inv1, float* inv2, float* morphed_pts);
+
+/* per-kernel timing of the last poppy_hip_render/morph_images call, in milliseconds (HIP events on
+ * the ctx stream).  names/ms hold up to `max` entries; returns the number written.                    */
+int poppy_hip_last_timing(poppy_hip_ctx* ctx, const char** names, float* ms, int max);
+int poppy_hip_set_timing(poppy_hip_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPPY_HIP_H_ */

@@ -1,0 +1,210 @@
+"""ctypes binding of libpoppy_hip.so — mirrors include/poppy_hip.h one to one.
+
+Importing this module never touches the GPU; Context() does and raises if there is no usable
+gfx950 device or the extension is missing (no fallback path exists).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libpoppy_hip.so")
+
+_lib = None
+
+
+class PoppySettings(C.Structure):
+    _fields_ = [("number_of_frames", C.c_int), ("match_tolerance", C.c_double), ("max_keypoints", C.c_int),
+                ("pyramid_levels", C.c_int), ("enable_radial_mask", C.c_int)]
+
+
+WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
+
+# every symbol include/poppy_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "poppy_settings_default", "poppy_hip_create", "poppy_hip_destroy", "poppy_hip_last_error", "poppy_hip_create_error",
+    "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
+    "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
+    "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
+    "poppy_hip_last_timing", "poppy_hip_set_timing",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is the product; there is no fallback)")
+        L = C.CDLL(SO_PATH)
+        L.poppy_hip_create.restype = C.c_void_p
+        L.poppy_hip_create.argtypes = [C.c_int, C.POINTER(PoppySettings)]
+        L.poppy_hip_destroy.argtypes = [C.c_void_p]
+        L.poppy_hip_last_error.restype = C.c_char_p
+        L.poppy_hip_last_error.argtypes = [C.c_void_p]
+        L.poppy_hip_create_error.restype = C.c_char_p
+        L.poppy_frame_ratio.restype = C.c_double
+        L.poppy_frame_ratio.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.poppy_hip_frame_device.restype = C.c_void_p
+        L.poppy_hip_frame_device.argtypes = [C.c_void_p]
+        L.poppy_hip_stream.restype = C.c_void_p
+        L.poppy_hip_stream.argtypes = [C.c_void_p]
+        vp, sz, i, d = C.c_void_p, C.c_size_t, C.c_int, C.c_double
+        L.poppy_hip_morph_images.argtypes = [vp, vp, sz, vp, sz, vp, i, i, vp, vp, i, d, d, vp, sz, vp]
+        L.poppy_hip_pair_load.argtypes = [vp, vp, sz, vp, sz, vp, i, i, vp, vp, i]
+        L.poppy_hip_pair_load_device.argtypes = [vp, vp, vp, vp, i, i, vp, vp, i]
+        L.poppy_hip_render.argtypes = [vp, d, d, i, vp, sz]
+        L.poppy_hip_pair_reset.argtypes = [vp]
+        L.poppy_hip_sync.argtypes = [vp]
+        L.poppy_hip_morph_frames.argtypes = [vp, d, vp, vp]
+        L.poppy_hip_dissolve.argtypes = [vp, vp, sz, vp, sz, i, i, d, vp, sz]
+        L.poppy_hip_set_debug.argtypes = [vp, i]
+        L.poppy_hip_set_timing.argtypes = [vp, i]
+        L.poppy_hip_debug_fetch.argtypes = [vp, C.c_char_p, vp, sz]
+        L.poppy_hip_debug_triangles.argtypes = [vp, vp, vp, vp, vp, i]
+        L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.poppy_hip_last_timing.argtypes = [vp, vp, vp, i]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class PoppyError(RuntimeError):
+    pass
+
+
+def plan_frame(w, h, p1, p2, shape):
+    """Host-only mesh planning (no GPU)."""
+    p1 = np.ascontiguousarray(p1, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    n = len(p1)
+    mt = 2 * n + 16
+    nt = C.c_int(0)
+    idx3 = np.zeros((mt, 3), np.int32); tri = np.zeros((mt, 3, 2), np.int32)
+    M1, M2, i1, i2 = (np.zeros((mt, 3, 3), np.float32) for _ in range(4))
+    mp = np.zeros((n, 2), np.float32)
+    rc = lib().poppy_plan_frame(w, h, _p(p1), _p(p2), n, shape, mt, C.byref(nt), _p(idx3), _p(tri), _p(M1), _p(M2), _p(i1), _p(i2), _p(mp))
+    if rc:
+        raise PoppyError(f"poppy_plan_frame: {rc}")
+    t = nt.value
+    return dict(idx3=idx3[:t], tri_xy=tri[:t], M1=M1[:t], M2=M2[:t], inv1=i1[:t], inv2=i2[:t], morphed=mp)
+
+
+class Context:
+    def __init__(self, device=0, **settings):
+        L = lib()
+        s = PoppySettings()
+        L.poppy_settings_default(C.byref(s))
+        for k, v in settings.items():
+            setattr(s, k, v)
+        self.settings = s
+        self.h = L.poppy_hip_create(device, C.byref(s))
+        if not self.h:
+            raise PoppyError("poppy_hip_create failed: " + L.poppy_hip_create_error().decode())
+        self.w = self.h_ = 0
+
+    def close(self):
+        if self.h:
+            lib().poppy_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise PoppyError(f"{what}: {rc}: {lib().poppy_hip_last_error(self.h).decode()}")
+
+    def morph_images(self, c1, c2, gabor2, p1, p2, shape, mask):
+        c1 = np.ascontiguousarray(c1, np.uint8); c2 = np.ascontiguousarray(c2, np.uint8)
+        g = np.ascontiguousarray(gabor2, np.float32)
+        p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+        h, w = c1.shape[:2]
+        out = np.empty((h, w, 3), np.uint8)
+        mp = np.empty((len(p1), 2), np.float32)
+        self._chk(lib().poppy_hip_morph_images(self.h, _p(c1), w * 3, _p(c2), w * 3, _p(g), w, h, _p(p1), _p(p2), len(p1),
+                                               shape, mask, _p(out), w * 3, _p(mp)), "morph_images")
+        self.w, self.h_ = w, h
+        return out, mp
+
+    def pair_load(self, c1, c2, gabor2, p1, p2):
+        c1 = np.ascontiguousarray(c1, np.uint8); c2 = np.ascontiguousarray(c2, np.uint8)
+        g = np.ascontiguousarray(gabor2, np.float32)
+        p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+        h, w = c1.shape[:2]
+        self._chk(lib().poppy_hip_pair_load(self.h, _p(c1), w * 3, _p(c2), w * 3, _p(g), w, h, _p(p1), _p(p2), len(p1)), "pair_load")
+        self.w, self.h_ = w, h
+
+    def pair_load_device(self, d1, d2, dg, w, h, p1, p2):
+        p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+        self._chk(lib().poppy_hip_pair_load_device(self.h, d1, d2, dg, w, h, _p(p1), _p(p2), len(p1)), "pair_load_device")
+        self.w, self.h_ = w, h
+
+    def render(self, shape, mask, chain=False, fetch=True):
+        out = np.empty((self.h_, self.w, 3), np.uint8) if fetch else None
+        self._chk(lib().poppy_hip_render(self.h, shape, mask, int(chain), _p(out), self.w * 3), "render")
+        return out
+
+    def reset(self):
+        self._chk(lib().poppy_hip_pair_reset(self.h), "pair_reset")
+
+    def sync(self):
+        self._chk(lib().poppy_hip_sync(self.h), "sync")
+
+    def morph_frames(self, phase=-1.0, collect=True):
+        frames = []
+
+        def cb(user, ptr, w, h, stride):
+            frames.append(np.ctypeslib.as_array(ptr, shape=(h, stride))[:, :w * 3].reshape(h, w, 3).copy())
+        fn = WRITE_CB(cb) if collect else None
+        self._chk(lib().poppy_hip_morph_frames(self.h, phase, C.cast(fn, C.c_void_p) if fn else None, None), "morph_frames")
+        return frames
+
+    def dissolve(self, img1, img2, phase):
+        a = np.ascontiguousarray(img1, np.uint8); b = np.ascontiguousarray(img2, np.uint8)
+        h, w = a.shape[:2]
+        out = np.empty((h, w, 3), np.uint8)
+        self._chk(lib().poppy_hip_dissolve(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, _p(out), w * 3), "dissolve")
+        return out
+
+    def set_debug(self, on=True):
+        lib().poppy_hip_set_debug(self.h, int(on))
+
+    def set_timing(self, on=True):
+        lib().poppy_hip_set_timing(self.h, int(on))
+
+    def fetch(self, name):
+        h, w = self.h_, self.w
+        shapes = {"triMap": ((h, w), np.int32), "trImg1": ((h, w, 3), np.uint8), "trImg2": ((h, w, 3), np.uint8),
+                  "lbmask": ((h, w), np.float32), "m2": ((h, w), np.float32), "lapBlend": ((h, w, 3), np.float32),
+                  "unsharp": ((h, w, 3), np.float32)}
+        shp, dt = shapes[name]
+        out = np.empty(shp, dt)
+        self._chk(lib().poppy_hip_debug_fetch(self.h, name.encode(), _p(out), out.nbytes), "debug_fetch " + name)
+        return out
+
+    def triangles(self, max_tris=8192):
+        nt = C.c_int(0)
+        idx3 = np.zeros((max_tris, 3), np.int32)
+        M1 = np.zeros((max_tris, 3, 3), np.float32); M2 = np.zeros((max_tris, 3, 3), np.float32)
+        self._chk(lib().poppy_hip_debug_triangles(self.h, C.byref(nt), _p(idx3), _p(M1), _p(M2), max_tris), "debug_triangles")
+        t = nt.value
+        return idx3[:t], M1[:t], M2[:t]
+
+    def last_timing(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = lib().poppy_hip_last_timing(self.h, names, ms, 32)
+        return [(names[i].decode(), ms[i]) for i in range(n)]
+
+    def frame_device_ptr(self):
+        return lib().poppy_hip_frame_device(self.h)
+
+    def stream_ptr(self):
+        return lib().poppy_hip_stream(self.h)

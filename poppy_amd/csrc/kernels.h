@@ -1,0 +1,50 @@
+// kernels.h — launchers of the HIP kernels behind libpoppy_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace poppy_hip {
+
+struct PyrLevel {        // geometry of one pyramid level and of the pyrDown that PRODUCES it
+    int w, h;            // size of this level
+    size_t off3, off1;   // element offsets of this level inside the 3-channel / 1-channel pyramid buffers
+};
+
+// --- once per pair ---------------------------------------------------------------------------
+// m2 = 1 - gray(gabor2)   (src/algo.cpp:250-252)
+void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s);
+
+// --- once per frame --------------------------------------------------------------------------
+// triangle-id map: exact fillConvexPoly raster of every triangle, later index wins (atomicMax)
+void launch_raster(const int* tri_xy, int n_tris, int32_t* triMap, int w, int h, hipStream_t s);
+
+// fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2
+void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s);
+
+// lbmask = clamp((1-mr) - m2*mr)  (double arithmetic, one rounding; src/algo.cpp:254-257)
+void launch_mask(const float* m2, float* mask, int n_px, double alpha, double beta, hipStream_t s);
+
+// one Gaussian-pyramid reduction step for L, R (3 channels) and the mask (1 channel) in one launch.
+// level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
+void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s);
+
+// one collapse step: B_i = pyrUp(B_{i+1}) + mix(G_i - pyrUp(G_{i+1}))   (src/blend.hpp:58-77)
+void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
+                     const float* nL, const float* nR, const float* nB, float* outB,
+                     int w, int h, int nw, int nh, hipStream_t s);
+
+// all remaining (small) levels in one workgroup: reductions down to level `levels`, the smallest-level
+// mix and the collapse back up to level `first`; writes B_first.
+void launch_pyr_tail(float* pyrL, float* pyrR, float* pyrM, float* pyrB, const PyrLevel* d_levels,
+                     int first, int levels, hipStream_t s);
+
+// unsharp_mask(lapBlend, 1, amount, 0.3) + convertTo(CV_8U, 255)  (src/util.cpp:113-148, src/algo.cpp:263-265)
+void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
+                    int w, int h, float amount, float threshold, hipStream_t s);
+
+// u8 cross-dissolve fallback (src/poppy.hpp:129)
+void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s);
+
+}  // namespace poppy_hip

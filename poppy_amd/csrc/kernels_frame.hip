@@ -1,0 +1,555 @@
+// kernels_frame.hip — per-frame HIP kernels of the morph hot path for gfx950 (CDNA4, wave64).
+//
+// Every kernel here is HBM/latency bound byte work: no MFMA anywhere (there is no dense float
+// contraction on this path).  Arithmetic is bit-compatible with the reference's SSE3-baseline build:
+//   * this file is compiled with -ffp-contract=off: every float multiply and add rounds on its own;
+//   * divisions are IEEE (__fdiv_rn); float->int is round-half-even with the x86 "integer indefinite"
+//     result for out-of-range inputs;
+//   * where the reference's 4-lane SIMD body and scalar tail associate a sum differently, the split
+//     point is reproduced per element (pyramids.cpp:380-402,503-521,848-855,897).
+// Reference routines are cited per kernel (OCV = third/opencv-4.6.0/modules).
+#include "kernels.h"
+#include <climits>
+
+namespace poppy_hip {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// cvRound(float) on x86 (cvtss2si): half-to-even; NaN / |v| >= 2^31 -> 0x80000000
+__device__ __forceinline__ int cv_round_x86(float v) {
+    return (fabsf(v) < 2147483648.f) ? __float2int_rn(v) : INT_MIN;
+}
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+constexpr float kInv255 = (float)(1.0 / 255.0);
+
+// ------------------------------------------------------------------------------------------------
+// m2 = 1 - (0.114 B + 0.587 G + 0.299 R)      color_rgb.simd.hpp:594-643, matrix_expressions.cpp:1332
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gray_inv(const float* __restrict__ g, float* __restrict__ m2, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float b = g[3 * (size_t)i], gg = g[3 * (size_t)i + 1], r = g[3 * (size_t)i + 2];
+    float gray = b * 0.114f + gg * 0.587f + r * 0.299f;
+    m2[i] = 1.f - gray;
+}
+void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s) {
+    hipLaunchKernelGGL(k_gray_inv, dim3((n_px + 255) / 256), dim3(256), 0, s, gabor2, m2, n_px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lbmask                                         arithm.simd.hpp:1160-1216,1808 (double, one rounding)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mask(const float* __restrict__ m2, float* __restrict__ mask, int n, double alpha, double beta) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double t = (double)m2[i] * beta + 0.0;
+    float v = (float)(1.0 * alpha + t);
+    if (v < 0.f) v = 0.f;
+    if (v > 1.f) v = 1.f;
+    mask[i] = v;
+}
+void launch_mask(const float* m2, float* mask, int n_px, double alpha, double beta, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask, dim3((n_px + 255) / 256), dim3(256), 0, s, m2, mask, n_px, alpha, beta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangle-id raster.  One wave per triangle.
+//   outline: Line(LINE_8) = clipLine + 8-connected Bresenham, x increasing   drawing.cpp:80-297
+//   fill   : FillConvexPoly 16.16 edge walk, spans [(xl+.5)>>16, (xr+.5)>>16] drawing.cpp:1093-1255
+// fillConvexPoly paints triangles one after another, so a pixel ends with the id of the LAST triangle
+// that touches it; ids grow with the index, hence atomicMax.
+// ------------------------------------------------------------------------------------------------
+__device__ bool clip_segment(long long W, long long H, long long& x1, long long& y1, long long& x2, long long& y2) {
+    long long right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a; c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a; c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// lanes walk the Bresenham steps of one segment in parallel: the minor-axis offset after k steps
+// is the number of steps j < k whose running error was negative, which has the closed form below.
+__device__ void outline_segment(int32_t* map, int W, int H, int ax, int ay, int bx, int by, int value, int lane) {
+    if ((unsigned)ax >= (unsigned)W || (unsigned)bx >= (unsigned)W || (unsigned)ay >= (unsigned)H || (unsigned)by >= (unsigned)H) {
+        long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+        if (!clip_segment(W, H, x1, y1, x2, y2)) return;
+        ax = (int)x1; ay = (int)y1; bx = (int)x2; by = (int)y2;
+    }
+    int dx = bx - ax, dy = by - ay;
+    int x0 = ax, y0 = ay;
+    if (dx < 0) { dx = -dx; dy = -dy; x0 = bx; y0 = by; }
+    int sMinor = 1;
+    if (dy < 0) { dy = -dy; sMinor = -1; }
+    const bool steep = dy > dx;
+    int major = steep ? dy : dx, minor = steep ? dx : dy;
+    // err_0 = major - 2*minor; step j adds -2*minor and, when err_j < 0, +2*major and a minor step.
+    // minor offset after k steps: m_k = max(0, ceil((2*minor*k - major) / (2*major)))  (major > 0)
+    const int count = major + 1;
+    for (int k = lane; k < count; k += 64) {
+        int m = 0;
+        if (major > 0) {
+            long long num = 2LL * minor * k - major;
+            m = num > 0 ? (int)((num + 2LL * major - 1) / (2LL * major)) : 0;
+        }
+        int x, y;
+        if (!steep) { x = x0 + k; y = y0 + sMinor * m; }
+        else        { y = y0 + sMinor * k; x = x0 + m; }
+        atomicMax(&map[(size_t)y * W + x], value);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_raster(const int* __restrict__ tri_xy, int n_tris, int32_t* __restrict__ map, int W, int H) {
+    const int t = blockIdx.x;
+    if (t >= n_tris) return;
+    const int lane = threadIdx.x;
+    const int value = t + 1;
+    int vx[3], vy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
+
+    // outline: (v2->v0), (v0->v1), (v1->v2)
+    outline_segment(map, W, H, vx[2], vy[2], vx[0], vy[0], value, lane);
+    outline_segment(map, W, H, vx[0], vy[0], vx[1], vy[1], value, lane);
+    outline_segment(map, W, H, vx[1], vy[1], vx[2], vy[2], value, lane);
+
+    int imin = 0;
+    int xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        ymax = max(ymax, vy[i]); xmax = max(xmax, vx[i]); xmin = min(xmin, vx[i]);
+    }
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    ymax = min(ymax, H - 1);
+
+    // the edge state machine is tiny and wave-uniform: every lane runs it, lanes split each span
+    int eidx[2] = {imin, imin}, eye[2] = {ymin, ymin};
+    const int edi[2] = {1, 2};
+    long long ex[2] = {-65536, -65536}, edx[2] = {0, 0};
+    int edges = 3;
+    int y = ymin;
+    do {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (y >= eye[i]) {
+                int idx0 = eidx[i], di = edi[i];
+                int idx = idx0 + di; if (idx >= 3) idx -= 3;
+                for (; edges-- > 0;) {
+                    int ty = vy[idx];
+                    if (ty > y) {
+                        long long xs = (long long)vx[idx0] << 16, xe = (long long)vx[idx] << 16;
+                        eye[i] = ty;
+                        edx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        ex[i] = xs;
+                        eidx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di; if (idx >= 3) idx -= 3;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int l = ex[0] > ex[1] ? 1 : 0;
+            int xx1 = (int)((ex[l] + 32768) >> 16);
+            int xx2 = (int)((ex[1 - l] + 32768) >> 16);
+            if (xx2 >= 0 && xx1 < W) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= W) xx2 = W - 1;
+                int32_t* row = map + (size_t)y * W;
+                for (int x = xx1 + lane; x <= xx2; x += 64) atomicMax(&row[x], value);
+            }
+        }
+        ex[0] += edx[0];
+        ex[1] += edx[1];
+    } while (++y <= ymax);
+}
+void launch_raster(const int* tri_xy, int n_tris, int32_t* triMap, int w, int h, hipStream_t s) {
+    if (n_tris > 0) hipLaunchKernelGGL(k_raster, dim3(n_tris), dim3(64), 0, s, tri_xy, n_tris, triMap, w, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused create_map + remap (+ both sources).  algo.cpp:146-176, imgwarp.cpp:1197-1234,721-731,808-852
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_weights(int fx, int fy, int& w00, int& w01, int& w10, int& w11) {
+    // BilinearTab_i: saturate_cast<short>((1-fy/32)(1-fx/32)*32768) etc.  All products are exact; only the
+    // very first entry saturates (32768 -> 32767) and its deficit goes to tap [1][1] (imgwarp.cpp:251-267).
+    w00 = (32 - fx) * (32 - fy) * 32; w01 = fx * (32 - fy) * 32;
+    w10 = (32 - fx) * fy * 32;        w11 = fx * fy * 32;
+    if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
+}
+
+__device__ __forceinline__ void sample3(const uint8_t* __restrict__ src, int W, int H, float mx, float my, uint8_t* out) {
+    int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
+    int w00, w01, w10, w11;
+    bilinear_weights(sx & 31, sy & 31, w00, w01, w10, w11);
+    int ix = sx >> 5, iy = sy >> 5;
+    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
+    bool x0 = (unsigned)ix < (unsigned)W, x1 = (unsigned)(ix + 1) < (unsigned)W;
+    bool y0 = (unsigned)iy < (unsigned)H, y1 = (unsigned)(iy + 1) < (unsigned)H;
+    const uint8_t* p00 = src + ((size_t)iy * W + ix) * 3;
+    const uint8_t* p10 = p00 + (size_t)W * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v00 = (x0 && y0) ? p00[k] : 0, v01 = (x1 && y0) ? p00[3 + k] : 0;
+        int v10 = (x0 && y1) ? p10[k] : 0, v11 = (x1 && y1) ? p10[3 + k] : 0;
+        int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        out[k] = sat_u8((acc + (1 << 14)) >> 15);
+    }
+}
+
+__device__ __forceinline__ void map_point(const float* __restrict__ h, int x, int y, float& mx, float& my) {
+    float fx = (float)x, fy = (float)y;
+    float z = h[6] * fx + h[7] * fy + h[8];
+    if (z == 0.f) z = 0.00001f;
+    mx = __fdiv_rn(h[0] * fx + h[1] * fy + h[2], z);
+    my = __fdiv_rn(h[3] * fx + h[4] * fy + h[5], z);
+}
+
+__global__ void __launch_bounds__(256) k_warp(const int32_t* __restrict__ triMap, const float* __restrict__ inv1, const float* __restrict__ inv2,
+                                              const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
+                                              uint8_t* __restrict__ tr1, uint8_t* __restrict__ tr2, int W, int H) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= W) return;
+    size_t p = (size_t)y * W + x;
+    int idx = triMap[p] - 1;
+    float mx1 = (float)x, my1 = (float)y, mx2 = mx1, my2 = my1;
+    if (idx >= 0) {
+        map_point(inv1 + (size_t)idx * 9, x, y, mx1, my1);
+        map_point(inv2 + (size_t)idx * 9, x, y, mx2, my2);
+    }
+    uint8_t o1[3], o2[3];
+    sample3(c1, W, H, mx1, my1, o1);
+    sample3(c2, W, H, mx2, my2, o2);
+    tr1[p * 3] = o1[0]; tr1[p * 3 + 1] = o1[1]; tr1[p * 3 + 2] = o1[2];
+    tr2[p * 3] = o2[0]; tr2[p * 3 + 1] = o2[1]; tr2[p * 3 + 2] = o2[2];
+}
+void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gaussian pyramid primitives, evaluated per output element.
+//   pyrDown_: pyramids.cpp:745-900; float SIMD bodies :344-402 (H) and :503-521 (V)
+//   pyrUp_  : pyramids.cpp:903-1005 (H scalar only; V SIMD == scalar bitwise)
+// ------------------------------------------------------------------------------------------------
+template <bool U8> __device__ __forceinline__ float ld(const void* p, size_t i) {
+    if (U8) return (float)((const uint8_t*)p)[i] * kInv255;      // convertTo(CV_32F, 1/255): v*a + 0
+    return ((const float*)p)[i];
+}
+
+struct DownGeom {            // host-computed constants of one pyrDown (source sw x sh, cn channels)
+    int sw, sh, dw, dh, cn;
+    int w0;                  // width0 in pixels: columns reachable without the right border table
+    int hBodyEnd;            // element index where the SIMD-body association of the H pass stops
+    int vBodyEnd;            // same for the V pass: (dw*cn/4)*4
+};
+
+__host__ __device__ inline DownGeom make_down_geom(int sw, int sh, int cn) {
+    DownGeom g;
+    g.sw = sw; g.sh = sh; g.cn = cn; g.dw = (sw + 1) / 2; g.dh = (sh + 1) / 2;
+    int w0 = (sw - 3) / 2 + 1;                 // C division truncates toward zero, as in the reference
+    g.w0 = w0 < g.dw ? w0 : g.dw;
+    int width = g.w0 * cn - cn;                // elements offered to the SIMD body (starts after pixel 0)
+    int covered = 0;
+    if (width >= 4) covered = (cn == 1) ? ((width - 4) / 4 + 1) * 4 : ((width - 4) / 3 + 1) * 3;
+    g.hBodyEnd = cn + covered;
+    g.vBodyEnd = (g.dw * cn / 4) * 4;
+    return g;
+}
+
+template <bool U8>
+__device__ __forceinline__ float pyrdown_elem(const void* src, const DownGeom& g, int y, int xe) {
+    const int cn = g.cn;
+    const int px = xe / cn, c = xe - px * cn;
+    const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
+    int col[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) col[k] = reflect101(2 * px + k - 2, g.sw) * cn + c;
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int sy = reflect101(2 * y + k - 2, g.sh);
+        size_t base = (size_t)sy * g.sw * cn;
+        float t0 = ld<U8>(src, base + col[0]), t1 = ld<U8>(src, base + col[1]), t2 = ld<U8>(src, base + col[2]);
+        float t3 = ld<U8>(src, base + col[3]), t4 = ld<U8>(src, base + col[4]);
+        r[k] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                     : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+    }
+    const float s = 1.f / 256;
+    return (xe < g.vBodyEnd) ? ((r[1] + r[3] + r[2]) * 4.f + (r[0] + r[4] + (r[2] + r[2]))) * s
+                             : (r[2] * 6.f + (r[1] + r[3]) * 4.f + r[0] + r[4]) * s;
+}
+
+// horizontal pyrUp value of source row `row` at destination element dxe
+__device__ __forceinline__ float pyrup_h(const float* __restrict__ row, int sw, int cn, int dxe) {
+    const int dpx = dxe / cn, c = dxe - dpx * cn;
+    const int spx = dpx >> 1;
+    const bool odd = dpx & 1;
+    if (sw == 1) return row[c] * 8.f;
+    if (spx == 0) {
+        float s0 = row[c], s1 = row[cn + c];
+        return odd ? (s0 + s1) * 4.f : s0 * 6.f + s1 * 2.f;
+    }
+    if (spx >= sw - 1) {
+        float sm = row[(sw - 2) * cn + c], s0 = row[(sw - 1) * cn + c];
+        return odd ? s0 * 8.f : sm + s0 * 7.f;
+    }
+    float sm = row[(spx - 1) * cn + c], s0 = row[spx * cn + c], sp = row[(spx + 1) * cn + c];
+    return odd ? (s0 + sp) * 4.f : sm + s0 * 6.f + sp;
+}
+
+__device__ __forceinline__ float pyrup_elem(const float* __restrict__ src, int sw, int sh, int cn, int dy, int dxe) {
+    const int sy = dy >> 1;
+    const size_t stride = (size_t)sw * cn;
+    const float s = 1.f / 64;
+    if (dy & 1) {
+        int syp = reflect101((sy + 1) * 2, sh * 2) >> 1;
+        float r1 = pyrup_h(src + sy * stride, sw, cn, dxe), r2 = pyrup_h(src + syp * stride, sw, cn, dxe);
+        return ((r1 + r2) * 4.f) * s;
+    }
+    int sym = reflect101((sy - 1) * 2, sh * 2) >> 1, syp = reflect101((sy + 1) * 2, sh * 2) >> 1;
+    float r0 = pyrup_h(src + sym * stride, sw, cn, dxe), r1 = pyrup_h(src + sy * stride, sw, cn, dxe);
+    float r2 = pyrup_h(src + syp * stride, sw, cn, dxe);
+    return (r0 + r1 * 6.f + r2) * s;
+}
+
+// blend of one Laplacian level (blend.hpp:67-77): A = lapL*m; B = lapR*(1-m); A + B
+__device__ __forceinline__ float mix_lr(float l, float r, float m) {
+    float a = l * m;
+    float anti = 1.f - m;
+    float b = r * anti;
+    return a + b;
+}
+
+// --- one reduction step, L / R / mask selected by blockIdx.z -------------------------------------
+template <bool U8>
+__global__ void __launch_bounds__(256) k_pyrdown(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                 float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                 DownGeom g3, DownGeom g1) {
+    const int which = blockIdx.z;
+    const int xe = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (which == 2) {
+        if (xe >= g1.dw) return;
+        dstM[(size_t)y * g1.dw + xe] = pyrdown_elem<false>(srcM, g1, y, xe);
+    } else {
+        if (xe >= g3.dw * 3) return;
+        const void* src = which ? srcR : srcL;
+        float* dst = which ? dstR : dstL;
+        dst[(size_t)y * g3.dw * 3 + xe] = pyrdown_elem<U8>(src, g3, y, xe);
+    }
+}
+void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
+    DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+    dim3 grid((g3.dw * 3 + 255) / 256, g3.dh, 3);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown<true>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
+    else        hipLaunchKernelGGL(k_pyrdown<false>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
+}
+
+// --- one collapse step ----------------------------------------------------------------------------
+template <bool U8>
+__device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
+                                               const float* nB, int w, int h, int nw, int nh, int y, int xe) {
+    const size_t i = (size_t)y * w * 3 + xe;
+    const float m = gM[(size_t)y * w + xe / 3];
+    float lapL = ld<U8>(gL, i) - pyrup_elem(nL, nw, nh, 3, y, xe);
+    float lapR = ld<U8>(gR, i) - pyrup_elem(nR, nw, nh, 3, y, xe);
+    float res = mix_lr(lapL, lapR, m);
+    return pyrup_elem(nB, nw, nh, 3, y, xe) + res;
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                  const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                  float* __restrict__ outB, int w, int h, int nw, int nh) {
+    const int xe = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (xe >= w * 3) return;
+    outB[(size_t)y * w * 3 + xe] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, xe);
+}
+void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
+                     float* outB, int w, int h, int nw, int nh, hipStream_t s) {
+    dim3 grid((w * 3 + 255) / 256, h);
+    if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+}
+
+// --- all small levels in one workgroup ------------------------------------------------------------
+// levels first..levels-1 are reduced to first+1..levels, the smallest level is mixed, then levels
+// levels-1..first are collapsed.  Global memory written by the block is re-read by the same block
+// after __syncthreads(), which is sufficient inside one workgroup.
+__global__ void __launch_bounds__(1024) k_pyr_tail(float* __restrict__ pyrL, float* __restrict__ pyrR, float* __restrict__ pyrM,
+                                                   float* __restrict__ pyrB, const PyrLevel* __restrict__ lv, int first, int levels) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int i = first; i < levels; ++i) {
+        const PyrLevel s = lv[i], d = lv[i + 1];
+        DownGeom g3 = make_down_geom(s.w, s.h, 3), g1 = make_down_geom(s.w, s.h, 1);
+        const int n3 = d.w * d.h * 3, n1 = d.w * d.h;
+        for (int e = tid; e < 2 * n3 + n1; e += nth) {
+            if (e < n3) { int y = e / (d.w * 3), xe = e - y * d.w * 3; pyrL[d.off3 + e] = pyrdown_elem<false>(pyrL + s.off3, g3, y, xe); }
+            else if (e < 2 * n3) { int q = e - n3; int y = q / (d.w * 3), xe = q - y * d.w * 3; pyrR[d.off3 + q] = pyrdown_elem<false>(pyrR + s.off3, g3, y, xe); }
+            else { int q = e - 2 * n3; int y = q / d.w, xe = q - y * d.w; pyrM[d.off1 + q] = pyrdown_elem<false>(pyrM + s.off1, g1, y, xe); }
+        }
+        __syncthreads();
+    }
+    {
+        const PyrLevel t = lv[levels];
+        for (int e = tid; e < t.w * t.h * 3; e += nth)
+            pyrB[t.off3 + e] = mix_lr(pyrL[t.off3 + e], pyrR[t.off3 + e], pyrM[t.off1 + e / 3]);
+        __syncthreads();
+    }
+    for (int i = levels - 1; i >= first; --i) {
+        const PyrLevel c = lv[i], n = lv[i + 1];
+        for (int e = tid; e < c.w * c.h * 3; e += nth) {
+            int y = e / (c.w * 3), xe = e - y * c.w * 3;
+            pyrB[c.off3 + e] = collapse_elem<false>(pyrL + c.off3, pyrR + c.off3, pyrM + c.off1, pyrL + n.off3, pyrR + n.off3,
+                                                    pyrB + n.off3, c.w, c.h, n.w, n.h, y, xe);
+        }
+        __syncthreads();
+    }
+}
+void launch_pyr_tail(float* pyrL, float* pyrR, float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels, hipStream_t s) {
+    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(1024), 0, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels);
+}
+
+// ------------------------------------------------------------------------------------------------
+// unsharp_mask(radius 1 -> 9 taps) + u8 conversion.            util.cpp:113-148, algo.cpp:263-265
+//   row pass   : s = x0*k0; s = xk*kk + s                      filter.simd.hpp:1682-1730,2477-2487
+//   column pass: s = ky0*c + 0; s = kyk*(S[+k] + S[-k]) + s    filter.simd.hpp:2753-2759
+//   median 3x3 : 19-exchange sorting network, replicated edges median_blur.simd.hpp:692-713
+//   norm       : sqrt of a double sum of squares               matx.hpp:929-932
+// ------------------------------------------------------------------------------------------------
+__constant__ float c_gauss9[9] = {0x1.18a9c4p-13f, 0x1.22724cp-8f, 0x1.ba4b9ap-5f, 0x1.ef8ebap-3f, 0x1.9884a4p-2f,
+                                  0x1.ef8ebap-3f, 0x1.ba4b9ap-5f, 0x1.22724cp-8f, 0x1.18a9c4p-13f};
+
+__global__ void __launch_bounds__(256) k_gauss_row(const float* __restrict__ src, float* __restrict__ dst, int W, int H) {
+    const int xe = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (xe >= W * 3) return;
+    const int px = xe / 3, c = xe - px * 3;
+    const float* row = src + (size_t)y * W * 3;
+    float acc = row[reflect101(px - 4, W) * 3 + c] * c_gauss9[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) acc = row[reflect101(px - 4 + k, W) * 3 + c] * c_gauss9[k] + acc;
+    dst[(size_t)y * W * 3 + xe] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_gauss_col_diff(const float* __restrict__ src, const float* __restrict__ tmp, float* __restrict__ diff, int W, int H) {
+    const int xe = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (xe >= W * 3) return;
+    const size_t stride = (size_t)W * 3;
+    float acc = c_gauss9[4] * tmp[y * stride + xe] + 0.f;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k)
+        acc = c_gauss9[4 + k] * (tmp[reflect101(y + k, H) * stride + xe] + tmp[reflect101(y - k, H) * stride + xe]) + acc;
+    diff[y * stride + xe] = src[y * stride + xe] - acc;
+}
+
+__device__ __forceinline__ void mnmx(float& a, float& b) {
+    float t = a;
+    a = (b < a) ? b : a;
+    b = (b < t) ? t : b;
+}
+
+__device__ __forceinline__ float median9(const float* __restrict__ d, int W, int H, int x, int y, int c) {
+    if (W == 1 || H == 1) {     // 1-D special case of the reference (median_blur.simd.hpp:694-711)
+        int len = W + H - 1, i = (H == 1) ? x : y;
+        float p0 = d[(size_t)(i > 0 ? i - 1 : i) * 3 + c], p1 = d[(size_t)i * 3 + c], p2 = d[(size_t)(i < len - 1 ? i + 1 : i) * 3 + c];
+        mnmx(p0, p1); mnmx(p1, p2); mnmx(p0, p1);
+        return p1;
+    }
+    const int x0 = x > 0 ? x - 1 : x, x2 = x < W - 1 ? x + 1 : x;
+    const float* r0 = d + (size_t)(y > 0 ? y - 1 : 0) * W * 3;
+    const float* r1 = d + (size_t)y * W * 3;
+    const float* r2 = d + (size_t)(y < H - 1 ? y + 1 : H - 1) * W * 3;
+    float p0 = r0[x0 * 3 + c], p1 = r0[x * 3 + c], p2 = r0[x2 * 3 + c];
+    float p3 = r1[x0 * 3 + c], p4 = r1[x * 3 + c], p5 = r1[x2 * 3 + c];
+    float p6 = r2[x0 * 3 + c], p7 = r2[x * 3 + c], p8 = r2[x2 * 3 + c];
+    mnmx(p1, p2); mnmx(p4, p5); mnmx(p7, p8); mnmx(p0, p1);
+    mnmx(p3, p4); mnmx(p6, p7); mnmx(p1, p2); mnmx(p4, p5);
+    mnmx(p7, p8); mnmx(p0, p3); mnmx(p5, p8); mnmx(p4, p7);
+    mnmx(p3, p6); mnmx(p1, p4); mnmx(p2, p5); mnmx(p4, p7);
+    mnmx(p4, p2); mnmx(p6, p4); mnmx(p4, p2);
+    return p4;
+}
+
+__global__ void __launch_bounds__(256) k_median_apply(const float* __restrict__ src, const float* __restrict__ diff, uint8_t* __restrict__ out,
+                                                      float* __restrict__ outF, int W, int H, float amount, float threshold) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float d0 = median9(diff, W, H, x, y, 0), d1 = median9(diff, W, H, x, y, 1), d2 = median9(diff, W, H, x, y, 2);
+    double s = (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2;
+    const size_t p = ((size_t)y * W + x) * 3;
+    float v0 = src[p], v1 = src[p + 1], v2 = src[p + 2];
+    if (sqrt(s) >= (double)threshold) {
+        v0 = v0 + amount * d0; v1 = v1 + amount * d1; v2 = v2 + amount * d2;
+    }
+    if (outF) { outF[p] = v0; outF[p + 1] = v1; outF[p + 2] = v2; }
+    out[p] = sat_u8(cv_round_x86(v0 * 255.f + 0.f));
+    out[p + 1] = sat_u8(cv_round_x86(v1 * 255.f + 0.f));
+    out[p + 2] = sat_u8(cv_round_x86(v2 * 255.f + 0.f));
+}
+
+void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
+                    int w, int h, float amount, float threshold, hipStream_t s) {
+    dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_gauss_row, ge, dim3(256), 0, s, src, tmpRow, w, h);
+    hipLaunchKernelGGL(k_gauss_col_diff, ge, dim3(256), 0, s, src, tmpRow, diff, w, h);
+    hipLaunchKernelGGL(k_median_apply, gp, dim3(256), 0, s, src, diff, out_u8, out_f32_or_null, w, h, amount, threshold);
+}
+
+// ------------------------------------------------------------------------------------------------
+// u8 addWeighted fallback: dst = sat(round(a*wa + b*wb))          arithm.simd.hpp:131-135,1705-1755
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dissolve(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ dst, size_t n, float wa, float wb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = (float)a[i] * wa + ((float)b[i] * wb + 0.f);
+    dst[i] = sat_u8(cv_round_x86(v));
+}
+void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s) {
+    hipLaunchKernelGGL(k_dissolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, dst, n, wa, wb);
+}
+
+}  // namespace poppy_hip

@@ -1,0 +1,479 @@
+// poppy_hip.cpp — context, HBM layout and orchestration behind the C ABI of include/poppy_hip.h.
+//
+// Host C++ (as the reference's own morph driver is, src/poppy.hpp:46-248) calling the hand-written
+// gfx950 kernels of kernels_*.hip.  Per pair everything stays resident in HBM; per frame the host only
+// plans the mesh (frame_plan.cpp, ~1k triangles) and uploads ~100 KB through a pinned ring.
+//
+// HBM layout for a W x H pair (P = W*H):
+//   c1, c2            u8x3   3P each     sources (c1 is replaced by the previous frame in chained mode)
+//   m2                f32    4P          1 - gray(gabor2), loop invariant (algo.cpp:250-252)
+//   triMap            i32    4P          triangle id per pixel
+//   tr1, tr2          u8x3   3P each     warped sources (never widened to float in memory)
+//   pyrL, pyrR        f32x3  ~4P each    Gaussian levels 1..levels of the warped sources
+//   pyrM              f32    ~5.3P       mask levels 0..levels
+//   pyrB              f32x3  ~16P        blended levels; level 0 is lapBlend
+//   tmp, diff         f32x3  12P each    unsharp scratch
+//   frame[2]          u8x3   3P each     output ring (chained mode feeds one back as c1)
+// No CPU fallback exists in this library: every entry point either runs the kernels or fails.
+#include "../../include/poppy_hip.h"
+#include "frame_plan.h"
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace poppy_hip;
+
+static std::string g_create_error;
+
+struct poppy_hip_ctx {
+    int device = 0;
+    poppy_settings cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int W = 0, H = 0;
+    bool pair_ready = false;
+    // resident buffers
+    uint8_t *c1 = nullptr, *c2 = nullptr, *tr1 = nullptr, *tr2 = nullptr, *frame[2] = {nullptr, nullptr};
+    float *gabor2 = nullptr, *m2 = nullptr, *pyrL = nullptr, *pyrR = nullptr, *pyrM = nullptr, *pyrB = nullptr, *tmp = nullptr, *diff = nullptr;
+    float* unsharpF = nullptr;
+    int32_t* triMap = nullptr;
+    const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
+    int frame_slot = 0, last_slot = -1;
+    std::vector<PyrLevel> levels;        // 0..pyramid_levels
+    PyrLevel* d_levels = nullptr;
+    int first_tail = 1;
+    // points
+    std::vector<P2f> pts1_0, pts1, pts2;
+    // per-frame plan upload ring (pinned host + device), so the host can plan ahead of the GPU
+    static const int kRing = 4;
+    int max_tris = 0;
+    int* h_tri[kRing] = {};  float* h_inv[kRing] = {};
+    int* d_tri[kRing] = {};  float* d_inv[kRing] = {};
+    hipEvent_t ring_done[kRing] = {};
+    int ring_pos = 0;
+    FramePlan plan;
+    // diagnostics
+    bool debug = false, timing = false;
+    std::vector<std::pair<const char*, float>> last_times;
+    std::vector<hipEvent_t> ev;
+    // staging for host-image entry points
+    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return POPPY_E_DEVICE;                                                                    \
+        }                                                                                             \
+    } while (0)
+
+static int fail(poppy_hip_ctx* c, int code, const char* msg) { c->err = msg; return code; }
+
+extern "C" {
+
+void poppy_settings_default(poppy_settings* s) {
+    s->number_of_frames = 60; s->match_tolerance = 1.0; s->max_keypoints = 300; s->pyramid_levels = 64; s->enable_radial_mask = 0;
+}
+const char* poppy_hip_create_error(void) { return g_create_error.c_str(); }
+const char* poppy_hip_last_error(const poppy_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = "no HIP device (libpoppy_hip has no CPU fallback)"; return nullptr; }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return nullptr; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
+    poppy_hip_ctx* c = new poppy_hip_ctx();
+    c->device = device;
+    if (settings) c->cfg = *settings; else poppy_settings_default(&c->cfg);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) (void)hipEventCreateWithFlags(&c->ring_done[i], hipEventDisableTiming);
+    return c;
+}
+
+static void free_pair(poppy_hip_ctx* c) {
+    void* bufs[] = {c->c1, c->c2, c->tr1, c->tr2, c->frame[0], c->frame[1], c->gabor2, c->m2, c->pyrL, c->pyrR, c->pyrM, c->pyrB,
+                    c->tmp, c->diff, c->unsharpF, c->triMap, c->d_levels};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    c->c1 = c->c2 = c->tr1 = c->tr2 = c->frame[0] = c->frame[1] = nullptr;
+    c->gabor2 = c->m2 = c->pyrL = c->pyrR = c->pyrM = c->pyrB = c->tmp = c->diff = c->unsharpF = nullptr;
+    c->triMap = nullptr; c->d_levels = nullptr;
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
+        if (c->h_tri[i]) (void)hipHostFree(c->h_tri[i]);
+        if (c->h_inv[i]) (void)hipHostFree(c->h_inv[i]);
+        if (c->d_tri[i]) (void)hipFree(c->d_tri[i]);
+        if (c->d_inv[i]) (void)hipFree(c->d_inv[i]);
+        c->h_tri[i] = nullptr; c->h_inv[i] = nullptr; c->d_tri[i] = nullptr; c->d_inv[i] = nullptr;
+    }
+    c->max_tris = 0; c->W = c->H = 0; c->pair_ready = false;
+}
+
+void poppy_hip_destroy(poppy_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_pair(c);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) (void)hipEventDestroy(c->ring_done[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
+int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on != 0; return POPPY_OK; }
+void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return POPPY_OK; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+static int ensure_ring(poppy_hip_ctx* c, int n_points) {
+    int need = 2 * n_points + 16;            // a planar triangulation of n points has < 2n triangles
+    if (need <= c->max_tris) return POPPY_OK;
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
+        if (c->h_tri[i]) (void)hipHostFree(c->h_tri[i]);
+        if (c->h_inv[i]) (void)hipHostFree(c->h_inv[i]);
+        if (c->d_tri[i]) (void)hipFree(c->d_tri[i]);
+        if (c->d_inv[i]) (void)hipFree(c->d_inv[i]);
+        HIPCHK(c, hipHostMalloc((void**)&c->h_tri[i], (size_t)need * 6 * sizeof(int)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_inv[i], (size_t)need * 18 * sizeof(float)));
+        HIPCHK(c, hipMalloc((void**)&c->d_tri[i], (size_t)need * 6 * sizeof(int)));
+        HIPCHK(c, hipMalloc((void**)&c->d_inv[i], (size_t)need * 18 * sizeof(float)));
+    }
+    c->max_tris = need;
+    return POPPY_OK;
+}
+
+static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
+    if (c->W == W && c->H == H && c->c1) return POPPY_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_pair(c);
+    if (c->cfg.pyramid_levels < 1 || c->cfg.pyramid_levels > 256) return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels must be in [1,256]");
+    const size_t P = (size_t)W * H;
+    const int L = c->cfg.pyramid_levels;
+    c->levels.resize(L + 1);
+    size_t off3 = 0, off1 = 0;
+    int w = W, h = H;
+    for (int i = 0; i <= L; ++i) {
+        c->levels[i] = PyrLevel{w, h, off3, off1};
+        off3 += (size_t)w * h * 3; off1 += (size_t)w * h;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    c->first_tail = L;
+    for (int i = 1; i <= L; ++i)
+        if ((size_t)c->levels[i].w * c->levels[i].h <= 4096) { c->first_tail = i; break; }
+    HIPCHK(c, hipMalloc((void**)&c->c1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3));
+    HIPCHK(c, hipMalloc((void**)&c->tr1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->tr2, P * 3));
+    HIPCHK(c, hipMalloc((void**)&c->frame[0], P * 3)); HIPCHK(c, hipMalloc((void**)&c->frame[1], P * 3));
+    HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12)); HIPCHK(c, hipMalloc((void**)&c->m2, P * 4));
+    HIPCHK(c, hipMalloc((void**)&c->triMap, P * 4));
+    HIPCHK(c, hipMalloc((void**)&c->pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&c->pyrR, off3 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&c->pyrM, off1 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&c->diff, P * 12));
+    HIPCHK(c, hipMalloc((void**)&c->unsharpF, P * 12));
+    HIPCHK(c, hipMalloc((void**)&c->d_levels, sizeof(PyrLevel) * (L + 1)));
+    HIPCHK(c, hipMemcpy(c->d_levels, c->levels.data(), sizeof(PyrLevel) * (L + 1), hipMemcpyHostToDevice));
+    c->W = W; c->H = H;
+    return POPPY_OK;
+}
+
+static int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n) {
+    if (n < 0 || (n > 0 && (!p1 || !p2))) return fail(c, POPPY_E_ARG, "bad point sets");
+    c->pts1_0.resize(n); c->pts2.resize(n);
+    if (n) { memcpy(c->pts1_0.data(), p1, (size_t)n * 8); memcpy(c->pts2.data(), p2, (size_t)n * 8); }
+    c->pts1 = c->pts1_0;
+    return ensure_ring(c, n);
+}
+
+static int finish_pair_load(poppy_hip_ctx* c) {
+    launch_gray_inv(c->gabor2, c->m2, c->W * c->H, c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->cur1 = c->c1; c->frame_slot = 0; c->last_slot = -1; c->pair_ready = true;
+    return POPPY_OK;
+}
+
+static int stage_host(poppy_hip_ctx* c, size_t bytes) {
+    if (bytes <= c->h_stage_bytes) return POPPY_OK;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes));
+    c->h_stage_bytes = bytes;
+    return POPPY_OK;
+}
+
+struct Timer {
+    poppy_hip_ctx* c; size_t n = 0;
+    explicit Timer(poppy_hip_ctx* c_) : c(c_) { if (c->timing) c->last_times.clear(); }
+    void mark(const char* name) {
+        if (!c->timing) return;
+        if (n >= c->ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->ev.push_back(e); }
+        (void)hipEventRecord(c->ev[n++], c->stream);
+        c->last_times.push_back({name, 0.f});
+    }
+    void finish() {
+        if (!c->timing || n == 0) return;
+        (void)hipEventSynchronize(c->ev[n - 1]);
+        for (size_t i = 1; i < n; ++i) (void)hipEventElapsedTime(&c->last_times[i].second, c->ev[i - 1], c->ev[i]);
+    }
+};
+
+// one frame on the resident pair; result in frame[slot]
+static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain) {
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
+    const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
+    int rc = plan_frame(W, H, c->pts1, c->pts2, shape, c->plan);
+    if (rc) return fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)");
+    const int T = c->plan.n_tris;
+    if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
+
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % poppy_hip_ctx::kRing;
+    HIPCHK(c, hipEventSynchronize(c->ring_done[slot]));          // the copy that last used this slot has drained
+    if (T) {
+        memcpy(c->h_tri[slot], c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
+        memcpy(c->h_inv[slot], c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(c->h_inv[slot] + (size_t)T * 9, c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
+    }
+    hipStream_t s = c->stream;
+    Timer tm(c);
+    tm.mark("begin");
+    if (T) {
+        HIPCHK(c, hipMemcpyAsync(c->d_tri[slot], c->h_tri[slot], (size_t)T * 6 * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_inv[slot], c->h_inv[slot], (size_t)T * 18 * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipEventRecord(c->ring_done[slot], s));
+    HIPCHK(c, hipMemsetAsync(c->triMap, 0, (size_t)W * H * 4, s));
+    tm.mark("upload+clear");
+    launch_raster(c->d_tri[slot], T, c->triMap, W, H, s);
+    tm.mark("raster");
+    launch_warp(c->triMap, c->d_inv[slot], c->d_inv[slot] + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
+    tm.mark("warp");
+    launch_mask(c->m2, c->pyrM, W * H, 1.0 - mask, -mask, s);
+    tm.mark("mask");
+    const int ft = c->first_tail < L ? c->first_tail : L;
+    for (int i = 0; i < ft; ++i) {
+        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
+        const void* sl = i == 0 ? (const void*)c->tr1 : (const void*)(c->pyrL + a.off3);
+        const void* sr = i == 0 ? (const void*)c->tr2 : (const void*)(c->pyrR + a.off3);
+        launch_pyrdown(sl, sr, c->pyrM + a.off1, i == 0, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrM + b.off1, a.w, a.h, s);
+    }
+    tm.mark("pyrdown");
+    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, s);
+    tm.mark("pyr_tail");
+    for (int i = ft - 1; i >= 0; --i) {
+        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
+        const void* gl = i == 0 ? (const void*)c->tr1 : (const void*)(c->pyrL + a.off3);
+        const void* gr = i == 0 ? (const void*)c->tr2 : (const void*)(c->pyrR + a.off3);
+        launch_collapse(gl, gr, i == 0, c->pyrM + a.off1, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrB + b.off3, c->pyrB + a.off3,
+                        a.w, a.h, b.w, b.h, s);
+    }
+    tm.mark("collapse");
+    const double amount = std::sin(mask * M_PI);
+    uint8_t* out = c->frame[c->frame_slot];
+    launch_unsharp(c->pyrB, c->tmp, c->diff, out, c->debug ? c->unsharpF : nullptr, W, H, (float)(1.0 - amount), (float)0.3, s);
+    tm.mark("unsharp");
+    HIPCHK(c, hipGetLastError());
+    tm.finish();
+    c->last_slot = c->frame_slot;
+    c->frame_slot ^= 1;
+    if (chain) {                                   // src/poppy.hpp:217-218
+        c->cur1 = out;
+        c->pts1 = c->plan.morphed;
+    }
+    return POPPY_OK;
+}
+
+static int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H) {
+    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)W * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    return POPPY_OK;
+}
+
+extern "C" {
+
+int poppy_hip_pair_load(poppy_hip_ctx* c, const uint8_t* c1, size_t s1, const uint8_t* c2, size_t s2, const float* gabor2,
+                        int W, int H, const float* p1, const float* p2, int n) {
+    if (!c) return POPPY_E_ARG;
+    if (!c1 || !c2 || !gabor2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = alloc_pair(c, W, H); if (rc) return rc;
+    rc = set_points(c, p1, p2, n); if (rc) return rc;
+    rc = upload_image(c, c->c1, c1, s1, W, H); if (rc) return rc;
+    rc = upload_image(c, c->c2, c2, s2, W, H); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->gabor2, gabor2, (size_t)W * H * 12, hipMemcpyHostToDevice, c->stream));
+    rc = finish_pair_load(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // host buffers may be reused by the caller
+    return POPPY_OK;
+}
+
+int poppy_hip_pair_load_device(poppy_hip_ctx* c, const void* d1, const void* d2, const void* dg, int W, int H,
+                               const float* p1, const float* p2, int n) {
+    if (!c) return POPPY_E_ARG;
+    if (!d1 || !d2 || !dg || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad image arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = alloc_pair(c, W, H); if (rc) return rc;
+    rc = set_points(c, p1, p2, n); if (rc) return rc;
+    const size_t P = (size_t)W * H;
+    HIPCHK(c, hipMemcpyAsync(c->c1, d1, P * 3, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->c2, d2, P * 3, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->gabor2, dg, P * 12, hipMemcpyDeviceToDevice, c->stream));
+    rc = finish_pair_load(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
+int poppy_hip_pair_reset(poppy_hip_ctx* c) {
+    if (!c) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    c->cur1 = c->c1; c->pts1 = c->pts1_0; c->last_slot = -1;
+    return POPPY_OK;
+}
+
+int poppy_hip_render(poppy_hip_ctx* c, double shape, double mask, int chain, uint8_t* dst, size_t dst_stride) {
+    if (!c) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = render_frame(c, shape, mask, chain != 0); if (rc) return rc;
+    if (dst) {
+        if (dst_stride < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "dst_stride too small");
+        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->frame[c->last_slot], (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return POPPY_OK;
+}
+
+const void* poppy_hip_frame_device(poppy_hip_ctx* c) { return (c && c->last_slot >= 0) ? c->frame[c->last_slot] : nullptr; }
+
+int poppy_hip_morph_images(poppy_hip_ctx* c, const uint8_t* c1, size_t s1, const uint8_t* c2, size_t s2, const float* gabor2, int W, int H,
+                           const float* p1, const float* p2, int n, double shape, double mask, uint8_t* dst, size_t dst_stride, float* morphed) {
+    if (!c) return POPPY_E_ARG;
+    if (!dst) return fail(c, POPPY_E_ARG, "dst is null");
+    int rc = poppy_hip_pair_load(c, c1, s1, c2, s2, gabor2, W, H, p1, p2, n); if (rc) return rc;
+    rc = poppy_hip_render(c, shape, mask, 0, dst, dst_stride); if (rc) return rc;
+    if (morphed && n) memcpy(morphed, c->plan.morphed.data(), (size_t)n * 8);
+    return POPPY_OK;
+}
+
+double poppy_frame_ratio(int j, int number_of_frames, double phase) {
+    const double N = (double)number_of_frames;
+    const double linear = j / N;
+    double progress = 0;
+    if (phase >= 1.0) progress = 1;
+    if (phase < 1.0 && phase >= 0) progress = 1.0 / N;
+    else if (linear == 0) progress = 0;
+    else if (linear == 1) progress = 1;
+    else progress = (1.0 / (1.0 - linear)) / N;
+    double shape = (phase < 1.0 && phase >= 0) ? progress * phase : progress;
+    if (shape > 1) shape = 1;
+    return shape;
+}
+
+int poppy_hip_morph_frames(poppy_hip_ctx* c, double phase, poppy_write_cb write, void* user) {
+    if (!c) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->cfg.number_of_frames;
+    const size_t row = (size_t)c->W * 3;
+    if (write) { int rc = stage_host(c, row * c->H); if (rc) return rc; }
+    for (int j = 0; j < N; ++j) {
+        const double shape = poppy_frame_ratio(j, N, phase);
+        int rc = render_frame(c, shape, shape, true); if (rc) return rc;
+        if (write) {
+            HIPCHK(c, hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * c->H, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            write(user, c->h_stage, c->W, c->H, row);
+        }
+        if (phase >= 0) break;                                 // src/poppy.hpp:234-235
+    }
+    return POPPY_OK;
+}
+
+int poppy_hip_dissolve(poppy_hip_ctx* c, const uint8_t* img1, size_t s1, const uint8_t* img2, size_t s2, int W, int H, double phase,
+                       uint8_t* dst, size_t dst_stride) {
+    if (!c) return POPPY_E_ARG;
+    if (!img1 || !img2 || !dst || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = alloc_pair(c, W, H); if (rc) return rc;
+    rc = upload_image(c, c->c1, img1, s1, W, H); if (rc) return rc;
+    rc = upload_image(c, c->c2, img2, s2, W, H); if (rc) return rc;
+    // Mat blend = img2*phase + img1*(1.0-phase)  ->  addWeighted(img2, phase, img1, 1-phase, 0)
+    launch_dissolve(c->c2, c->c1, c->frame[0], (size_t)W * H * 3, (float)phase, (float)(1.0 - phase), c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->frame[0], (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pair_ready = false;
+    return POPPY_OK;
+}
+
+int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t bytes) {
+    if (!c || !name || !host) return POPPY_E_ARG;
+    if (!c->W) return fail(c, POPPY_E_STATE, "no pair loaded");
+    const size_t P = (size_t)c->W * c->H;
+    const void* src = nullptr; size_t need = 0;
+    std::string n(name);
+    if (n == "triMap") { src = c->triMap; need = P * 4; }
+    else if (n == "trImg1") { src = c->tr1; need = P * 3; }
+    else if (n == "trImg2") { src = c->tr2; need = P * 3; }
+    else if (n == "lbmask") { src = c->pyrM; need = P * 4; }
+    else if (n == "lapBlend") { src = c->pyrB; need = P * 12; }
+    else if (n == "unsharp") { if (!c->debug) return fail(c, POPPY_E_STATE, "enable debug first"); src = c->unsharpF; need = P * 12; }
+    else if (n == "m2") { src = c->m2; need = P * 4; }
+    else return fail(c, POPPY_E_ARG, "unknown debug buffer");
+    if (bytes != need) return fail(c, POPPY_E_ARG, "debug buffer size mismatch");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
+    return POPPY_OK;
+}
+
+int poppy_hip_debug_triangles(poppy_hip_ctx* c, int* n_tris, int* idx3, float* M1, float* M2, int max_tris) {
+    if (!c || !n_tris) return POPPY_E_ARG;
+    const int T = c->plan.n_tris;
+    *n_tris = T;
+    if (T > max_tris) return fail(c, POPPY_E_ARG, "max_tris too small");
+    if (idx3 && T) memcpy(idx3, c->plan.idx3.data(), (size_t)T * 3 * sizeof(int));
+    if (M1 && T) memcpy(M1, c->plan.M1.data(), (size_t)T * 9 * sizeof(float));
+    if (M2 && T) memcpy(M2, c->plan.M2.data(), (size_t)T * 9 * sizeof(float));
+    return POPPY_OK;
+}
+
+int poppy_plan_frame(int W, int H, const float* p1, const float* p2, int n, double shape, int max_tris,
+                     int* n_tris, int* idx3, int* tri_xy, float* M1, float* M2, float* inv1, float* inv2, float* morphed) {
+    if (W <= 0 || H <= 0 || n < 0 || !n_tris) return POPPY_E_ARG;
+    std::vector<P2f> a(n), b(n);
+    if (n) { memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8); }
+    FramePlan plan;
+    if (plan_frame(W, H, a, b, shape, plan)) return POPPY_E_RANGE;
+    const int T = plan.n_tris;
+    *n_tris = T;
+    if (T > max_tris) return POPPY_E_ARG;
+    if (idx3 && T) memcpy(idx3, plan.idx3.data(), (size_t)T * 12);
+    if (tri_xy && T) memcpy(tri_xy, plan.tri_xy.data(), (size_t)T * 24);
+    if (M1 && T) memcpy(M1, plan.M1.data(), (size_t)T * 36);
+    if (M2 && T) memcpy(M2, plan.M2.data(), (size_t)T * 36);
+    if (inv1 && T) memcpy(inv1, plan.inv1.data(), (size_t)T * 36);
+    if (inv2 && T) memcpy(inv2, plan.inv2.data(), (size_t)T * 36);
+    if (morphed && n) memcpy(morphed, plan.morphed.data(), (size_t)n * 8);
+    return POPPY_OK;
+}
+
+int poppy_hip_last_timing(poppy_hip_ctx* c, const char** names, float* ms, int max) {
+    if (!c) return 0;
+    int n = 0;
+    for (size_t i = 1; i < c->last_times.size() && n < max; ++i, ++n) { names[n] = c->last_times[i].first; ms[n] = c->last_times[i].second; }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""GPU parity of the per-frame path: HIP kernels (through the C ABI) vs the oracle and the reference fixtures.
+
+Bar: bit-exact on every integer/byte stage (triMap, warped images, final frame) and — because the kernels
+reproduce the reference's float association and are built without FMA contraction — bit-exact on the float
+stages as well (lbmask, lapBlend, unsharp).  north_star allows 1 LSB on blended pixels; we assert 0.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from poppy_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    c.set_debug(True)
+    yield c
+    c.close()
+
+
+def _bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def _same(name, got, want):
+    assert got.shape == want.shape, name
+    neq = _bits(got) != _bits(want)
+    if neq.any():
+        idx = np.argwhere(neq)
+        raise AssertionError(f"{name}: {len(idx)} of {got.size} elements differ, first at {idx[0]}: {got[tuple(idx[0])]} vs {want[tuple(idx[0])]}")
+
+
+@pytest.mark.parametrize("case", ["b_64x48", "b_256x256", "b_509x381"])
+def test_frame_vs_reference_fixtures(ctx, case):
+    inp = G.bstage_inputs(case)
+    w, h, n, ratios, levels = G.make_inputs.BSTAGE[case]
+    for k, (s, m) in enumerate(ratios):
+        pf = f"f{k}_"
+        out, mp = ctx.morph_images(inp["c1"], inp["c2"], inp["gabor2"], inp["pts1"], inp["pts2"], s, m)
+        G.check(case, pf + "morphedPoints", mp)
+        for name in ("triMap", "trImg1", "trImg2", "lbmask", "lapBlend", "unsharp"):
+            G.check(case, pf + name, ctx.fetch(name), what=f"ratio {s}")
+        G.check(case, pf + "frame", out)
+
+
+def test_frame_1080p_vs_reference_and_oracle(ctx):
+    case = "b_1920x1080"
+    inp = G.bstage_inputs(case)
+    s, m = G.make_inputs.BSTAGE[case][3][0]
+    out, mp = ctx.morph_images(inp["c1"], inp["c2"], inp["gabor2"], inp["pts1"], inp["pts2"], s, m)
+    for name in ("triMap", "trImg1", "trImg2", "lbmask", "lapBlend", "unsharp"):
+        G.check(case, "f0_" + name, ctx.fetch(name))
+    G.check(case, "f0_frame", out)
+
+
+@pytest.mark.parametrize("w,h,n", [(97, 61, 9), (200, 33, 20), (33, 200, 20), (640, 360, 120)])
+def test_frame_vs_oracle_ragged_sizes(ctx, w, h, n):
+    c1 = synth.textured_bgr(w, h, 51); c2 = synth.textured_bgr(w, h, 52)
+    g = synth.unit_field(w, h, 13)
+    p1, p2 = synth.point_pairs(w, h, n, seed=w + h)
+    for s in (0.0, 0.37, 1.0):
+        want, wmp, d = O.morph_images(c1, c2, g, p1, p2, s, s, 64, debug=True)
+        got, gmp = ctx.morph_images(c1, c2, g, p1, p2, s, s)
+        _same("morphed", gmp, wmp)
+        for name in ("triMap", "trImg1", "trImg2", "lbmask", "lapBlend", "unsharp"):
+            _same(f"{name} {w}x{h} s={s}", ctx.fetch(name), d[name])
+        _same("frame", got, want)
+
+
+def test_chained_sequence_vs_oracle(ctx):
+    """Default CLI mode (src/poppy.hpp:177-219): frame j warps frame j-1 and the previous morphed points."""
+    w, h, n, N = 320, 200, 40, 6
+    c1 = synth.textured_bgr(w, h, 61); c2 = synth.textured_bgr(w, h, 62)
+    g = synth.unit_field(w, h, 14)
+    p1, p2 = synth.point_pairs(w, h, n, seed=9, dup=0, oob=0)
+    ctx.pair_load(c1, c2, g, p1, p2)
+    cur, pts = c1, p1
+    L = capi.lib()
+    for j in range(N):
+        s = L.poppy_frame_ratio(j, N, -1.0)
+        want, mp = O.morph_images(cur, c2, g, pts, p2, s, s, 64)
+        got = ctx.render(s, s, chain=True)
+        _same(f"chained frame {j}", got, want)
+        cur, pts = want, mp
+
+
+def test_morph_frames_callback_and_reset(ctx):
+    w, h, n = 160, 120, 16
+    c1 = synth.textured_bgr(w, h, 71); c2 = synth.textured_bgr(w, h, 72)
+    g = synth.unit_field(w, h, 15)
+    p1, p2 = synth.point_pairs(w, h, n, seed=3, dup=0, oob=0)
+    c = capi.Context(0, number_of_frames=4)
+    c.pair_load(c1, c2, g, p1, p2)
+    a = c.morph_frames(-1.0)
+    assert len(a) == 4
+    c.reset()
+    b = c.morph_frames(-1.0)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    c.reset()
+    one = c.morph_frames(0.5)          # phase mode: exactly one frame (src/poppy.hpp:234-235)
+    assert len(one) == 1
+    want, _ = O.morph_images(c1, c2, g, p1, p2, 0.5 / 4, 0.5 / 4, 64)
+    _same("phase frame", one[0], want)
+    c.close()
+
+
+def test_no_points_and_dissolve(ctx):
+    w, h = 64, 40
+    a = synth.textured_bgr(w, h, 81); b = synth.textured_bgr(w, h, 82)
+    g = synth.unit_field(w, h, 16)
+    empty = np.zeros((0, 2), np.float32)
+    with pytest.raises(capi.PoppyError):
+        ctx.morph_images(a, b, g, empty, empty, 0.5, 0.5)
+    for phase in (0.25, 0.5, 1.0 / 3):
+        got = ctx.dissolve(a, b, phase)
+        fa, fb = np.float32(phase), np.float32(1.0 - phase)
+        want = np.clip(np.rint(b.astype(np.float32) * fa + a.astype(np.float32) * fb), 0, 255).astype(np.uint8)
+        _same("dissolve", got, want)
+
+
+def test_full_size_round_trip_properties(ctx):
+    """Size-independent properties at BASELINE.json's 1080p size: shape 0 with mask 0 keeps image 1's warp the
+    identity; shape 1 / mask 1 maps onto image 2; rendering is deterministic and chain reset is exact."""
+    w, h = 1920, 1080
+    c1, c2 = synth.gen_pair(w, h)
+    g = synth.unit_field(w, h, 17)
+    p1, p2 = synth.point_pairs(w, h, 300, seed=21, dup=0, oob=0)
+    ctx.pair_load(c1, c2, g, p1, p2)
+    f0 = ctx.render(0.0, 0.0)
+    assert (ctx.fetch("trImg1") == c1).all()          # identity warp of source 1 at shape 0
+    f1 = ctx.render(1.0, 1.0)
+    assert (ctx.fetch("trImg2") == c2).all()          # identity warp of source 2 at shape 1
+    a = ctx.render(0.4, 0.4); b = ctx.render(0.4, 0.4)
+    assert (a == b).all()
+    tm = ctx.fetch("triMap")
+    assert tm.min() >= 0 and tm.max() <= len(ctx.triangles()[0])

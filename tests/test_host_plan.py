@@ -1,0 +1,58 @@
+"""CPU tests of the product's host side: C-ABI surface and mesh planning (no GPU needed)."""
+import re
+import os
+import numpy as np
+import pytest
+
+import golden_util as G
+from poppy_amd import capi
+
+ROOT = G.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "poppy_hip.h")).read()
+    declared = set(re.findall(r"\b(poppy_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"poppy_write_cb"}
+    L = capi.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"libpoppy_hip.so lacks {missing}"
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+
+
+def test_create_fails_loudly_without_gpu(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.PoppyError):
+        capi.Context(0)
+
+
+@pytest.mark.parametrize("case", ["b_64x48", "b_256x256", "b_509x381", "b_1920x1080"])
+def test_plan_frame_matches_reference(case):
+    inp = G.bstage_inputs(case)
+    w, h, n, ratios, levels = G.make_inputs.BSTAGE[case]
+    for k, (s, m) in enumerate(ratios):
+        pf = f"f{k}_"
+        plan = capi.plan_frame(w, h, inp["pts1"], inp["pts2"], s)
+        G.check(case, pf + "morphedPoints", plan["morphed"])
+        G.check(case, pf + "triIdx", plan["idx3"])
+        G.check(case, pf + "triMorphInt", plan["tri_xy"])
+        G.check(case, pf + "M1", plan["M1"])
+        G.check(case, pf + "M2", plan["M2"])
+
+
+def test_plan_frame_out_of_range_point():
+    p = np.array([[10, 10], [64, 20], [30, 40]], np.float32)     # x == cols survives clip_points and must fail
+    with pytest.raises(capi.PoppyError):
+        capi.plan_frame(64, 48, p, p, 0.5)
+
+
+def test_frame_ratio_scheduler():
+    L = capi.lib()
+    N = 60
+    assert L.poppy_frame_ratio(0, N, -1.0) == 0.0
+    for j in range(1, N):
+        lin = j / float(N)
+        assert L.poppy_frame_ratio(j, N, -1.0) == min(1.0, (1.0 / (1.0 - lin)) / N)
+    assert L.poppy_frame_ratio(0, 1, 0.5) == 0.5           # --frames 1 --phase t  =>  shape = t
+    assert L.poppy_frame_ratio(0, 60, 0.5) == 0.5 * (1.0 / 60)
