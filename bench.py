@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — morph frames/sec at 1080p (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one 60-frame morph of a synthetic 1080p pair on every rank:
+  N = 1 : the reference's default CLI mode (chained: frame j warps frame j-1; src/poppy.hpp:177-219);
+  N > 1 : frame-range sharding.  The job is ONE 60*N-frame phase-mode morph (N = 8 -> the 480-frame morph of
+          BASELINE.json configs[3]); rank r renders frames [60r, 60r+60) with phase t_j = j / (60 N), each
+          equal to the reference call morph(img1, img2, ..., phase = t_j) with number_of_frames = 1.  The source
+          pair and the mask field are broadcast once from rank 0 over RCCL (torch.distributed "nccl"); there
+          is no data-path collective afterwards.  Per-GPU work is fixed => "scaling": "weak".
+Frames stay in HBM (inputs are resident before the timed region, outputs are not copied back); the PCIe-inclusive
+rate is printed as an extra key, never as `value`.
+
+Output: ONE JSON line on rank 0 (see the driver contract), extended with
+  roofline     : the fused map+remap kernel (k_warp), algorithmic bytes = 16 B/px (faithful path),
+                 average launch duration measured live with HIP events on the library's stream;
+  kernels      : the same for every kernel group of the frame;
+  cpu_baseline : oracle/ (CPU restatement, "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, FRAMES, NPTS = 1920, 1080, 60, 436
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel P
+ALGO_BYTES_PER_PX = {
+    "upload+clear": 4.0,                       # memset of the id map
+    "raster": 4.0,                             # every pixel's id written once
+    "warp": 16.0,                              # triMap 4 + c1 3 + c2 3 in, trImg1 3 + trImg2 3 out
+    "mask": 8.0,                               # m2 in, lbmask out
+    "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3),      # level 0: u8 L,R + mask in; quarter-size f32 L,R,M out; geometric tail
+    "pyr_tail": 0.0,
+    "collapse": (6 + 4 + 12) + (36 / 4) * (4 / 3) + 12 * (1 / 3),   # G_i (u8 at level 0), mask, lower level L,R,B in; B_i out
+    "unsharp": (12 + 12) + (12 + 12 + 12) + (12 + 12 + 3),        # row pass, column pass + diff, median + apply + u8
+}
+
+
+def synth_inputs():
+    from poppy_amd import synth
+    a, b = synth.gen_pair(W, H)
+    g = synth.unit_field(W, H, 11)
+    p1, p2 = synth.point_pairs(W, H, NPTS, seed=5, dup=0, oob=0)       # 436 matches + 4 corners
+    return a, b, g, p1, p2
+
+
+def cpu_baseline(a, b, g, p1, p2, frames=3):
+    """oracle/ timed on the host: `frames` chained 1080p frames of the same workload, one thread."""
+    import oracle_lib as O
+    from poppy_amd import capi
+    O.lib()
+    L = capi.lib()
+    cur, pts = a, p1
+    t0 = time.perf_counter()
+    for j in range(1, frames + 1):
+        s = L.poppy_frame_ratio(j, FRAMES, -1.0)
+        cur, pts = O.morph_images(cur, b, g, pts, p2, s, s, 64)
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} chained 1080p frames (j=1..{frames} of the 60-frame sequence) through oracle/liboracle.so, "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["chain", "phase"], default=None, help="default: chain at N=1, phase at N>1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from poppy_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    mode = args.mode or ("chain" if world == 1 else "phase")
+    if mode == "chain" and world > 1:
+        raise SystemExit("chained mode is sequential by construction (SURVEY.md F5); use --mode phase for N>1")
+
+    # ---- inputs: generated on rank 0, broadcast once over RCCL, resident in HBM before timing --------------
+    if rank == 0:
+        a, b, g, p1, p2 = synth_inputs()
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        tg = torch.from_numpy(g).to(dev)
+        tp = torch.from_numpy(np.stack([p1, p2])).to(dev)
+    else:
+        ta = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        tb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        tg = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        tp = torch.empty((2, NPTS + 4, 2), dtype=torch.float32, device=dev)
+    if world > 1:
+        for t in (ta, tb, tg, tp):
+            dist.broadcast(t, src=0)
+    torch.cuda.synchronize()
+    pts = tp.cpu().numpy()
+    p1r, p2r = np.ascontiguousarray(pts[0]), np.ascontiguousarray(pts[1])
+
+    ctx = capi.Context(local, number_of_frames=FRAMES)
+    ctx.pair_load_device(ta.data_ptr(), tb.data_ptr(), tg.data_ptr(), W, H, p1r, p2r)
+
+    total_frames = FRAMES * world
+    if mode == "chain":
+        shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
+    else:
+        shapes = np.array([(rank * FRAMES + j) / float(total_frames) for j in range(FRAMES)])
+
+    def step():
+        ctx.reset()
+        ctx.render_many(shapes, chain=(mode == "chain"))
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    summary = ctx.timing_summary()
+    ctx.set_timing(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    # PCIe-inclusive rate (frames copied back to pinned host memory), rank 0, short run, not `value`
+    pcie_fps = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        ctx.reset()
+        nfr = 20
+        for j in range(nfr):
+            ctx.render(float(shapes[j]), float(shapes[j]), chain=(mode == "chain"), fetch=True)
+        pcie_fps = nfr / (time.perf_counter() - t1)
+
+    if rank == 0:
+        fps = args.steps * total_frames / dt_max
+        P = W * H
+        kernels = {}
+        for name, ms, cnt in summary:
+            per_launch_ms = ms / max(cnt, 1)
+            ab = ALGO_BYTES_PER_PX.get(name, 0.0) * P
+            kernels[name] = {"avg_ms": round(per_launch_ms, 5), "launch_groups": cnt,
+                             "algo_MB": round(ab / 1e6, 3), "GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 1) if per_launch_ms > 0 else None}
+        wk = kernels.get("warp", {})
+        achieved = wk.get("GBps") or 0.0
+        out = {
+            "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped",
+            "value": round(fps, 2), "unit": "frames/s",
+            "mpix_per_s": round(fps * P / 1e6, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 pixels / f32 pyramid (bit-compatible with the reference: no FMA contraction)",
+            "data": "synthetic (integer-defined shapes pair, synthetic mask field and 436+4 point pairs; poppy_amd/synth.py)",
+            "config": {"workload": f"1920x1080 pair, {FRAMES}-frame morph per GPU ({total_frames} frames total), "
+                                   f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
+                                   "pyramid_levels 64, per-frame operator on a resident pair",
+                       "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_warp (fused create_map + remap of both sources)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algo_bytes_per_launch": 16 * P, "avg_launch_ms": wk.get("avg_ms")},
+            "kernels": kernels,
+            "gpu_ms_per_frame": round(sum(ms for _, ms, _ in summary) / max(args.steps * FRAMES, 1), 4),
+            "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                a_h, b_h, g_h = ta.cpu().numpy(), tb.cpu().numpy(), tg.cpu().numpy()
+                out["cpu_baseline"] = cpu_baseline(a_h, b_h, g_h, p1r, p2r)
+            except Exception as e:   # the checker is optional for the measurement, never for parity
+                out["cpu_baseline"] = {"value": None, "error": str(e)}
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,12 @@ double poppy_frame_ratio(int j, int number_of_frames, double phase);
 typedef void (*poppy_write_cb)(void* user, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_frames(poppy_hip_ctx* ctx, double phase, poppy_write_cb write, void* user);
 
+/* n frames with explicit ratios on the resident pair (frame-range sharding: each GPU renders its own
+ * sub-range of phase-mode frames; shape[j] = mask[j] = t_j reproduces morph(..., phase = t_j) with
+ * number_of_frames = 1).  chain as in poppy_hip_render.  write may be NULL.                            */
+int poppy_hip_render_many(poppy_hip_ctx* ctx, const double* shape_ratio, const double* mask_ratio, int n, int chain,
+                          poppy_write_cb write, void* user);
+
 /* No-match fallback  img2*phase + img1*(1-phase)  (src/poppy.hpp:125-134; u8 addWeighted,
  * OCV/core/src/arithm.simd.hpp:1705-1755).                                                          */
 int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, const uint8_t* img2, size_t stride2,
@@ -116,10 +122,11 @@ int poppy_plan_frame(int width, int height, const float* src_points1, const floa
                      double shape_ratio, int max_tris, int* n_tris, int* idx3, int* tri_xy,
                      float* M1, float* M2, float* inv1, float* inv2, float* morphed_pts);
 
-/* per-kernel timing of the last poppy_hip_render/morph_images call, in milliseconds (HIP events on
- * the ctx stream).  names/ms hold up to `max` entries; returns the number written.                    */
-int poppy_hip_last_timing(poppy_hip_ctx* ctx, const char** names, float* ms, int max);
+/* Per-kernel timing (HIP events recorded on the ctx stream around every kernel group while timing is on).
+ * timing_summary drains the stream and returns, per kernel group, the summed duration and the number of
+ * launches since the last summary / set_timing call; returns the number of entries written.            */
 int poppy_hip_set_timing(poppy_hip_ctx* ctx, int on);
+int poppy_hip_timing_summary(poppy_hip_ctx* ctx, const char** names, float* total_ms, int* launches, int max);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes the raw input files of every golden case into oracle/_ref/cases/<case>/in/.
+"""Writes the raw input files of every golden case into oracle/_dumps/cases/<case>/in/.
 
 Inputs come from poppy_amd/synth.py (integer-defined), so the tests can regenerate them
 on any box; only the reference OUTPUTS are committed as fixtures (see pack.py).
@@ -14,7 +14,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 from poppy_amd import synth  # noqa: E402
 
-CASES_DIR = os.path.join(ROOT, "oracle", "_ref", "cases")
+CASES_DIR = os.path.join(ROOT, "oracle", "_dumps", "cases")
 
 _DT = {np.dtype(np.uint8): "u8", np.dtype(np.float32): "f32", np.dtype(np.int32): "i32", np.dtype(np.float64): "f64"}
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Packs the raw reference dumps (oracle/_ref/cases/*/out) into committed fixtures.
+"""Packs the raw reference dumps (oracle/_dumps/cases/*/out) into committed fixtures.
 
 tests/golden/<case>.npz      arrays small enough to commit, stored in full (compressed)
 tests/golden/manifest.json   for EVERY dumped array: dtype, shape, sha256 of the raw bytes,
@@ -17,7 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
-CASES = os.path.join(ROOT, "oracle", "_ref", "cases")
+CASES = os.path.join(ROOT, "oracle", "_dumps", "cases")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 DT = {"u8": np.uint8, "f32": np.float32, "i32": np.int32, "f64": np.float64, "i16": np.int16, "u16": np.uint16}

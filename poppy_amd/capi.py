@@ -26,7 +26,7 @@ SYMBOLS = [
     "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
-    "poppy_hip_last_timing", "poppy_hip_set_timing",
+    "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
 ]
 
 
@@ -63,7 +63,8 @@ def lib():
         L.poppy_hip_debug_fetch.argtypes = [vp, C.c_char_p, vp, sz]
         L.poppy_hip_debug_triangles.argtypes = [vp, vp, vp, vp, vp, i]
         L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
-        L.poppy_hip_last_timing.argtypes = [vp, vp, vp, i]
+        L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
+        L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         _lib = L
     return _lib
 
@@ -197,11 +198,18 @@ class Context:
         t = nt.value
         return idx3[:t], M1[:t], M2[:t]
 
-    def last_timing(self):
+    def timing_summary(self):
+        """[(kernel group, total ms, launches)] since timing was switched on / last summary (drains the stream)."""
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()
-        n = lib().poppy_hip_last_timing(self.h, names, ms, 32)
-        return [(names[i].decode(), ms[i]) for i in range(n)]
+        cnt = (C.c_int * 32)()
+        n = lib().poppy_hip_timing_summary(self.h, names, ms, cnt, 32)
+        return [(names[i].decode(), ms[i], cnt[i]) for i in range(n)]
+
+    def render_many(self, shapes, masks=None, chain=False):
+        sh = np.ascontiguousarray(shapes, np.float64)
+        mk = sh if masks is None else np.ascontiguousarray(masks, np.float64)
+        self._chk(lib().poppy_hip_render_many(self.h, _p(sh), _p(mk), len(sh), int(chain), None, None), "render_many")
 
     def frame_device_ptr(self):
         return lib().poppy_hip_frame_device(self.h)

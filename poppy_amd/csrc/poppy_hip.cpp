@@ -59,8 +59,8 @@ struct poppy_hip_ctx {
     FramePlan plan;
     // diagnostics
     bool debug = false, timing = false;
-    std::vector<std::pair<const char*, float>> last_times;
-    std::vector<hipEvent_t> ev;
+    struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
+    std::vector<Mark> marks; size_t marks_used = 0;
     // staging for host-image entry points
     uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
 };
@@ -127,14 +127,14 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_pair(c);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (auto e : c->ev) (void)hipEventDestroy(e);
+    for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     for (int i = 0; i < poppy_hip_ctx::kRing; ++i) (void)hipEventDestroy(c->ring_done[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
-int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on != 0; return POPPY_OK; }
+int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on != 0; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return POPPY_OK; }
 
@@ -215,19 +215,17 @@ static int stage_host(poppy_hip_ctx* c, size_t bytes) {
     return POPPY_OK;
 }
 
+// Per-kernel timing: events are only RECORDED while frames are queued (no host sync); they are resolved
+// in poppy_hip_timing_summary() after the caller has drained the stream.
 struct Timer {
-    poppy_hip_ctx* c; size_t n = 0;
-    explicit Timer(poppy_hip_ctx* c_) : c(c_) { if (c->timing) c->last_times.clear(); }
+    poppy_hip_ctx* c;
+    explicit Timer(poppy_hip_ctx* c_) : c(c_) {}
     void mark(const char* name) {
         if (!c->timing) return;
-        if (n >= c->ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->ev.push_back(e); }
-        (void)hipEventRecord(c->ev[n++], c->stream);
-        c->last_times.push_back({name, 0.f});
-    }
-    void finish() {
-        if (!c->timing || n == 0) return;
-        (void)hipEventSynchronize(c->ev[n - 1]);
-        for (size_t i = 1; i < n; ++i) (void)hipEventElapsedTime(&c->last_times[i].second, c->ev[i - 1], c->ev[i]);
+        if (c->marks_used >= c->marks.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->marks.push_back({nullptr, e}); }
+        c->marks[c->marks_used].name = name;
+        (void)hipEventRecord(c->marks[c->marks_used].ev, c->stream);
+        ++c->marks_used;
     }
 };
 
@@ -251,7 +249,7 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     }
     hipStream_t s = c->stream;
     Timer tm(c);
-    tm.mark("begin");
+    tm.mark(nullptr);
     if (T) {
         HIPCHK(c, hipMemcpyAsync(c->d_tri[slot], c->h_tri[slot], (size_t)T * 6 * sizeof(int), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->d_inv[slot], c->h_inv[slot], (size_t)T * 18 * sizeof(float), hipMemcpyHostToDevice, s));
@@ -288,7 +286,6 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     launch_unsharp(c->pyrB, c->tmp, c->diff, out, c->debug ? c->unsharpF : nullptr, W, H, (float)(1.0 - amount), (float)0.3, s);
     tm.mark("unsharp");
     HIPCHK(c, hipGetLastError());
-    tm.finish();
     c->last_slot = c->frame_slot;
     c->frame_slot ^= 1;
     if (chain) {                                   // src/poppy.hpp:217-218
@@ -469,11 +466,39 @@ int poppy_plan_frame(int W, int H, const float* p1, const float* p2, int n, doub
     return POPPY_OK;
 }
 
-int poppy_hip_last_timing(poppy_hip_ctx* c, const char** names, float* ms, int max) {
+int poppy_hip_timing_summary(poppy_hip_ctx* c, const char** names, float* total_ms, int* launches, int max) {
     if (!c) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
     int n = 0;
-    for (size_t i = 1; i < c->last_times.size() && n < max; ++i, ++n) { names[n] = c->last_times[i].first; ms[n] = c->last_times[i].second; }
+    for (size_t i = 1; i < c->marks_used; ++i) {
+        const char* nm = c->marks[i].name;
+        if (!nm) continue;                                  // frame boundary
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->marks[i - 1].ev, c->marks[i].ev) != hipSuccess) continue;
+        int k = 0;
+        while (k < n && strcmp(names[k], nm) != 0) ++k;
+        if (k == n) { if (n >= max) continue; names[n] = nm; total_ms[n] = 0.f; launches[n] = 0; ++n; }
+        total_ms[k] += ms; launches[k] += 1;
+    }
+    c->marks_used = 0;
     return n;
+}
+
+int poppy_hip_render_many(poppy_hip_ctx* c, const double* shape, const double* mask, int n, int chain, poppy_write_cb write, void* user) {
+    if (!c || !shape || !mask || n < 0) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t row = (size_t)c->W * 3;
+    if (write) { int rc = stage_host(c, row * c->H); if (rc) return rc; }
+    for (int j = 0; j < n; ++j) {
+        int rc = render_frame(c, shape[j], mask[j], chain != 0); if (rc) return rc;
+        if (write) {
+            HIPCHK(c, hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * c->H, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            write(user, c->h_stage, c->W, c->H, row);
+        }
+    }
+    return POPPY_OK;
 }
 
 }  // extern "C"
