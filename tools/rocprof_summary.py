@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Turns a rocprofv3 rocpd database (--kernel-trace --stats) into the per-kernel summary kept under profiles/.
+
+usage: tools/rocprof_summary.py <results.db> [<out.md>] [--title "..."]
+"""
+import sqlite3
+import sys
+
+
+def main():
+    db_path = sys.argv[1]
+    out = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else None
+    title = sys.argv[sys.argv.index("--title") + 1] if "--title" in sys.argv else db_path
+    db = sqlite3.connect(db_path)
+    rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    lines = [f"# rocprofv3 --kernel-trace --stats: {title}", "",
+             "| kernel | calls | total (us) | avg (us) | % |", "|---|---:|---:|---:|---:|"]
+    for name, calls, total, avg, pct in rows:
+        short = name.split("(")[0].replace("poppy_hip::", "").replace("void ", "")
+        lines.append(f"| `{short}` | {calls} | {total:.1f} | {avg:.3f} | {pct:.2f} |")
+    text = "\n".join(lines) + "\n"
+    if out:
+        open(out, "a").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
