@@ -135,37 +135,17 @@ __device__ void outline_segment(int32_t* map, int W, int H, int ax, int ay, int 
     }
 }
 
-__global__ void __launch_bounds__(64) k_raster(const int* __restrict__ tri_xy, int n_tris, int32_t* __restrict__ map, int W, int H) {
-    const int t = blockIdx.x;
-    if (t >= n_tris) return;
-    const int lane = threadIdx.x;
-    const int value = t + 1;
-    int vx[3], vy[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
-
-    // outline: (v2->v0), (v0->v1), (v1->v2)
-    outline_segment(map, W, H, vx[2], vy[2], vx[0], vy[0], value, lane);
-    outline_segment(map, W, H, vx[0], vy[0], vx[1], vy[1], value, lane);
-    outline_segment(map, W, H, vx[1], vy[1], vx[2], vy[2], value, lane);
-
-    int imin = 0;
-    int xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
-        ymax = max(ymax, vy[i]); xmax = max(xmax, vx[i]); xmin = min(xmin, vx[i]);
-    }
-    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
-    ymax = min(ymax, H - 1);
-
-    // the edge state machine is tiny and wave-uniform: every lane runs it, lanes split each span
+// Replays FillConvexPoly's two-edge state machine (drawing.cpp:1164-1252) up to row `target` without
+// visiting the rows in between: between two vertex transitions an edge advances by a constant dx per row,
+// so its 16.16 position at any row follows from the last transition.  Returns false when the reference
+// loop would already have stopped (edges exhausted) or never reaches `target`.
+__device__ bool fill_span_at(const int* vx, const int* vy, int imin, int ymin, int ymax, int target, long long& xl, long long& xr) {
     int eidx[2] = {imin, imin}, eye[2] = {ymin, ymin};
     const int edi[2] = {1, 2};
     long long ex[2] = {-65536, -65536}, edx[2] = {0, 0};
     int edges = 3;
     int y = ymin;
-    do {
+    while (y <= ymax) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (y >= eye[i]) {
@@ -186,24 +166,69 @@ __global__ void __launch_bounds__(64) k_raster(const int* __restrict__ tri_xy, i
                 }
             }
         }
-        if (edges < 0) break;
-        if (y >= 0) {
-            int l = ex[0] > ex[1] ? 1 : 0;
-            int xx1 = (int)((ex[l] + 32768) >> 16);
-            int xx2 = (int)((ex[1 - l] + 32768) >> 16);
-            if (xx2 >= 0 && xx1 < W) {
-                if (xx1 < 0) xx1 = 0;
-                if (xx2 >= W) xx2 = W - 1;
-                int32_t* row = map + (size_t)y * W;
-                for (int x = xx1 + lane; x <= xx2; x += 64) atomicMax(&row[x], value);
-            }
+        if (edges < 0) return false;
+        int next = min(eye[0], eye[1]);            // first row at which another transition fires
+        if (next <= y) next = y + 1;               // (a finished chain keeps an old ye; advance row by row)
+        if (target < next) {
+            long long d = target - y;
+            long long a = ex[0] + d * edx[0], b = ex[1] + d * edx[1];
+            xl = a > b ? b : a; xr = a > b ? a : b;
+            return true;
         }
-        ex[0] += edx[0];
-        ex[1] += edx[1];
-    } while (++y <= ymax);
+        long long d = next - y;
+        ex[0] += d * edx[0]; ex[1] += d * edx[1];
+        y = next;
+    }
+    return false;
 }
-void launch_raster(const int* tri_xy, int n_tris, int32_t* triMap, int w, int h, hipStream_t s) {
-    if (n_tris > 0) hipLaunchKernelGGL(k_raster, dim3(n_tris), dim3(64), 0, s, tri_xy, n_tris, triMap, w, h);
+
+constexpr int kRasterRows = 16;      // rows of one triangle handled by one workgroup
+
+// work item = (triangle, chunk of kRasterRows rows).  256 threads: 4 waves take rows round-robin,
+// lanes split the span.  Chunk 0 also draws the outline (one segment per wave).
+__global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, const int2* __restrict__ work, int n_work,
+                                                int32_t* __restrict__ map, int W, int H) {
+    if ((int)blockIdx.x >= n_work) return;
+    const int2 item = work[blockIdx.x];
+    const int t = item.x, chunk = item.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int value = t + 1;
+    int vx[3], vy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
+
+    if (chunk == 0 && wave < 3) {      // outline: (v2->v0), (v0->v1), (v1->v2)
+        const int a = wave == 0 ? 2 : wave - 1, b = wave == 0 ? 0 : wave;
+        outline_segment(map, W, H, vx[a], vy[a], vx[b], vy[b], value, lane);
+    }
+
+    int imin = 0;
+    int xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        ymax = max(ymax, vy[i]); xmax = max(xmax, vx[i]); xmin = min(xmin, vx[i]);
+    }
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    ymax = min(ymax, H - 1);
+
+    const int y0 = ymin + chunk * kRasterRows;
+    const int y1 = min(y0 + kRasterRows - 1, ymax);
+    for (int y = y0 + wave; y <= y1; y += 4) {
+        if (y < 0) continue;
+        long long xl, xr;
+        if (!fill_span_at(vx, vy, imin, ymin, ymax, y, xl, xr)) continue;
+        int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+        if (xx2 >= 0 && xx1 < W) {
+            if (xx1 < 0) xx1 = 0;
+            if (xx2 >= W) xx2 = W - 1;
+            int32_t* row = map + (size_t)y * W;
+            for (int x = xx1 + lane; x <= xx2; x += 64) atomicMax(&row[x], value);
+        }
+    }
+}
+void launch_raster(const int* tri_xy, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s) {
+    if (n_work > 0) hipLaunchKernelGGL(k_raster, dim3(n_work), dim3(256), 0, s, tri_xy, (const int2*)work, n_work, triMap, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,42 +441,105 @@ void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
     else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
 }
 
-// --- all small levels in one workgroup ------------------------------------------------------------
-// levels first..levels-1 are reduced to first+1..levels, the smallest level is mixed, then levels
-// levels-1..first are collapsed.  Global memory written by the block is re-read by the same block
-// after __syncthreads(), which is sufficient inside one workgroup.
-__global__ void __launch_bounds__(1024) k_pyr_tail(float* __restrict__ pyrL, float* __restrict__ pyrR, float* __restrict__ pyrM,
-                                                   float* __restrict__ pyrB, const PyrLevel* __restrict__ lv, int first, int levels) {
+// --- all small levels in one workgroup, staged in LDS ---------------------------------------------
+// Levels first..levels live in LDS (at most ~1.4k pixels in total).  Levels with more than one pixel are
+// processed by the whole block with a barrier per level.  Once a level is 1x1 every deeper level is 1x1
+// too (there are ~50 of them at 1080p with pyramid_levels = 64): those form a purely sequential chain of a
+// few flops per level, which three lanes (one per colour channel) walk without any barrier — each lane only
+// ever reads what it wrote itself.  The mask chain is replicated per lane for the same reason.
+constexpr int kTailMaxLevels = 257;
+
+__global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL, const float* __restrict__ gR, const float* __restrict__ gM,
+                                                   float* __restrict__ gB, const PyrLevel* __restrict__ lv, int first, int levels,
+                                                   int n3, int n1) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sL = lds;                 // n3 floats each, indexed by (off3 - base3)
+    float* sR = sL + n3;
+    float* sB = sR + n3;
+    float* sM = sB + n3;             // n1 floats, indexed by (off1 - base1)
+    float* sMp = sM + n1;            // 3 x kTailMaxLevels private mask chains
     const int tid = threadIdx.x, nth = blockDim.x;
-    for (int i = first; i < levels; ++i) {
+    const size_t base3 = lv[first].off3, base1 = lv[first].off1;
+
+    {   // stage level `first` (produced by the previous pyrDown launch)
+        const PyrLevel f = lv[first];
+        const int c3 = f.w * f.h * 3, c1 = f.w * f.h;
+        for (int e = tid; e < c3; e += nth) { sL[e] = gL[f.off3 + e]; sR[e] = gR[f.off3 + e]; }
+        for (int e = tid; e < c1; e += nth) sM[e] = gM[f.off1 + e];
+    }
+    __syncthreads();
+
+    int k1 = levels;                 // first level that is a single pixel
+    for (int i = first; i <= levels; ++i)
+        if (lv[i].w == 1 && lv[i].h == 1) { k1 = i; break; }
+    const int wide_end = k1 < levels ? k1 : levels;        // levels [first, wide_end) are reduced block-wide
+
+    for (int i = first; i < wide_end; ++i) {
         const PyrLevel s = lv[i], d = lv[i + 1];
-        DownGeom g3 = make_down_geom(s.w, s.h, 3), g1 = make_down_geom(s.w, s.h, 1);
-        const int n3 = d.w * d.h * 3, n1 = d.w * d.h;
-        for (int e = tid; e < 2 * n3 + n1; e += nth) {
-            if (e < n3) { int y = e / (d.w * 3), xe = e - y * d.w * 3; pyrL[d.off3 + e] = pyrdown_elem<false>(pyrL + s.off3, g3, y, xe); }
-            else if (e < 2 * n3) { int q = e - n3; int y = q / (d.w * 3), xe = q - y * d.w * 3; pyrR[d.off3 + q] = pyrdown_elem<false>(pyrR + s.off3, g3, y, xe); }
-            else { int q = e - 2 * n3; int y = q / d.w, xe = q - y * d.w; pyrM[d.off1 + q] = pyrdown_elem<false>(pyrM + s.off1, g1, y, xe); }
+        const DownGeom g3 = make_down_geom(s.w, s.h, 3), g1 = make_down_geom(s.w, s.h, 1);
+        const int c3 = d.w * d.h * 3, c1 = d.w * d.h;
+        const int so3 = (int)(s.off3 - base3), do3 = (int)(d.off3 - base3), so1 = (int)(s.off1 - base1), do1 = (int)(d.off1 - base1);
+        for (int e = tid; e < 2 * c3 + c1; e += nth) {
+            if (e < c3) { int y = e / (d.w * 3), xe = e - y * d.w * 3; sL[do3 + e] = pyrdown_elem<false>(sL + so3, g3, y, xe); }
+            else if (e < 2 * c3) { int q = e - c3; int y = q / (d.w * 3), xe = q - y * d.w * 3; sR[do3 + q] = pyrdown_elem<false>(sR + so3, g3, y, xe); }
+            else { int q = e - 2 * c3; int y = q / d.w, xe = q - y * d.w; sM[do1 + q] = pyrdown_elem<false>(sM + so1, g1, y, xe); }
+        }
+        __syncthreads();
+    }
+
+    if (k1 < levels) {
+        // single-pixel chain: lanes 0..2 = channel
+        if (tid < 3) {
+            const int c = tid;
+            float* mp = sMp + c * kTailMaxLevels;
+            mp[k1] = sM[(int)(lv[k1].off1 - base1)];
+            const float s256 = 1.f / 256, s64 = 1.f / 64;
+            for (int i = k1; i < levels; ++i) {            // pyrDown 1x1 -> 1x1: every tap is the pixel itself
+                const int o = (int)(lv[i].off3 - base3) + c, n = (int)(lv[i + 1].off3 - base3) + c;
+                float v = sL[o], h = v * 6.f + (v + v) * 4.f + v + v;
+                sL[n] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
+                v = sR[o]; h = v * 6.f + (v + v) * 4.f + v + v;
+                sR[n] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
+                v = mp[i]; h = v * 6.f + (v + v) * 4.f + v + v;
+                mp[i + 1] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
+            }
+            const int ol = (int)(lv[levels].off3 - base3) + c;
+            float cur = mix_lr(sL[ol], sR[ol], mp[levels]);
+            sB[ol] = cur;
+            for (int i = levels - 1; i >= k1; --i) {       // pyrUp 1x1 -> 1x1: row value = s*8, (r + r*6 + r)/64
+                const int o = (int)(lv[i].off3 - base3) + c, n = (int)(lv[i + 1].off3 - base3) + c;
+                float hl = sL[n] * 8.f, hr = sR[n] * 8.f, hb = cur * 8.f;
+                float upL = (hl + hl * 6.f + hl) * s64, upR = (hr + hr * 6.f + hr) * s64, upB = (hb + hb * 6.f + hb) * s64;
+                float res = mix_lr(sL[o] - upL, sR[o] - upR, mp[i]);
+                cur = upB + res;
+                sB[o] = cur;
+            }
+        }
+    } else {
+        const PyrLevel t = lv[levels];
+        const int o3 = (int)(t.off3 - base3), o1 = (int)(t.off1 - base1);
+        for (int e = tid; e < t.w * t.h * 3; e += nth) sB[o3 + e] = mix_lr(sL[o3 + e], sR[o3 + e], sM[o1 + e / 3]);
+    }
+    __syncthreads();
+
+    for (int i = wide_end - 1; i >= first; --i) {
+        const PyrLevel c = lv[i], n = lv[i + 1];
+        const int co3 = (int)(c.off3 - base3), no3 = (int)(n.off3 - base3), co1 = (int)(c.off1 - base1);
+        for (int e = tid; e < c.w * c.h * 3; e += nth) {
+            int y = e / (c.w * 3), xe = e - y * c.w * 3;
+            sB[co3 + e] = collapse_elem<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe);
         }
         __syncthreads();
     }
     {
-        const PyrLevel t = lv[levels];
-        for (int e = tid; e < t.w * t.h * 3; e += nth)
-            pyrB[t.off3 + e] = mix_lr(pyrL[t.off3 + e], pyrR[t.off3 + e], pyrM[t.off1 + e / 3]);
-        __syncthreads();
-    }
-    for (int i = levels - 1; i >= first; --i) {
-        const PyrLevel c = lv[i], n = lv[i + 1];
-        for (int e = tid; e < c.w * c.h * 3; e += nth) {
-            int y = e / (c.w * 3), xe = e - y * c.w * 3;
-            pyrB[c.off3 + e] = collapse_elem<false>(pyrL + c.off3, pyrR + c.off3, pyrM + c.off1, pyrL + n.off3, pyrR + n.off3,
-                                                    pyrB + n.off3, c.w, c.h, n.w, n.h, y, xe);
-        }
-        __syncthreads();
+        const PyrLevel f = lv[first];
+        for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
     }
 }
-void launch_pyr_tail(float* pyrL, float* pyrR, float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels, hipStream_t s) {
-    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(1024), 0, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels);
+void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
+                     int n3, int n1, hipStream_t s) {
+    size_t lds = ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float);
+    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(1024), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, n3, n1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include "frame_plan.h"
 #include "kernels.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -52,8 +53,10 @@ struct poppy_hip_ctx {
     // per-frame plan upload ring (pinned host + device), so the host can plan ahead of the GPU
     static const int kRing = 4;
     int max_tris = 0;
-    int* h_tri[kRing] = {};  float* h_inv[kRing] = {};
-    int* d_tri[kRing] = {};  float* d_inv[kRing] = {};
+    // blob layout: [tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32][raster work items 2*n i32]
+    uint8_t* h_blob[kRing] = {};  uint8_t* d_blob[kRing] = {};
+    size_t blob_bytes = 0;
+    int tail_n3 = 0, tail_n1 = 0;
     hipEvent_t ring_done[kRing] = {};
     int ring_pos = 0;
     FramePlan plan;
@@ -112,11 +115,9 @@ static void free_pair(poppy_hip_ctx* c) {
     c->gabor2 = c->m2 = c->pyrL = c->pyrR = c->pyrM = c->pyrB = c->tmp = c->diff = c->unsharpF = nullptr;
     c->triMap = nullptr; c->d_levels = nullptr;
     for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
-        if (c->h_tri[i]) (void)hipHostFree(c->h_tri[i]);
-        if (c->h_inv[i]) (void)hipHostFree(c->h_inv[i]);
-        if (c->d_tri[i]) (void)hipFree(c->d_tri[i]);
-        if (c->d_inv[i]) (void)hipFree(c->d_inv[i]);
-        c->h_tri[i] = nullptr; c->h_inv[i] = nullptr; c->d_tri[i] = nullptr; c->d_inv[i] = nullptr;
+        if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
+        if (c->d_blob[i]) (void)hipFree(c->d_blob[i]);
+        c->h_blob[i] = nullptr; c->d_blob[i] = nullptr;
     }
     c->max_tris = 0; c->W = c->H = 0; c->pair_ready = false;
 }
@@ -144,16 +145,17 @@ int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hip
 static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     int need = 2 * n_points + 16;            // a planar triangulation of n points has < 2n triangles
     if (need <= c->max_tris) return POPPY_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // worst case every triangle spans the whole image height
+    const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 2);
+    const size_t bytes = (size_t)need * (6 * 4 + 18 * 4) + items * 8;
     for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
-        if (c->h_tri[i]) (void)hipHostFree(c->h_tri[i]);
-        if (c->h_inv[i]) (void)hipHostFree(c->h_inv[i]);
-        if (c->d_tri[i]) (void)hipFree(c->d_tri[i]);
-        if (c->d_inv[i]) (void)hipFree(c->d_inv[i]);
-        HIPCHK(c, hipHostMalloc((void**)&c->h_tri[i], (size_t)need * 6 * sizeof(int)));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_inv[i], (size_t)need * 18 * sizeof(float)));
-        HIPCHK(c, hipMalloc((void**)&c->d_tri[i], (size_t)need * 6 * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&c->d_inv[i], (size_t)need * 18 * sizeof(float)));
+        if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
+        if (c->d_blob[i]) (void)hipFree(c->d_blob[i]);
+        HIPCHK(c, hipHostMalloc((void**)&c->h_blob[i], bytes));
+        HIPCHK(c, hipMalloc((void**)&c->d_blob[i], bytes));
     }
+    c->blob_bytes = bytes;
     c->max_tris = need;
     return POPPY_OK;
 }
@@ -175,7 +177,11 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     }
     c->first_tail = L;
     for (int i = 1; i <= L; ++i)
-        if ((size_t)c->levels[i].w * c->levels[i].h <= 4096) { c->first_tail = i; break; }
+        if ((size_t)c->levels[i].w * c->levels[i].h <= 1024) { c->first_tail = i; break; }
+    c->tail_n3 = c->tail_n1 = 0;
+    for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
+    if (((size_t)3 * c->tail_n3 + c->tail_n1 + 3 * 257) * 4 > 64 * 1024)
+        return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
     HIPCHK(c, hipMalloc((void**)&c->c1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3));
     HIPCHK(c, hipMalloc((void**)&c->tr1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->tr2, P * 3));
     HIPCHK(c, hipMalloc((void**)&c->frame[0], P * 3)); HIPCHK(c, hipMalloc((void**)&c->frame[1], P * 3));
@@ -242,24 +248,37 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     const int slot = c->ring_pos;
     c->ring_pos = (c->ring_pos + 1) % poppy_hip_ctx::kRing;
     HIPCHK(c, hipEventSynchronize(c->ring_done[slot]));          // the copy that last used this slot has drained
+    int* h_tri = (int*)c->h_blob[slot];
+    float* h_inv = (float*)(h_tri + (size_t)T * 6);
+    int* h_work = (int*)(h_inv + (size_t)T * 18);
+    int n_work = 0;
     if (T) {
-        memcpy(c->h_tri[slot], c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
-        memcpy(c->h_inv[slot], c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
-        memcpy(c->h_inv[slot] + (size_t)T * 9, c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
+        memcpy(h_inv, c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(h_inv + (size_t)T * 9, c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
+        for (int t = 0; t < T; ++t) {              // raster work list: (triangle, chunk of kRasterChunkRows rows)
+            const int* v = &c->plan.tri_xy[(size_t)t * 6];
+            int ymin = std::min(v[1], std::min(v[3], v[5])), ymax = std::min(std::max(v[1], std::max(v[3], v[5])), H - 1);
+            int rows = ymax - ymin + 1;
+            int chunks = rows > 0 ? (rows + kRasterChunkRows - 1) / kRasterChunkRows : 1;
+            for (int k = 0; k < chunks; ++k) { h_work[2 * n_work] = t; h_work[2 * n_work + 1] = k; ++n_work; }
+        }
     }
+    const size_t used = (size_t)T * (6 + 18) * 4 + (size_t)n_work * 8;
+    if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
+    const int* d_tri = (const int*)c->d_blob[slot];
+    const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
+    const int* d_work = (const int*)(d_inv + (size_t)T * 18);
     hipStream_t s = c->stream;
     Timer tm(c);
     tm.mark(nullptr);
-    if (T) {
-        HIPCHK(c, hipMemcpyAsync(c->d_tri[slot], c->h_tri[slot], (size_t)T * 6 * sizeof(int), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_inv[slot], c->h_inv[slot], (size_t)T * 18 * sizeof(float), hipMemcpyHostToDevice, s));
-    }
+    if (used) HIPCHK(c, hipMemcpyAsync(c->d_blob[slot], c->h_blob[slot], used, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ring_done[slot], s));
     HIPCHK(c, hipMemsetAsync(c->triMap, 0, (size_t)W * H * 4, s));
     tm.mark("upload+clear");
-    launch_raster(c->d_tri[slot], T, c->triMap, W, H, s);
+    launch_raster(d_tri, d_work, n_work, c->triMap, W, H, s);
     tm.mark("raster");
-    launch_warp(c->triMap, c->d_inv[slot], c->d_inv[slot] + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
+    launch_warp(c->triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
     tm.mark("warp");
     launch_mask(c->m2, c->pyrM, W * H, 1.0 - mask, -mask, s);
     tm.mark("mask");
@@ -271,7 +290,7 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
         launch_pyrdown(sl, sr, c->pyrM + a.off1, i == 0, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrM + b.off1, a.w, a.h, s);
     }
     tm.mark("pyrdown");
-    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, s);
+    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, c->tail_n3, c->tail_n1, s);
     tm.mark("pyr_tail");
     for (int i = ft - 1; i >= 0; --i) {
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
