@@ -94,4 +94,16 @@ int morph_images(const ImageU8& c1, const ImageU8& c2, const ImageF& gabor2,
                  double shapeRatio, double maskRatio, int levels,
                  ImageU8& out, std::vector<Pt>& morphedPoints, FrameDebug* dbg = nullptr);
 
+// ---- orb.cpp ---------------------------------------------------------------------------------
+// ORB::create(nfeatures)->detect(image): n x 7 floats (x, y, size, angle, response, octave, class_id), order significant
+int orb_detect(const ImageU8& image, int nfeatures, std::vector<float>& kps, std::vector<float>* fastLevel0 = nullptr);
+void hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out);
+
+// ---- match.cpp -------------------------------------------------------------------------------
+struct DistPair { double d; Pt a, b; };
+void make_distance_map(const std::vector<Pt>& p1, const std::vector<Pt>& p2, std::vector<DistPair>& out);   // ascending, stable
+void filter_invalid_points(std::vector<Pt>& p1, std::vector<Pt>& p2, int cols, int rows);
+double morph_distance(const std::vector<Pt>& p1, const std::vector<Pt>& p2, int w, int h);
+void match_prepare(std::vector<Pt>& s1, std::vector<Pt>& s2, int w, int h, double tolerance, double initialMorphDist);
+
 }  // namespace oracle

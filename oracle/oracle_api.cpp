@@ -101,4 +101,32 @@ int orc_morph_images(const uint8_t* c1, const uint8_t* c2, const float* gabor2, 
     return 0;
 }
 
+int orc_orb_detect(const uint8_t* img, int w, int h, int nfeatures, float* kps7, int maxKps, float* fast3, int maxFast, int* nFast) {
+    std::vector<float> k, f;
+    int n = orb_detect(wrap_u8(img, w, h, 1), nfeatures, k, &f);
+    if (n > maxKps) return -1;
+    put(kps7, k);
+    if (nFast) *nFast = (int)f.size() / 3;
+    if (fast3 && (int)f.size() / 3 <= maxFast) put(fast3, f);
+    return n;
+}
+int orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, int* out3) {
+    std::vector<int> o; hamming_match(q, nq, t, nt, bytes, o); put(out3, o); return (int)o.size() / 3;
+}
+
+int orc_distance_map(const float* p1, const float* p2, int n, double* out5) {
+    std::vector<DistPair> dm; make_distance_map(wrap_pts(p1, n), wrap_pts(p2, n), dm);
+    for (size_t i = 0; i < dm.size(); ++i) { double* o = out5 + i * 5; o[0] = dm[i].d; o[1] = dm[i].a.x; o[2] = dm[i].a.y; o[3] = dm[i].b.x; o[4] = dm[i].b.y; }
+    return (int)dm.size();
+}
+int orc_filter_invalid(float* p1, float* p2, int n, int cols, int rows) {
+    auto a = wrap_pts(p1, n), b = wrap_pts(p2, n); filter_invalid_points(a, b, cols, rows);
+    if (a.size() > b.size()) a.resize(b.size()); else b.resize(a.size());
+    put((Pt*)p1, a); put((Pt*)p2, b); return (int)a.size();
+}
+double orc_morph_distance(const float* p1, const float* p2, int n, int w, int h) { return morph_distance(wrap_pts(p1, n), wrap_pts(p2, n), w, h); }
+int orc_match_prepare(const float* p1, const float* p2, int n, int w, int h, double tol, double imd, float* o1, float* o2) {
+    auto a = wrap_pts(p1, n), b = wrap_pts(p2, n); match_prepare(a, b, w, h, tol, imd); put((Pt*)o1, a); put((Pt*)o2, b); return (int)a.size();
+}
+
 }  // extern "C"

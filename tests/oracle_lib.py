@@ -230,3 +230,49 @@ def morph_images(c1, c2, gabor2, p1, p2, shape, mask, levels=64, debug=False):
         d["ntri"] = nt
         return out, mp, d
     return out, mp
+
+
+def orb_detect(img, nfeatures, with_fast=False):
+    g = np.ascontiguousarray(img, np.uint8)
+    h, w = g.shape
+    kp = np.zeros((nfeatures * 2 + 64, 7), np.float32)
+    mf = w * h // 4 + 16
+    fast = np.zeros((mf, 3), np.float32)
+    nf = C.c_int(0)
+    n = lib().orc_orb_detect(_vp(g), w, h, nfeatures, _vp(kp), len(kp), _vp(fast), mf, C.byref(nf))
+    if n < 0:
+        raise ValueError("orb_detect overflow")
+    return (kp[:n].copy(), fast[:nf.value].copy()) if with_fast else kp[:n].copy()
+
+
+def hamming_match(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros((len(q), 3), np.int32)
+    n = lib().orc_hamming_match(_vp(q), len(q), _vp(t), len(t), q.shape[1], _vp(out))
+    return out[:n]
+
+
+def distance_map(p1, p2):
+    p1, p2 = _f(p1), _f(p2)
+    out = np.zeros((len(p1), 5), np.float64)
+    n = lib().orc_distance_map(_vp(p1), _vp(p2), len(p1), _vp(out))
+    return out[:n]
+
+
+def filter_invalid(p1, p2, cols, rows):
+    a, b = _f(p1).copy(), _f(p2).copy()
+    n = lib().orc_filter_invalid(_vp(a), _vp(b), len(a), cols, rows)
+    return a[:n].copy(), b[:n].copy()
+
+
+def morph_distance(p1, p2, w, h):
+    p1, p2 = _f(p1), _f(p2)
+    lib().orc_morph_distance.restype = C.c_double
+    return lib().orc_morph_distance(_vp(p1), _vp(p2), len(p1), w, h)
+
+
+def match_prepare(p1, p2, w, h, tol, imd):
+    p1, p2 = _f(p1), _f(p2)
+    o1 = np.zeros((len(p1) + 4, 2), np.float32); o2 = np.zeros((len(p1) + 4, 2), np.float32)
+    n = lib().orc_match_prepare(_vp(p1), _vp(p2), len(p1), w, h, C.c_double(tol), C.c_double(imd), _vp(o1), _vp(o2))
+    return o1[:n].copy(), o2[:n].copy()

@@ -1,0 +1,80 @@
+"""The oracle's once-per-pair core against the reference fixtures: ORB detect,
+greedy point matcher, morph distance, threshold filter.  All comparisons are bit-exact, order included."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+
+def _bits_equal(a, b):
+    return a.shape == b.shape and (np.ascontiguousarray(a).view(np.uint32) == np.ascontiguousarray(b).view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("case", ["o_256x256", "o_640x480"])
+def test_orb_detect_bit_exact(case):
+    inp = G.orb_inputs(case)
+    w, h, nfs = G.make_inputs.ORB[case]
+    for nf in nfs:
+        for im in ("1", "2"):
+            G.check(case, f"n{nf}_kp{im}", O.orb_detect(inp["g" + im], nf))
+
+
+def test_fast_level0_matches_cv_fast():
+    case = "o_256x256"
+    inp = G.orb_inputs(case)
+    _, fast = O.orb_detect(inp["g1"], 300, with_fast=True)
+    ref = G.full(case, "fast_g1")               # cv::FAST(g1, 20, nonmax): x, y, size, angle, response, octave, class_id
+    assert _bits_equal(fast, ref[:, [0, 1, 4]])
+    assert (ref[:, 2] == 7).all() and (ref[:, 3] == -1).all()
+
+
+@pytest.mark.slow
+def test_orb_detect_1080p():
+    case = "o_1920x1080"
+    inp = G.orb_inputs(case)
+    G.check(case, "n516_kp1", O.orb_detect(inp["g1"], 516))
+    G.check(case, "n516_kp2", O.orb_detect(inp["g2"], 516))
+
+
+@pytest.mark.parametrize("case", ["m_640x480", "m_1920x1080", "m_tol2"])
+def test_point_matcher_bit_exact(case):
+    inp = G.match_inputs(case)
+    w, h, tol = int(inp["cfg"][0]), int(inp["cfg"][1]), float(inp["cfg"][2])
+    G.check(case, "distanceMap", O.distance_map(inp["pts1"], inp["pts2"]))
+    f1, f2 = O.filter_invalid(inp["pts1"], inp["pts2"], w, h)
+    G.check(case, "filtered1", f1)
+    G.check(case, "filtered2", f2)
+    md = O.morph_distance(f1, f2, w, h)
+    G.check(case, "initialMorphDist", np.array([md]))
+    a, b = O.match_prepare(f1, f2, w, h, tol, md)
+    G.check(case, "prepared1", a)
+    G.check(case, "prepared2", b)
+    # morph()'s printed distance after clip/uniq (src/poppy.hpp:142-159)
+    u1 = O.make_uniq(O.clip_points(a, w, h)); u2 = O.make_uniq(O.clip_points(b, w, h))
+    n = min(len(u1), len(u2))
+    G.check(case, "finalMorphDist", np.array([O.morph_distance(u1[:n], u2[:n], w, h)]))
+
+
+def test_real_pipeline_points_feed_the_matcher():
+    """Keypoints of the real A stage (a_512x384_chain fixture) -> found/prepared point sets."""
+    case = "a_512x384_chain"
+    kp1, kp2 = G.full(case, "kp1"), G.full(case, "kp2")
+    n = min(len(kp1), len(kp2))
+    p1, p2 = kp1[:n, :2].copy(), kp2[:n, :2].copy()
+    f1, f2 = O.filter_invalid(p1, p2, 512, 384)
+    G.check(case, "found1", f1)
+    G.check(case, "found2", f2)
+    md = O.morph_distance(f1, f2, 512, 384)
+    G.check(case, "initialMorphDist", np.array([md]))
+    a, b = O.match_prepare(f1, f2, 512, 384, 1.0, md)
+    G.check(case, "prepared1", a)
+    G.check(case, "prepared2", b)
+
+
+def test_real_pipeline_orb_on_reference_inputs():
+    """ORB on the reference's own ORB input images (g1/g2 of the real pre-filter chain)."""
+    case = "a_256x256_chain"
+    nf = int(G.full(case, "detail")[3])
+    G.check(case, "kp1", O.orb_detect(G.full(case, "g1"), nf))
+    G.check(case, "kp2", O.orb_detect(G.full(case, "g2"), nf))
