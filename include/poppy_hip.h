@@ -98,6 +98,34 @@ double poppy_frame_ratio(int j, int number_of_frames, double phase);
 typedef void (*poppy_write_cb)(void* user, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_frames(poppy_hip_ctx* ctx, double phase, poppy_write_cb write, void* user);
 
+/* ---- once-per-pair stage (outer boundary: poppy::morph, src/poppy.hpp:46-157) -------------------
+ * ORB::create(nfeatures)->detect(gray, keypoints)  (src/extractor.cpp:45,77-78).  gray is an 8-bit single
+ * channel host image.  kps7 receives max_kps x 7 floats per keypoint in cv::KeyPoint field order
+ * (x, y, size, angle, response, octave, class_id); the ORDER equals the reference's.                   */
+int poppy_hip_orb_detect(poppy_hip_ctx* ctx, const uint8_t* gray, size_t stride, int width, int height,
+                         int nfeatures, float* kps7, int max_kps, int* n_kps);
+
+/* Matcher::find (general branch) + Matcher::prepare on raw point lists (src/matcher.cpp:118-131,246-332):
+ * drop out-of-image pairs, morph distance, greedy nearest-neighbour pairing, threshold filter, 4 corners.
+ * Host only.  out1/out2 need room for n_points + 4 pairs.                                              */
+int poppy_match_points(const float* points1, const float* points2, int n_points, int width, int height,
+                       double match_tolerance, float* out1, float* out2, int* n_out, double* initial_morph_distance);
+
+/* Pair set-up from the two ORB input images g1/g2 (what Extractor::keypoints feeds the detector,
+ * src/extractor.cpp:50-78) and gabor2 (src/poppy.hpp:119-122): ORB x2 -> truncate to the shorter list
+ * (extractor.cpp:96-99) -> poppy_match_points -> resident pair.  nfeatures = int(max_keypoints * detail).  */
+int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* ctx,
+                                     const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
+                                     const uint8_t* orb_input1, const uint8_t* orb_input2, const float* gabor2_f32x3,
+                                     int width, int height, int nfeatures);
+/* Same from the raw BGR pair, including the reference's pre-ORB filter chain (MOG2 foreground, medians,
+ * Gabor banks, dft_detail2; src/extractor.cpp:33-83,136-229).  That chain is outside this round's scope
+ * (SURVEY.md 8f-1): the call returns POPPY_E_UNSUPPORTED instead of approximating it.                  */
+int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
+                         int width, int height);
+/* copies of the resident point sets after pair_begin / pair_load (n x 2 floats each); n via *n_points */
+int poppy_hip_pair_points(poppy_hip_ctx* ctx, float* points1, float* points2, int max_points, int* n_points);
+
 /* n frames with explicit ratios on the resident pair (frame-range sharding: each GPU renders its own
  * sub-range of phase-mode frames; shape[j] = mask[j] = t_j reproduces morph(..., phase = t_j) with
  * number_of_frames = 1).  chain as in poppy_hip_render.  write may be NULL.                            */

@@ -27,6 +27,7 @@ SYMBOLS = [
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
+    "poppy_hip_orb_detect", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_points",
 ]
 
 
@@ -65,6 +66,11 @@ def lib():
         L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
+        L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
+        L.poppy_match_points.argtypes = [vp, vp, i, i, i, d, vp, vp, vp, vp]
+        L.poppy_hip_pair_begin_prefiltered.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, i, i, i]
+        L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
+        L.poppy_hip_pair_points.argtypes = [vp, vp, vp, i, vp]
         _lib = L
     return _lib
 
@@ -92,6 +98,18 @@ def plan_frame(w, h, p1, p2, shape):
         raise PoppyError(f"poppy_plan_frame: {rc}")
     t = nt.value
     return dict(idx3=idx3[:t], tri_xy=tri[:t], M1=M1[:t], M2=M2[:t], inv1=i1[:t], inv2=i2[:t], morphed=mp)
+
+
+def match_points(p1, p2, w, h, tolerance=1.0):
+    """Host-only matcher (no GPU): returns (points1, points2, initial_morph_distance)."""
+    p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+    n = len(p1)
+    o1 = np.zeros((n + 4, 2), np.float32); o2 = np.zeros((n + 4, 2), np.float32)
+    m = C.c_int(0); imd = C.c_double(0)
+    rc = lib().poppy_match_points(_p(p1), _p(p2), n, w, h, tolerance, _p(o1), _p(o2), C.byref(m), C.byref(imd))
+    if rc:
+        raise PoppyError(f"poppy_match_points: {rc}")
+    return o1[:m.value].copy(), o2[:m.value].copy(), imd.value
 
 
 class Context:
@@ -151,6 +169,29 @@ class Context:
         out = np.empty((self.h_, self.w, 3), np.uint8) if fetch else None
         self._chk(lib().poppy_hip_render(self.h, shape, mask, int(chain), _p(out), self.w * 3), "render")
         return out
+
+    def orb_detect(self, gray, nfeatures):
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        cap = max(2 * nfeatures + 64, 64)
+        kp = np.zeros((cap, 7), np.float32)
+        n = C.c_int(0)
+        self._chk(lib().poppy_hip_orb_detect(self.h, _p(g), w, w, h, nfeatures, _p(kp), cap, C.byref(n)), "orb_detect")
+        return kp[:n.value].copy()
+
+    def pair_begin_prefiltered(self, bgr1, bgr2, g1, g2, gabor2, nfeatures):
+        a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
+        g1 = np.ascontiguousarray(g1, np.uint8); g2 = np.ascontiguousarray(g2, np.uint8)
+        g = np.ascontiguousarray(gabor2, np.float32)
+        h, w = a.shape[:2]
+        self._chk(lib().poppy_hip_pair_begin_prefiltered(self.h, _p(a), w * 3, _p(b), w * 3, _p(g1), _p(g2), _p(g), w, h, nfeatures), "pair_begin_prefiltered")
+        self.w, self.h_ = w, h
+
+    def pair_points(self, max_points=8192):
+        p1 = np.zeros((max_points, 2), np.float32); p2 = np.zeros((max_points, 2), np.float32)
+        n = C.c_int(0)
+        self._chk(lib().poppy_hip_pair_points(self.h, _p(p1), _p(p2), max_points, C.byref(n)), "pair_points")
+        return p1[:n.value].copy(), p2[:n.value].copy()
 
     def reset(self):
         self._chk(lib().poppy_hip_pair_reset(self.h), "pair_reset")

@@ -1,0 +1,32 @@
+// kernels_orb.h — launchers of the ORB / matcher kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace poppy_hip {
+
+constexpr int kOrbBorder = 32;     // max(edgeThreshold 31, ceil(15*sqrt 2) = 22, 4) + 1   (orb.cpp:985-989)
+constexpr int kOrbLevels = 8;
+
+struct OrbLevel {
+    int w, h;               // level size without border
+    size_t stride;          // row pitch of the padded level = w + 64
+    size_t offset;          // byte offset of the padded level inside the atlas
+    size_t score_offset;    // byte offset of the (unpadded) FAST score plane
+    float scale;            // 1.2^level as float
+};
+struct OrbLevelSet { int n; OrbLevel lv[kOrbLevels]; };
+
+void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8_t* atlas, const OrbLevelSet& S, hipStream_t s);
+void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, hipStream_t s);
+void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s);
+void launch_ic_angle(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* angle, hipStream_t s);
+
+// rBRIEF (WTA_K = 2): blurred copy of every level, then 32 bytes per keypoint.  kp = (level, x, y) in level coordinates.
+void launch_orb_blur(const uint8_t* atlas, uint8_t* blurred, const OrbLevelSet& S, hipStream_t s);
+void launch_orb_describe(const uint8_t* blurred, const OrbLevelSet& S, const int* kp, const float* angle_deg, int n, uint8_t* desc, hipStream_t s);
+
+// brute-force Hamming 1-NN: out[i] = (best train index, distance); ties -> lowest train index
+void launch_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out2, hipStream_t s);
+
+}  // namespace poppy_hip

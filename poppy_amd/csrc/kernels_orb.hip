@@ -1,0 +1,243 @@
+// kernels_orb.hip — ORB keypoint detection kernels for gfx950 (integer / byte work, wave64).
+//
+//   pyramid  : 8 levels, INTER_LINEAR_EXACT (8.8 fixed point) + 32-pixel reflect-101 border
+//              OCV/features2d/src/orb.cpp:1033-1113, OCV/imgproc/src/resize.cpp:345-398,619-760
+//   FAST     : FAST-9/16 corner test + corner score, threshold 20       fast.cpp:57-266, fast_score.cpp:120-211
+//   NMS      : strict 3x3 maximum, border filter (edgeThreshold 31), unordered append (the host
+//              sorts the few thousand survivors into raster order)       fast.cpp:271-290, keypoint.cpp:106-118
+//   Harris   : 7x7 block, Sobel-like integer sums                        orb.cpp:130-177
+//   IC angle : intensity centroid over the circular patch + fastAtan2    orb.cpp:181-215, mathfuncs_core.simd.hpp:34-64
+//   rBRIEF   : 7x7 sigma-2 fixed-point blur + 256 steered comparisons    orb.cpp:219-285,1188
+//   Hamming  : brute-force 1-NN, xor + popcount, wave min-reduction       batch_distance.cpp:103-110,199-262
+// Selection of the best keypoints (std::nth_element / std::partition order) stays on the host by design.
+#include "kernels_orb.h"
+#include <cfloat>
+#include <climits>
+
+namespace poppy_hip {
+
+__device__ __forceinline__ int reflect101i(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do { p = p < 0 ? -p : 2 * len - 2 - p; } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyramid
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_orb_level0(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride, uint8_t* __restrict__ atlas, OrbLevel L) {
+    int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= L.w + 2 * kOrbBorder) return;
+    int x = reflect101i(px - kOrbBorder, L.w), y = reflect101i(py - kOrbBorder, L.h);
+    atlas[L.offset + (size_t)py * L.stride + px] = src[(size_t)y * sstride + x];
+}
+
+// 8.8 coefficient pair of destination index v (interpolationLinear::getCoeffs); returns the source offset,
+// kind: 0 = interpolate, -1 = left of the image (use src[0]), +1 = right (use src[last])
+__device__ __forceinline__ int lin_coeff(int v, double scale, int ssize, int& c0, int& c1, int& kind) {
+    double f = scale * ((double)v + 0.5) - 0.5;
+    int iv = (int)floor(f);
+    if (iv >= 0 && ssize > 1) {
+        if (iv < ssize - 1) {
+            double frac = f - (double)iv;
+            c1 = frac < 0 ? 0 : __double2int_rn(frac * 256.0);
+            c0 = 256 > c1 ? 256 - c1 : 0;
+            kind = 0;
+            return iv;
+        }
+        kind = 1; c0 = c1 = 0;
+        return ssize - 1;
+    }
+    kind = -1; c0 = c1 = 0;
+    return 0;
+}
+
+// One padded pixel of level `L` from the interior of the previous level (`P`, or the input image for level 1).
+// The reference computes "left/right of the image" as contiguous index ranges [0,min) and [max,dsize); because
+// the source coordinate is monotonic in v these coincide with the per-index kinds computed here.
+__global__ void __launch_bounds__(256) k_orb_resize(const uint8_t* __restrict__ src, int sw, int sh, size_t sstride,
+                                                   uint8_t* __restrict__ atlas, OrbLevel L, double scale_x, double scale_y) {
+    int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= L.w + 2 * kOrbBorder) return;
+    int x = reflect101i(px - kOrbBorder, L.w), y = reflect101i(py - kOrbBorder, L.h);
+    int xc0, xc1, xk, yc0, yc1, yk;
+    int xo = lin_coeff(x, scale_x, sw, xc0, xc1, xk);
+    int yo = lin_coeff(y, scale_y, sh, yc0, yc1, yk);
+    auto hline = [&](int row) -> unsigned {
+        const uint8_t* s = src + (size_t)row * sstride;
+        if (xk == 0) return (unsigned)(xc0 * s[xo] + xc1 * s[xo + 1]) & 0xFFFFu;
+        return (unsigned)s[xk < 0 ? 0 : sw - 1] << 8;
+    };
+    unsigned out;
+    if (yk == 0) {
+        unsigned r0 = hline(yo), r1 = hline(yo + 1);
+        out = (r0 * (unsigned)yc0 + r1 * (unsigned)yc1 + (1u << 15)) >> 16;
+    } else {
+        unsigned r = hline(yk < 0 ? 0 : sh - 1);
+        out = ((r + 128u) & 0xFFFFu) >> 8;
+    }
+    atlas[L.offset + (size_t)py * L.stride + px] = (uint8_t)out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16
+// ------------------------------------------------------------------------------------------------
+__constant__ int c_ring[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                                  {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+__device__ __forceinline__ bool run9(unsigned m) {       // 16-bit circular mask has >= 9 consecutive ones
+    unsigned x = m | (m << 16);
+    unsigned a = x & (x >> 1);
+    a &= a >> 2;
+    a &= a >> 4;
+    a &= x >> 8;
+    return (a & 0xFFFFu) != 0;
+}
+
+__global__ void __launch_bounds__(256) k_fast_score(const uint8_t* __restrict__ atlas, OrbLevelSet S, uint8_t* __restrict__ scores, int threshold) {
+    const OrbLevel L = S.lv[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= L.w || y >= L.h) return;
+    uint8_t result = 0;
+    if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+        const uint8_t* c = atlas + L.offset + (size_t)(y + kOrbBorder) * L.stride + (x + kOrbBorder);
+        int v = c[0];
+        int d[16];
+        unsigned dark = 0, bright = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            d[k] = v - (int)c[c_ring[k][1] * (int)L.stride + c_ring[k][0]];
+            dark |= (unsigned)(d[k] > threshold) << k;          // ring < v - t
+            bright |= (unsigned)(d[k] < -threshold) << k;       // ring > v + t
+        }
+        if (run9(dark) || run9(bright)) {
+            int best_min = -1000, best_max = 1000;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int mn = d[k], mx = d[k];
+#pragma unroll
+                for (int j = 1; j < 9; ++j) { int e = d[(k + j) & 15]; mn = min(mn, e); mx = max(mx, e); }
+                best_min = max(best_min, mn);
+                best_max = min(best_max, mx);
+            }
+            result = (uint8_t)(max(best_min, -best_max) - 1);
+        }
+    }
+    scores[L.score_offset + (size_t)y * L.w + x] = result;
+}
+
+// strict 3x3 maximum + border filter; survivors appended unordered: (level, y*w + x, score)
+__global__ void __launch_bounds__(256) k_fast_nms(const uint8_t* __restrict__ scores, OrbLevelSet S, int edge, int* __restrict__ counters,
+                                                  int* __restrict__ cand, int cap) {
+    const int lvl = blockIdx.z;
+    const OrbLevel L = S.lv[lvl];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (L.w <= 2 * edge || L.h <= 2 * edge) return;
+    if (x < edge || x >= L.w - edge || y < edge || y >= L.h - edge) return;
+    const uint8_t* p = scores + L.score_offset + (size_t)y * L.w + x;
+    int s = p[0];
+    if (s == 0) return;
+    int W = L.w;
+    if (s > p[-1] && s > p[1] && s > p[-W - 1] && s > p[-W] && s > p[-W + 1] && s > p[W - 1] && s > p[W] && s > p[W + 1]) {
+        int slot = atomicAdd(&counters[lvl], 1);
+        if (slot < cap) { cand[((size_t)lvl * cap + slot) * 2] = y * W + x; cand[((size_t)lvl * cap + slot) * 2 + 1] = s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Harris response and intensity-centroid angle, one thread per keypoint: kp = (level, x, y)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_harris(const uint8_t* __restrict__ atlas, OrbLevelSet S, const int* __restrict__ kp, int n, float* __restrict__ resp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OrbLevel L = S.lv[kp[3 * i]];
+    const int st = (int)L.stride;
+    const uint8_t* c = atlas + L.offset + (size_t)(kp[3 * i + 2] + kOrbBorder) * L.stride + (kp[3 * i + 1] + kOrbBorder);
+    int a = 0, b = 0, cc = 0;
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) {
+            const uint8_t* p = c + dy * st + dx;
+            int Ix = ((int)p[1] - p[-1]) * 2 + ((int)p[-st + 1] - p[-st - 1]) + ((int)p[st + 1] - p[st - 1]);
+            int Iy = ((int)p[st] - p[-st]) * 2 + ((int)p[st - 1] - p[-st - 1]) + ((int)p[st + 1] - p[-st + 1]);
+            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+        }
+    const float harris_k = 0.04f;
+    float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    float s4 = scale * scale * scale * scale;
+    resp[i] = ((float)a * (float)b - (float)cc * (float)cc - harris_k * ((float)a + (float)b) * ((float)a + (float)b)) * s4;
+}
+
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.141592653589793238462643383279502884197169399375105820974944592307816406286),
+                p3 = -0.3258083974640975f * (float)(180 / 3.141592653589793238462643383279502884197169399375105820974944592307816406286),
+                p5 = 0.1555786518463281f * (float)(180 / 3.141592653589793238462643383279502884197169399375105820974944592307816406286),
+                p7 = -0.04432655554792128f * (float)(180 / 3.141592653589793238462643383279502884197169399375105820974944592307816406286);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, ax + (float)DBL_EPSILON); c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = __fdiv_rn(ax, ay + (float)DBL_EPSILON); c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ void k_ic_angle(const uint8_t* __restrict__ atlas, OrbLevelSet S, const int* __restrict__ kp, int n, float* __restrict__ angle) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OrbLevel L = S.lv[kp[3 * i]];
+    const int st = (int)L.stride;
+    const uint8_t* c = atlas + L.offset + (size_t)(kp[3 * i + 2] + kOrbBorder) * L.stride + (kp[3 * i + 1] + kOrbBorder);
+    int m01 = 0, m10 = 0;
+    for (int u = -15; u <= 15; ++u) m10 += u * (int)c[u];
+    for (int v = 1; v <= 15; ++v) {
+        int vsum = 0, d = c_umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int p = c[u + v * st], m = c[u - v * st];
+            vsum += p - m;
+            m10 += u * (p + m);
+        }
+        m01 += v * vsum;
+    }
+    angle[i] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8_t* atlas, const OrbLevelSet& S, hipStream_t s) {
+    for (int l = 0; l < S.n; ++l) {
+        const OrbLevel& L = S.lv[l];
+        dim3 grid((L.w + 2 * kOrbBorder + 255) / 256, L.h + 2 * kOrbBorder);
+        if (l == 0) {
+            hipLaunchKernelGGL(k_orb_level0, grid, dim3(256), 0, s, d_img, w, h, stride, atlas, L);
+        } else {
+            const uint8_t* src; int sw, sh; size_t sst;
+            if (l == 1) { src = d_img; sw = w; sh = h; sst = stride; }
+            else { const OrbLevel& P = S.lv[l - 1]; src = atlas + P.offset + (size_t)kOrbBorder * P.stride + kOrbBorder; sw = P.w; sh = P.h; sst = P.stride; }
+            double sx = 1.0 / ((double)L.w / sw), sy = 1.0 / ((double)L.h / sh);
+            hipLaunchKernelGGL(k_orb_resize, grid, dim3(256), 0, s, src, sw, sh, sst, atlas, L, sx, sy);
+        }
+    }
+}
+
+void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, hipStream_t s) {
+    dim3 grid((S.lv[0].w + 255) / 256, S.lv[0].h, S.n);
+    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, atlas, S, scores, threshold);
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, scores, S, edge, counters, cand, cap);
+}
+
+void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_harris, dim3((n + 63) / 64), dim3(64), 0, s, atlas, S, kp, n, resp);
+}
+void launch_ic_angle(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* angle, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_ic_angle, dim3((n + 63) / 64), dim3(64), 0, s, atlas, S, kp, n, angle);
+}
+
+}  // namespace poppy_hip

@@ -1,0 +1,163 @@
+// orb_detect.cpp — host side of ORB::detect on the GPU: level geometry, kernel sequencing and the
+// order-sensitive selection steps that the reference performs with libstdc++ algorithms.
+//
+//   OCV/features2d/src/orb.cpp:970-1127  detectAndCompute (atlas layout, resize chain)
+//   OCV/features2d/src/orb.cpp:784-959   computeKeyPoints (per-level quota, FAST -> border filter -> retainBest(2n)
+//                                        -> Harris -> retainBest(n) -> IC angle -> pt *= scale)
+//   OCV/features2d/src/keypoint.cpp:69-90 retainBest: std::nth_element + std::partition.  The resulting ORDER
+//                                        is part of the contract (Poppy truncates and pairs keypoints by position,
+//                                        src/extractor.cpp:96-99), so these two calls stay on the host and use
+//                                        the very same library routines.
+#include "orb_detect.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace poppy_hip {
+
+namespace {
+inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
+
+struct Cand { int x, y, level; float response; };
+struct ByResponse { bool operator()(const Cand& a, const Cand& b) const { return a.response > b.response; } };
+
+void retain_best(std::vector<Cand>& k, int n) {
+    if (n >= 0 && k.size() > (size_t)n) {
+        if (n == 0) { k.clear(); return; }
+        std::nth_element(k.begin(), k.begin() + n - 1, k.end(), ByResponse());
+        const float ambiguous = k[n - 1].response;
+        auto new_end = std::partition(k.begin() + n, k.end(), [ambiguous](const Cand& c) { return c.response >= ambiguous; });
+        k.resize(new_end - k.begin());
+    }
+}
+}  // namespace
+
+void OrbDetector::release() {
+    void* bufs[] = {d_img, d_atlas, d_blur, d_scores, d_counters, d_cand, d_kp, d_val, d_desc};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    d_img = d_atlas = d_blur = d_scores = nullptr; d_counters = d_cand = d_kp = nullptr; d_val = nullptr; d_desc = nullptr;
+    if (h_cand) (void)hipHostFree(h_cand);
+    if (h_kp) (void)hipHostFree(h_kp);
+    if (h_val) (void)hipHostFree(h_val);
+    h_cand = nullptr; h_kp = nullptr; h_val = nullptr;
+    W = H = 0;
+}
+
+hipError_t OrbDetector::prepare(int w, int h) {
+    if (w == W && h == H) return hipSuccess;
+    release();
+    const double scaleFactor = (double)1.2f;                       // ORB::create takes a float, stores a double
+    size_t off = 0, soff = 0;
+    S.n = kOrbLevels;
+    for (int l = 0; l < kOrbLevels; ++l) {
+        OrbLevel& L = S.lv[l];
+        L.scale = (float)std::pow(scaleFactor, (double)l);
+        const float inv = 1.0f / L.scale;
+        L.w = round_half_even(w * inv); L.h = round_half_even(h * inv);
+        L.stride = (size_t)L.w + 2 * kOrbBorder;
+        L.offset = off; L.score_offset = soff;
+        off += L.stride * ((size_t)L.h + 2 * kOrbBorder);
+        soff += (size_t)L.w * L.h;
+        off = (off + 255) & ~(size_t)255; soff = (soff + 255) & ~(size_t)255;
+    }
+    atlas_bytes = off;
+    cap = std::max(4096, w * h / 16);
+    kp_cap = 1 << 16;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_img, (size_t)w * h)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_atlas, off)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_blur, off)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_scores, soff)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_counters, kOrbLevels * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_cand, (size_t)kOrbLevels * cap * 2 * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_desc, (size_t)kp_cap * 32)) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_cand, ((size_t)kOrbLevels * cap * 2 + kOrbLevels) * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
+    W = w; H = h;
+    return hipSuccess;
+}
+
+#define ORB_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
+
+int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out) {
+    out.clear();
+    ORB_CHK(prepare(w, h));
+    const int edge = 31, patch = 31, fastThreshold = 20;
+    ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, hipMemcpyHostToDevice, s));
+    launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
+    ORB_CHK(hipMemsetAsync(d_counters, 0, kOrbLevels * sizeof(int), s));
+    launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, s);
+    int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
+    ORB_CHK(hipMemcpyAsync(h_counts, d_counters, kOrbLevels * sizeof(int), hipMemcpyDeviceToHost, s));
+    ORB_CHK(hipStreamSynchronize(s));
+    for (int l = 0; l < kOrbLevels; ++l) {
+        if (h_counts[l] > cap) { err = "FAST candidate buffer overflow"; return -1; }
+        if (h_counts[l])
+            ORB_CHK(hipMemcpyAsync(h_cand + (size_t)l * cap * 2, d_cand + (size_t)l * cap * 2, (size_t)h_counts[l] * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    ORB_CHK(hipStreamSynchronize(s));
+
+    // per-level quota (orb.cpp:803-813)
+    int quota[kOrbLevels];
+    {
+        const float factor = (float)(1.0 / (double)1.2f);
+        float desired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)kOrbLevels));
+        int sum = 0;
+        for (int l = 0; l < kOrbLevels - 1; ++l) { quota[l] = round_half_even(desired); sum += quota[l]; desired *= factor; }
+        quota[kOrbLevels - 1] = std::max(nfeatures - sum, 0);
+    }
+
+    std::vector<Cand> all, k;
+    int counts[kOrbLevels];
+    for (int l = 0; l < kOrbLevels; ++l) {
+        const int n = h_counts[l], lw = S.lv[l].w;
+        const int* c = h_cand + (size_t)l * cap * 2;
+        std::vector<std::pair<int, int>> keyed(n);
+        for (int i = 0; i < n; ++i) keyed[i] = {c[2 * i], c[2 * i + 1]};
+        std::sort(keyed.begin(), keyed.end());                  // raster order = FAST's emission order (fast.cpp:271-290)
+        k.resize(n);
+        for (int i = 0; i < n; ++i) k[i] = Cand{keyed[i].first % lw, keyed[i].first / lw, l, (float)keyed[i].second};
+        retain_best(k, 2 * quota[l]);
+        counts[l] = (int)k.size();
+        all.insert(all.end(), k.begin(), k.end());
+    }
+    if (all.empty()) return 0;
+    if ((int)all.size() > kp_cap) { err = "keypoint buffer overflow"; return -1; }
+
+    auto upload = [&](const std::vector<Cand>& v) -> hipError_t {
+        for (size_t i = 0; i < v.size(); ++i) { h_kp[3 * i] = v[i].level; h_kp[3 * i + 1] = v[i].x; h_kp[3 * i + 2] = v[i].y; }
+        return hipMemcpyAsync(d_kp, h_kp, v.size() * 3 * sizeof(int), hipMemcpyHostToDevice, s);
+    };
+    ORB_CHK(upload(all));
+    launch_harris(d_atlas, S, d_kp, (int)all.size(), d_val, s);
+    ORB_CHK(hipMemcpyAsync(h_val, d_val, all.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    ORB_CHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < all.size(); ++i) all[i].response = h_val[i];
+
+    std::vector<Cand> fin;
+    size_t off = 0;
+    for (int l = 0; l < kOrbLevels; ++l) {
+        k.assign(all.begin() + off, all.begin() + off + counts[l]);
+        off += counts[l];
+        retain_best(k, quota[l]);
+        fin.insert(fin.end(), k.begin(), k.end());
+    }
+    if (fin.empty()) return 0;
+    ORB_CHK(upload(fin));
+    launch_ic_angle(d_atlas, S, d_kp, (int)fin.size(), d_val, s);
+    ORB_CHK(hipMemcpyAsync(h_val, d_val, fin.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    ORB_CHK(hipStreamSynchronize(s));
+    out.resize(fin.size());
+    last_levels.resize(fin.size() * 3);
+    for (size_t i = 0; i < fin.size(); ++i) {
+        const float sc = S.lv[fin[i].level].scale;
+        out[i] = OrbKeyPoint{(float)fin[i].x * sc, (float)fin[i].y * sc, patch * sc, h_val[i], fin[i].response, fin[i].level, -1};
+        last_levels[3 * i] = fin[i].level; last_levels[3 * i + 1] = fin[i].x; last_levels[3 * i + 2] = fin[i].y;
+    }
+    return (int)fin.size();
+}
+
+}  // namespace poppy_hip

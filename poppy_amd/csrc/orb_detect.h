@@ -1,0 +1,34 @@
+// orb_detect.h — ORB::detect driver (host) over the kernels of kernels_orb.hip.
+#pragma once
+#include "kernels_orb.h"
+#include <string>
+#include <vector>
+
+namespace poppy_hip {
+
+struct OrbKeyPoint { float x, y, size, angle, response; int octave, class_id; };   // cv::KeyPoint field order
+
+class OrbDetector {
+public:
+    ~OrbDetector() { release(); }
+    // ORB::create(nfeatures)->detect(gray): host image in, keypoints (order significant) out.  <0 on error (see err).
+    int detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out);
+    void release();
+    std::string err;
+
+    // state of the last detect() call, reused by describe(): atlas on the device + (level, x, y) per keypoint
+    OrbLevelSet S{};
+    uint8_t *d_img = nullptr, *d_atlas = nullptr, *d_blur = nullptr, *d_scores = nullptr, *d_desc = nullptr;
+    int *d_counters = nullptr, *d_cand = nullptr, *d_kp = nullptr;
+    float* d_val = nullptr;
+    int *h_cand = nullptr, *h_kp = nullptr;
+    float* h_val = nullptr;
+    std::vector<int> last_levels;
+    size_t atlas_bytes = 0;
+    int W = 0, H = 0, cap = 0, kp_cap = 0;
+
+private:
+    hipError_t prepare(int w, int h);
+};
+
+}  // namespace poppy_hip

@@ -1,0 +1,271 @@
+// point_match.cpp — Poppy's keypoint pairing on the host (see point_match.h for why it is host code).
+//
+//   src/util.cpp:351-383   make_distance_map: greedy first-come nearest neighbour, ascending by distance
+//   src/util.cpp:385-431   morph_distance (hull areas, mean pair distance, signed coordinate sums; long double mix)
+//   src/util.cpp:473-496   filter_invalid_points
+//   src/matcher.cpp:246-332 match (statistical threshold) + prepare (add_corners, src/util.cpp:268-279)
+//   OCV/imgproc/src/convhull.cpp:48-312, approx.cpp:476-671, shapedescr.cpp:308-338 (hull, Douglas-Peucker, area)
+// The reference translation unit is `using namespace std`, so hypot(float,float) resolves to the float overload.
+#include "point_match.h"
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace poppy_hip {
+
+void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs) {
+    std::vector<P2f> pool = src2;
+    std::vector<char> taken(pool.size(), 0);
+    pairs.clear();
+    pairs.reserve(src1.size());
+    for (const P2f& a : src1) {
+        double best = std::numeric_limits<double>::max();
+        int pick = -1;
+        for (size_t j = 0; j < pool.size(); ++j) {
+            if (taken[j] || (pool[j].x == -1 && pool[j].y == -1)) continue;     // (-1,-1) doubles as the tombstone value
+            double d = hypotf(pool[j].x - a.x, pool[j].y - a.y);
+            if (d < best) { best = d; pick = (int)j; }
+        }
+        if (pick < 0) continue;
+        pairs.push_back(PointPair{(double)hypotf(pool[pick].x - a.x, pool[pick].y - a.y), a, pool[pick]});
+        taken[pick] = 1;
+    }
+    // multimap<double,...>: ascending keys, equal keys in insertion order
+    std::stable_sort(pairs.begin(), pairs.end(), [](const PointPair& l, const PointPair& r) { return l.dist < r.dist; });
+}
+
+void drop_out_of_image(std::vector<P2f>& p1, std::vector<P2f>& p2, int cols, int rows) {
+    auto bad = [&](const P2f& p) { return p.x < 0 || p.x > cols || p.y < 0 || p.y > rows; };
+    for (size_t i = 0; i < p1.size();)
+        if (bad(p1[i])) { p1.erase(p1.begin() + i); p2.erase(p2.begin() + i); } else ++i;
+    for (size_t i = 0; i < p2.size();)
+        if (bad(p2[i])) { p1.erase(p1.begin() + i); p2.erase(p2.begin() + i); } else ++i;
+    if (p1.size() > p2.size()) p1.resize(p2.size()); else p2.resize(p1.size());
+}
+
+namespace {
+
+inline int sign_of(double v) { return (v > 0) - (v < 0); }
+
+// one monotone chain of Sklansky's scan over the x-sorted points
+int chain(const std::vector<const P2f*>& a, int start, int end, int* stk, int nsign, int sign2) {
+    const int step = end > start ? 1 : -1;
+    int prev = start, cur = prev + step, next = cur + step, size = 3;
+    if (start == end || (a[start]->x == a[end]->x && a[start]->y == a[end]->y)) { stk[0] = start; return 1; }
+    stk[0] = prev; stk[1] = cur; stk[2] = next;
+    end += step;
+    while (next != end) {
+        const float cy = a[cur]->y, ny = a[next]->y, by = ny - cy;
+        if (sign_of(by) != nsign) {
+            const float ax = a[cur]->x - a[prev]->x, bx = a[next]->x - a[cur]->x, ay = cy - a[prev]->y;
+            const double turn = (double)ay * bx - (double)ax * by;
+            if (sign_of(turn) == sign2 && (ax != 0 || ay != 0)) {
+                prev = cur; cur = next; next += step; stk[size++] = next;
+            } else if (prev == start) {
+                cur = next; stk[1] = cur; next += step; stk[2] = next;
+            } else {
+                stk[size - 2] = next; cur = prev; prev = stk[size - 4]; --size;
+            }
+        } else { next += step; stk[size - 1] = next; }
+    }
+    return --size;
+}
+
+void hull_ccw(const std::vector<P2f>& pts, std::vector<P2f>& hull) {
+    const int n = (int)pts.size();
+    hull.clear();
+    if (!n) return;
+    std::vector<const P2f*> a(n);
+    for (int i = 0; i < n; ++i) a[i] = &pts[i];
+    std::sort(a.begin(), a.end(), [](const P2f* l, const P2f* r) {
+        if (l->x != r->x) return l->x < r->x;
+        if (l->y != r->y) return l->y < r->y;
+        return l < r;
+    });
+    int lo = 0, hi = 0;
+    for (int i = 1; i < n; ++i) { if (a[lo]->y > a[i]->y) lo = i; if (a[hi]->y < a[i]->y) hi = i; }
+    std::vector<int> stk(n + 2), idx(n);
+    int m = 0;
+    const P2f* base = pts.data();
+    if (a[0]->x == a[n - 1]->x && a[0]->y == a[n - 1]->y) idx[m++] = 0;
+    else {
+        int* s0 = stk.data(); int c0 = chain(a, 0, hi, s0, -1, 1);
+        int* s1 = s0 + c0;    int c1 = chain(a, n - 1, hi, s1, -1, -1);
+        std::swap(s0, s1); std::swap(c0, c1);
+        for (int i = 0; i < c0 - 1; ++i) idx[m++] = (int)(a[s0[i]] - base);
+        for (int i = c1 - 1; i > 0; --i) idx[m++] = (int)(a[s1[i]] - base);
+        const int stop = c1 > 2 ? s1[1] : c0 > 2 ? s0[c0 - 2] : -1;
+        int* b0 = stk.data(); int d0 = chain(a, 0, lo, b0, 1, -1);
+        int* b1 = b0 + d0;    int d1 = chain(a, n - 1, lo, b1, 1, 1);
+        if (stop >= 0) {
+            const int chk = d0 > 2 ? b0[1] : d0 + d1 > 2 ? b1[2 - d0] : -1;
+            if (chk == stop || (chk >= 0 && a[chk]->x == a[stop]->x && a[chk]->y == a[stop]->y)) { d0 = std::min(d0, 2); d1 = std::min(d1, 2); }
+        }
+        for (int i = 0; i < d0 - 1; ++i) idx[m++] = (int)(a[b0[i]] - base);
+        for (int i = d1 - 1; i > 0; --i) idx[m++] = (int)(a[b1[i]] - base);
+        if (m >= 3) {                    // rotate so the index sequence is monotone when it can be
+            int imin = 0, imax = 0, lt = 0, i;
+            for (i = 1; i < m; ++i) {
+                lt += idx[i - 1] < idx[i];
+                if (lt > 1 && lt <= i - 2) break;
+                if (idx[i] < idx[imin]) imin = i;
+                if (idx[i] > idx[imax]) imax = i;
+            }
+            const int gap = std::abs(imax - imin);
+            if ((gap == 1 || gap == m - 1) && (lt <= 1 || lt >= m - 2)) {
+                const int asc = (imax + 1) % m == imin;
+                int i0 = asc ? imin : imax, j = i0;
+                if (i0 > 0) {
+                    int* tmp = stk.data();
+                    for (i = 0; i < m; ++i) {
+                        const int c = tmp[i] = idx[j], nj = j + 1 < m ? j + 1 : 0;
+                        if (i < m - 1 && (asc != (c < idx[nj]))) break;
+                        j = nj;
+                    }
+                    if (i == m) std::copy(tmp, tmp + m, idx.begin());
+                }
+            }
+        }
+    }
+    for (int i = 0; i < m; ++i) hull.push_back(base[idx[i]]);
+}
+
+// approxPolyDP(hull, eps, closed = true)
+void simplify_closed(const std::vector<P2f>& src, double eps, std::vector<P2f>& out) {
+    int count = (int)src.size();
+    out.clear();
+    if (!count) return;
+    struct Span { int s, e; };
+    std::vector<Span> todo;
+    std::vector<P2f> dst(count);
+    int kept = 0, pos = 0;
+    Span cur{0, 0}, right{0, 0};
+    P2f a{-1000000.f, -1000000.f}, b{0, 0}, p{0, 0};
+    bool flat = false;
+    eps *= eps;
+    auto next_src = [&](P2f& q, int& i) { q = src[i]; if (++i >= count) i = 0; };
+    for (int it = 0; it < 3; ++it) {          // approximately the two farthest points
+        double far = 0;
+        pos = (pos + right.s) % count;
+        next_src(a, pos);
+        for (int j = 1; j < count; ++j) {
+            next_src(p, pos);
+            const double dx = p.x - a.x, dy = p.y - a.y, d = dx * dx + dy * dy;
+            if (d > far) { far = d; right.s = j; }
+        }
+        flat = far <= eps;
+    }
+    if (!flat) {
+        right.e = cur.s = pos % count;
+        cur.e = right.s = (right.s + cur.s) % count;
+        todo.push_back(right); todo.push_back(cur);
+    } else dst[kept++] = a;
+    while (!todo.empty()) {
+        cur = todo.back(); todo.pop_back();
+        b = src[cur.e];
+        pos = cur.s;
+        next_src(a, pos);
+        if (pos != cur.e) {
+            double far = 0;
+            const double dx = b.x - a.x, dy = b.y - a.y;
+            while (pos != cur.e) {
+                next_src(p, pos);
+                const double d = std::fabs((p.y - a.y) * dx - (p.x - a.x) * dy);
+                if (d > far) { far = d; right.s = (pos + count - 1) % count; }
+            }
+            flat = far * far <= eps * (dx * dx + dy * dy);
+        } else { flat = true; a = src[cur.s]; }
+        if (flat) dst[kept++] = a;
+        else { right.e = cur.e; cur.e = right.s; todo.push_back(right); todo.push_back(cur); }
+    }
+    count = kept;
+    auto next_dst = [&](P2f& q, int& i) { q = dst[i]; if (++i >= count) i = 0; };
+    pos = count - 1;
+    next_dst(a, pos);
+    int w = pos;
+    next_dst(p, pos);
+    for (int i = 0; i < count && kept > 2; ++i) {
+        next_dst(b, pos);
+        const double dx = b.x - a.x, dy = b.y - a.y;
+        const double d = std::fabs((p.x - a.x) * dy - (p.y - a.y) * dx);
+        const double along = (p.x - a.x) * (b.x - p.x) + (p.y - a.y) * (b.y - p.y);    // evaluated in float
+        if (d * d <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && along >= 0) {
+            --kept;
+            dst[w] = a = b;
+            if (++w >= count) w = 0;
+            next_dst(p, pos);
+            ++i;
+            continue;
+        }
+        dst[w] = a = p;
+        if (++w >= count) w = 0;
+        p = b;
+    }
+    out.assign(dst.begin(), dst.begin() + kept);
+}
+
+double polygon_area(const std::vector<P2f>& c) {
+    if (c.empty()) return 0.;
+    double acc = 0;
+    P2f prev = c.back();
+    for (const P2f& q : c) { acc += (double)prev.x * q.y - (double)prev.y * q.x; prev = q; }
+    return std::fabs(acc * 0.5);
+}
+
+double hull_area(const std::vector<P2f>& pts) {
+    std::vector<P2f> h, c;
+    hull_ccw(pts, h);
+    simplify_closed(h, 0.001, c);
+    return std::fabs(polygon_area(c));
+}
+
+}  // namespace
+
+double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h) {
+    const long double width = w, height = h;
+    std::vector<PointPair> pairs;
+    greedy_pairs(p1, p2, pairs);
+    const double area1 = hull_area(p1), area2 = hull_area(p2);
+    float in1 = 0, in2 = 0;
+    for (size_t i = 0; i < p1.size(); ++i)
+        for (size_t j = 0; j < p1.size(); ++j) { const float vx = p1[i].x - p1[j].x, vy = p1[i].y - p1[j].y; in1 += vx + vy; }
+    in1 = (float)((in1 / (p1.size() * p1.size())) / (width + height));
+    for (size_t i = 0; i < p2.size(); ++i)
+        for (size_t j = 0; j < p2.size(); ++j) { const float vx = p2[i].x - p1[j].x, vy = p2[i].y - p1[j].y; in2 += vx + vy; }   // second set against the FIRST, as in the reference
+    in2 = (float)((in2 / (p2.size() * p2.size())) / (width + height));
+    float total = 0;
+    for (const PointPair& e : pairs) total += hypotf(e.b.x - e.a.x, e.b.y - e.a.y);
+    const long double r = ((total / (pairs.size())) / hypotl(width, height)) + fabs(in1 - in2) + (fabs(area1 - area2) / (width * height)) / 3.0;
+    return (double)r;
+}
+
+void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist) {
+    std::vector<PointPair> pairs;
+    greedy_pairs(s1, s2, pairs);
+    const size_t n = pairs.size();
+    double sum = 0.0;
+    for (const PointPair& e : pairs) sum += e.dist;
+    const double mean = sum / n;
+    double var = 0.0;
+    for (const PointPair& e : pairs) var += pow(e.dist - mean, 2);
+    const double deviation = sqrt(var / n), total = sum;
+    const double density = total / (w * h), area = (w * h);
+    s1.clear(); s2.clear();
+    if (mean == 0) {
+        for (const PointPair& e : pairs) { s1.push_back(e.a); s2.push_back(e.b); }
+    } else {
+        double thresh = 1;
+        if (tolerance != 0)
+            thresh = (area * (mean / deviation) * tolerance) / ((total * sqrt(density) * (1.0 / sqrt(initial_morph_dist))) / ((1 + sqrt(5)) / 2.0));
+        for (const PointPair& e : pairs) {
+            const double r = e.dist / thresh;
+            if (r > 0.0 && r <= 1.0) { s1.push_back(e.a); s2.push_back(e.b); }
+        }
+        if (s1.empty() && n) { s1.push_back(pairs[0].a); s2.push_back(pairs[0].b); }
+    }
+    const float fw = (float)(w - 1), fh = (float)(h - 1);
+    const P2f corners[4] = {{0, 0}, {fw, 0}, {0, fh}, {fw, fh}};
+    for (const P2f& c : corners) { s1.push_back(c); s2.push_back(c); }
+}
+
+}  // namespace poppy_hip

@@ -1,0 +1,20 @@
+// point_match.h — Poppy's keypoint pairing (greedy nearest neighbour on POSITIONS + statistical threshold).
+//
+// This stage is a strictly sequential claim process over ~500 points (each claim changes what the next
+// point may take) followed by double / long-double statistics whose libm results (hypotf, hypotl, sqrt, pow)
+// must equal the reference's bit for bit; it costs < 1 ms once per pair.  It therefore runs on the host with
+// the same libm, exactly like the order-defining std::nth_element of ORB.
+#pragma once
+#include "frame_plan.h"
+#include <vector>
+
+namespace poppy_hip {
+
+struct PointPair { double dist; P2f a, b; };
+
+void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs);   // make_distance_map
+void drop_out_of_image(std::vector<P2f>& p1, std::vector<P2f>& p2, int cols, int rows);                         // filter_invalid_points + resize
+double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h);               // morph_distance
+void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist);
+
+}  // namespace poppy_hip

@@ -18,6 +18,8 @@
 #include "../../include/poppy_hip.h"
 #include "frame_plan.h"
 #include "kernels.h"
+#include "orb_detect.h"
+#include "point_match.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -60,6 +62,8 @@ struct poppy_hip_ctx {
     hipEvent_t ring_done[kRing] = {};
     int ring_pos = 0;
     FramePlan plan;
+    OrbDetector orb;
+    double initial_morph_dist = 0;
     // diagnostics
     bool debug = false, timing = false;
     struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
@@ -482,6 +486,71 @@ int poppy_plan_frame(int W, int H, const float* p1, const float* p2, int n, doub
     if (inv1 && T) memcpy(inv1, plan.inv1.data(), (size_t)T * 36);
     if (inv2 && T) memcpy(inv2, plan.inv2.data(), (size_t)T * 36);
     if (morphed && n) memcpy(morphed, plan.morphed.data(), (size_t)n * 8);
+    return POPPY_OK;
+}
+
+int poppy_hip_orb_detect(poppy_hip_ctx* c, const uint8_t* gray, size_t stride, int W, int H, int nfeatures, float* kps7, int max_kps, int* n_kps) {
+    if (!c || !gray || !n_kps || W <= 0 || H <= 0 || stride < (size_t)W || nfeatures < 0) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<OrbKeyPoint> kps;
+    int n = c->orb.detect(gray, stride, W, H, nfeatures, c->stream, kps);
+    if (n < 0) { c->err = "orb_detect: " + c->orb.err; return n == -2 ? POPPY_E_DEVICE : POPPY_E_ARG; }
+    *n_kps = n;
+    if (n > max_kps) return fail(c, POPPY_E_ARG, "max_kps too small");
+    for (int i = 0; i < n && kps7; ++i) {
+        float* o = kps7 + (size_t)i * 7;
+        o[0] = kps[i].x; o[1] = kps[i].y; o[2] = kps[i].size; o[3] = kps[i].angle; o[4] = kps[i].response;
+        o[5] = (float)kps[i].octave; o[6] = (float)kps[i].class_id;
+    }
+    return POPPY_OK;
+}
+
+int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
+    if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
+    std::vector<P2f> a(n), b(n);
+    if (n) { memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8); }
+    drop_out_of_image(a, b, W, H);
+    if (a.empty()) { *n_out = 0; if (imd) *imd = 0; return POPPY_OK; }     // caller falls back to the dissolve (poppy.hpp:125)
+    const double d = morph_distance_ref(a, b, W, H);
+    if (imd) *imd = d;
+    match_and_prepare(a, b, W, H, tol, d);
+    *n_out = (int)a.size();
+    if (o1) memcpy(o1, a.data(), a.size() * 8);
+    if (o2) memcpy(o2, b.data(), b.size() * 8);
+    return POPPY_OK;
+}
+
+int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2,
+                                     const uint8_t* g1, const uint8_t* g2, const float* gabor2, int W, int H, int nfeatures) {
+    if (!c || !bgr1 || !bgr2 || !g1 || !g2 || !gabor2) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<OrbKeyPoint> k1, k2;
+    if (c->orb.detect(g1, W, W, H, nfeatures, c->stream, k1) < 0 || c->orb.detect(g2, W, W, H, nfeatures, c->stream, k2) < 0) {
+        c->err = "orb_detect: " + c->orb.err;
+        return POPPY_E_DEVICE;
+    }
+    const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
+    std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
+    for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
+    int m = 0;
+    int rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
+    if (rc) return fail(c, rc, "poppy_match_points failed");
+    return poppy_hip_pair_load(c, bgr1, s1, bgr2, s2, gabor2, W, H, o1.data(), o2.data(), m);
+}
+
+int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t*, size_t, const uint8_t*, size_t, int, int) {
+    if (!c) return POPPY_E_ARG;
+    return fail(c, POPPY_E_UNSUPPORTED, "the pre-ORB filter chain (MOG2 / median / Gabor / dft_detail2) is not part of this round; "
+                                        "use poppy_hip_pair_begin_prefiltered");
+}
+
+int poppy_hip_pair_points(poppy_hip_ctx* c, float* p1, float* p2, int max_points, int* n_points) {
+    if (!c || !n_points) return POPPY_E_ARG;
+    const int n = (int)c->pts1_0.size();
+    *n_points = n;
+    if (n > max_points) return fail(c, POPPY_E_ARG, "max_points too small");
+    if (p1 && n) memcpy(p1, c->pts1_0.data(), (size_t)n * 8);
+    if (p2 && n) memcpy(p2, c->pts2.data(), (size_t)n * 8);
     return POPPY_OK;
 }
 

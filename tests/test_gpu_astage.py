@@ -1,0 +1,64 @@
+"""GPU parity of the once-per-pair stage: ORB detect kernels + host selection vs reference fixtures / oracle."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from poppy_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case", ["o_256x256", "o_640x480", "o_1920x1080"])
+def test_orb_detect_vs_reference(ctx, case):
+    inp = G.orb_inputs(case)
+    w, h, nfs = G.make_inputs.ORB[case]
+    for nf in nfs:
+        for im in ("1", "2"):
+            G.check(case, f"n{nf}_kp{im}", ctx.orb_detect(inp["g" + im], nf))
+
+
+@pytest.mark.parametrize("w,h,nf", [(97, 80, 50), (333, 211, 200), (1000, 70, 300), (64, 64, 100)])
+def test_orb_detect_vs_oracle_ragged(ctx, w, h, nf):
+    g = synth.textured_gray(w, h, 3)
+    want = O.orb_detect(g, nf)
+    got = ctx.orb_detect(g, nf)
+    assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_orb_on_reference_prefiltered_images(ctx):
+    case = "a_512x384_chain"
+    nf = int(G.full(case, "detail")[3])
+    G.check(case, "kp1", ctx.orb_detect(G.full(case, "g1"), nf))
+    G.check(case, "kp2", ctx.orb_detect(G.full(case, "g2"), nf))
+
+
+def test_pair_begin_prefiltered_reproduces_reference_frames(ctx):
+    """From the reference's ORB inputs + gabor2 (fixtures) to the first chained frames of poppy::morph."""
+    case = "a_256x256_chain"
+    inp = G.astage_inputs(case)
+    nf = int(G.full(case, "detail")[3])
+    gabor2 = G.full(case, "gabor2")
+    c = capi.Context(0, number_of_frames=int(inp["cfg"][0]))
+    c.pair_begin_prefiltered(inp["img1"], inp["img2"], G.full(case, "g1"), G.full(case, "g2"), gabor2, nf)
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
+    frames = c.morph_frames(-1.0)
+    assert len(frames) == int(inp["cfg"][0])
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
+    c.close()
+
+
+def test_pair_begin_raw_is_unsupported_not_approximated(ctx):
+    a = synth.textured_bgr(64, 48, 1)
+    rc = capi.lib().poppy_hip_pair_begin(ctx.h, capi._p(a), 64 * 3, capi._p(a), 64 * 3, 64, 48)
+    assert rc == -6

@@ -56,3 +56,30 @@ def test_frame_ratio_scheduler():
         assert L.poppy_frame_ratio(j, N, -1.0) == min(1.0, (1.0 / (1.0 - lin)) / N)
     assert L.poppy_frame_ratio(0, 1, 0.5) == 0.5           # --frames 1 --phase t  =>  shape = t
     assert L.poppy_frame_ratio(0, 60, 0.5) == 0.5 * (1.0 / 60)
+
+
+@pytest.mark.parametrize("case", ["m_640x480", "m_1920x1080", "m_tol2"])
+def test_host_point_matcher_matches_reference(case):
+    """poppy_match_points = filter_invalid_points + morph_distance + Matcher::match/prepare (host C++, no GPU)."""
+    inp = G.match_inputs(case)
+    w, h, tol = int(inp["cfg"][0]), int(inp["cfg"][1]), float(inp["cfg"][2])
+    a, b, imd = capi.match_points(inp["pts1"], inp["pts2"], w, h, tol)
+    G.check(case, "initialMorphDist", np.array([imd]))
+    G.check(case, "prepared1", a)
+    G.check(case, "prepared2", b)
+
+
+def test_host_point_matcher_on_real_keypoints():
+    case = "a_512x384_chain"
+    kp1, kp2 = G.full(case, "kp1"), G.full(case, "kp2")
+    n = min(len(kp1), len(kp2))
+    a, b, imd = capi.match_points(kp1[:n, :2], kp2[:n, :2], 512, 384, 1.0)
+    G.check(case, "initialMorphDist", np.array([imd]))
+    G.check(case, "prepared1", a)
+    G.check(case, "prepared2", b)
+
+
+def test_match_points_all_out_of_image():
+    p = np.array([[-5, 3], [700, 2]], np.float32)
+    a, b, imd = capi.match_points(p, p, 64, 48, 1.0)
+    assert len(a) == 0 and len(b) == 0
