@@ -105,6 +105,15 @@ int poppy_hip_morph_frames(poppy_hip_ctx* ctx, double phase, poppy_write_cb writ
 int poppy_hip_orb_detect(poppy_hip_ctx* ctx, const uint8_t* gray, size_t stride, int width, int height,
                          int nfeatures, float* kps7, int max_kps, int* n_kps);
 
+/* North-star kernels WITHOUT a call site in Poppy (it never computes descriptors); pinned against
+ * OpenCV directly:  ORB::compute (WTA_K 2, 32 bytes/keypoint; OCV/features2d/src/orb.cpp:219-285,1148-1216) and
+ * BFMatcher(NORM_HAMMING).match (OCV/features2d/src/matchers.cpp:757, OCV/core/src/batch_distance.cpp:199-262;
+ * rows of out3 = queryIdx, trainIdx, distance; lowest train index wins ties).                            */
+int poppy_hip_orb_describe(poppy_hip_ctx* ctx, const uint8_t* gray, size_t stride, int width, int height,
+                           const float* kps7, int n_kps, uint8_t* descriptors32);
+int poppy_hip_hamming_match(poppy_hip_ctx* ctx, const uint8_t* query32, int n_query, const uint8_t* train32, int n_train,
+                            int* out3, int* n_matches);
+
 /* Matcher::find (general branch) + Matcher::prepare on raw point lists (src/matcher.cpp:118-131,246-332):
  * drop out-of-image pairs, morph distance, greedy nearest-neighbour pairing, threshold filter, 4 corners.
  * Host only.  out1/out2 need room for n_points + 4 pairs.                                              */

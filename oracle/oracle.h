@@ -98,6 +98,8 @@ int morph_images(const ImageU8& c1, const ImageU8& c2, const ImageF& gabor2,
 // ORB::create(nfeatures)->detect(image): n x 7 floats (x, y, size, angle, response, octave, class_id), order significant
 int orb_detect(const ImageU8& image, int nfeatures, std::vector<float>& kps, std::vector<float>* fastLevel0 = nullptr);
 void hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out);
+// ORB::compute (WTA_K 2): n x 32 bytes.  trig_mode 0 = cosf/sinf, 1 = (float)cos(double) (diagnostic only)
+int orb_describe(const ImageU8& image, const std::vector<float>& kps7, std::vector<uint8_t>& desc, int trig_mode = 0);
 
 // ---- match.cpp -------------------------------------------------------------------------------
 struct DistPair { double d; Pt a, b; };

@@ -110,6 +110,10 @@ int orc_orb_detect(const uint8_t* img, int w, int h, int nfeatures, float* kps7,
     if (fast3 && (int)f.size() / 3 <= maxFast) put(fast3, f);
     return n;
 }
+int orc_orb_describe(const uint8_t* img, int w, int h, const float* kps7, int n, uint8_t* desc, int trig_mode) {
+    std::vector<float> k(kps7, kps7 + (size_t)n * 7); std::vector<uint8_t> d;
+    int m = orb_describe(wrap_u8(img, w, h, 1), k, d, trig_mode); put(desc, d); return m;
+}
 int orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, int* out3) {
     std::vector<int> o; hamming_match(q, nq, t, nt, bytes, o); put(out3, o); return (int)o.size() / 3;
 }

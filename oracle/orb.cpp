@@ -273,6 +273,76 @@ int orb_detect(const ImageU8& image, int nfeatures, std::vector<float>& kps, std
     return (int)fin.size();
 }
 
+// ORB::compute(image, keypoints, descriptors) with the default WTA_K = 2, patch 31: 32 bytes per keypoint.
+// kps7 as produced by orb_detect (octave in column 5).  Every level is first blurred IN PLACE inside the
+// padded atlas by GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) (orb.cpp:1188): the level is a submatrix and
+// the border type is not ISOLATED, so the fixed-point 8-bit path is skipped (smooth.dispatch.cpp:646) and the
+// generic separable filter runs in float (row: uchar->float RowFilter; column: symmetric, cvRound to uchar).
+static const int8_t kPattern[1024] = {
+#include "orb_pattern.inc"
+};
+static const float kGauss7Sigma2[7] = {0x1.1f5f62p-4f, 0x1.0c70fcp-3f, 0x1.869472p-3f, 0x1.ba95c0p-3f, 0x1.869472p-3f, 0x1.0c70fcp-3f, 0x1.1f5f62p-4f};
+
+static void blur_level(const Level& L, ImageU8& out) {
+    const int W = L.w, H = L.h, P = L.img.w;
+    std::vector<float> tmp((size_t)(H + 6) * W);
+    for (int y = -3; y < H + 3; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t* s = L.at(x, y);
+            float acc = kGauss7Sigma2[0] * (float)s[-3];
+            for (int k = 1; k < 7; ++k) acc += kGauss7Sigma2[k] * (float)s[k - 3];
+            tmp[(size_t)(y + 3) * W + x] = acc;
+        }
+    out = L.img;                                     // border keeps the unblurred pixels
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float* c = &tmp[(size_t)(y + 3) * W + x];
+            float acc = kGauss7Sigma2[3] * c[0] + 0.f;
+            for (int k = 1; k <= 3; ++k) acc += kGauss7Sigma2[3 + k] * (c[(size_t)k * W] + c[-(ptrdiff_t)k * W]);
+            int v = cv_round_f(acc);
+            out.d[(size_t)(y + kBorder) * P + (x + kBorder)] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
+int orb_describe(const ImageU8& image, const std::vector<float>& kps7, std::vector<uint8_t>& desc, int trig_mode) {
+    int n = (int)kps7.size() / 7, nlevels = 0;
+    for (int i = 0; i < n; ++i) nlevels = std::max(nlevels, (int)kps7[i * 7 + 5] + 1);
+    desc.assign((size_t)n * 32, 0);
+    if (!n) return 0;
+    std::vector<Level> lv;
+    build_pyramid(image, nlevels, lv);
+    std::vector<ImageU8> blurred(nlevels);
+    for (int l = 0; l < nlevels; ++l) blur_level(lv[l], blurred[l]);
+    for (int j = 0; j < n; ++j) {
+        const float* k = &kps7[(size_t)j * 7];
+        const int oct = (int)k[5];
+        const Level& L = lv[oct];
+        const int P = L.img.w;
+        float scale = 1.f / L.scale;
+        float angle = k[3];
+        angle *= (float)(M_PI / 180.f);
+        float a, b;
+        if (trig_mode == 0) { a = cosf(angle); b = sinf(angle); } else { a = (float)cos((double)angle); b = (float)sin((double)angle); }
+        int cx = cv_round_f(k[0] * scale), cy = cv_round_f(k[1] * scale);
+        const uint8_t* center = &blurred[oct].d[(size_t)(cy + kBorder) * P + (cx + kBorder)];
+        const int8_t* pat = kPattern;
+        for (int i = 0; i < 32; ++i, pat += 32) {
+            int val = 0;
+            for (int bit = 0; bit < 8; ++bit) {
+                int t[2];
+                for (int q = 0; q < 2; ++q) {
+                    float px = pat[bit * 4 + q * 2], py = pat[bit * 4 + q * 2 + 1];
+                    float x = px * a - py * b, y = px * b + py * a;
+                    t[q] = center[cv_round_f(y) * P + cv_round_f(x)];
+                }
+                val |= (t[0] < t[1]) << bit;
+            }
+            desc[(size_t)j * 32 + i] = (uint8_t)val;
+        }
+    }
+    return n;
+}
+
 // BFMatcher(NORM_HAMMING).match: for every query the train descriptor with the smallest Hamming distance,
 // lowest train index on ties.  out: nq x 3 ints (queryIdx, trainIdx, distance)
 void hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out) {

@@ -27,6 +27,7 @@ SYMBOLS = [
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
+    "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_hip_orb_detect", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_points",
 ]
 
@@ -67,6 +68,8 @@ def lib():
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
+        L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
+        L.poppy_hip_hamming_match.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.poppy_match_points.argtypes = [vp, vp, i, i, i, d, vp, vp, vp, vp]
         L.poppy_hip_pair_begin_prefiltered.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, i, i, i]
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
@@ -178,6 +181,21 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_orb_detect(self.h, _p(g), w, w, h, nfeatures, _p(kp), cap, C.byref(n)), "orb_detect")
         return kp[:n.value].copy()
+
+    def orb_describe(self, gray, kps7):
+        g = np.ascontiguousarray(gray, np.uint8)
+        k = np.ascontiguousarray(kps7, np.float32)
+        h, w = g.shape
+        out = np.zeros((len(k), 32), np.uint8)
+        self._chk(lib().poppy_hip_orb_describe(self.h, _p(g), w, w, h, _p(k), len(k), _p(out)), "orb_describe")
+        return out
+
+    def hamming_match(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8); t = np.ascontiguousarray(train, np.uint8)
+        out = np.zeros((len(q), 3), np.int32)
+        n = C.c_int(0)
+        self._chk(lib().poppy_hip_hamming_match(self.h, _p(q), len(q), _p(t), len(t), _p(out), C.byref(n)), "hamming_match")
+        return out[:n.value].copy()
 
     def pair_begin_prefiltered(self, bgr1, bgr2, g1, g2, gabor2, nfeatures):
         a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)

@@ -24,7 +24,8 @@ void launch_ic_angle(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, 
 
 // rBRIEF (WTA_K = 2): blurred copy of every level, then 32 bytes per keypoint.  kp = (level, x, y) in level coordinates.
 void launch_orb_blur(const uint8_t* atlas, uint8_t* blurred, const OrbLevelSet& S, hipStream_t s);
-void launch_orb_describe(const uint8_t* blurred, const OrbLevelSet& S, const int* kp, const float* angle_deg, int n, uint8_t* desc, hipStream_t s);
+// cos_sin: (cos, sin) of each keypoint angle, computed by the host with the reference's libm call
+void launch_orb_describe(const uint8_t* blurred, const OrbLevelSet& S, const int* kp, const float* cos_sin, int n, uint8_t* desc, hipStream_t s);
 
 // brute-force Hamming 1-NN: out[i] = (best train index, distance); ties -> lowest train index
 void launch_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out2, hipStream_t s);

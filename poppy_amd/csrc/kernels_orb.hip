@@ -209,8 +209,117 @@ __global__ void k_ic_angle(const uint8_t* __restrict__ atlas, OrbLevelSet S, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// rBRIEF.  Blur: the level is blurred inside the padded atlas by the generic float separable filter
+// (smooth.dispatch.cpp:646 skips the fixed-point path for a non-isolated submatrix): row pass
+// acc = k0*s0; acc += kj*sj (filter.simd.hpp:2477-2487), column pass acc = k3*c + 0; acc += kj*(c[+j] + c[-j])
+// (:2753-2759), cvRound to u8.  The border ring keeps the unblurred pixels, exactly like the in-place reference.
+// ------------------------------------------------------------------------------------------------
+__constant__ float c_gauss7[7] = {0x1.1f5f62p-4f, 0x1.0c70fcp-3f, 0x1.869472p-3f, 0x1.ba95c0p-3f, 0x1.869472p-3f, 0x1.0c70fcp-3f, 0x1.1f5f62p-4f};
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__global__ void __launch_bounds__(256) k_orb_blur(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ blurred, OrbLevelSet S) {
+    const OrbLevel L = S.lv[blockIdx.z];
+    int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= L.w + 2 * kOrbBorder || py >= L.h + 2 * kOrbBorder) return;
+    const size_t o = L.offset + (size_t)py * L.stride + px;
+    int x = px - kOrbBorder, y = py - kOrbBorder;
+    if (x < 0 || x >= L.w || y < 0 || y >= L.h) { blurred[o] = atlas[o]; return; }
+    const uint8_t* c = atlas + o;
+    const int st = (int)L.stride;
+    float row[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint8_t* s = c + (r - 3) * st;
+        float acc = c_gauss7[0] * (float)s[-3];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc += c_gauss7[k] * (float)s[k - 3];
+        row[r] = acc;
+    }
+    float acc = c_gauss7[3] * row[3] + 0.f;
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) acc += c_gauss7[3 + k] * (row[3 + k] + row[3 - k]);
+    int v = (fabsf(acc) < 2147483648.f) ? __float2int_rn(acc) : INT_MIN;
+    blurred[o] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+// one thread per (keypoint, descriptor byte).  cs = (cos, sin) of the keypoint angle, computed on the host
+// with the same libm call as the reference (orb.cpp:236).
+__global__ void __launch_bounds__(256) k_orb_describe(const uint8_t* __restrict__ blurred, OrbLevelSet S, const int* __restrict__ kp,
+                                                      const float2* __restrict__ cs, int n, uint8_t* __restrict__ desc) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = t >> 5, byte = t & 31;
+    if (j >= n) return;
+    const OrbLevel L = S.lv[kp[3 * j]];
+    const int st = (int)L.stride;
+    const uint8_t* center = blurred + L.offset + (size_t)(kp[3 * j + 2] + kOrbBorder) * L.stride + (kp[3 * j + 1] + kOrbBorder);
+    const float a = cs[j].x, b = cs[j].y;
+    const signed char* pat = c_pattern + byte * 32;
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+        int tv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float px = (float)pat[bit * 4 + q * 2], py = (float)pat[bit * 4 + q * 2 + 1];
+            float x = px * a - py * b, y = px * b + py * a;
+            tv[q] = center[__float2int_rn(y) * st + __float2int_rn(x)];
+        }
+        val |= (tv[0] < tv[1]) << bit;
+    }
+    desc[(size_t)j * 32 + byte] = (uint8_t)val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Brute-force Hamming 1-NN (BFMatcher(NORM_HAMMING).match).  One wave per query descriptor; the train set is
+// streamed through LDS in tiles shared by the 4 waves of the block; xor + popcount on 8 dwords; the running
+// best is (distance, index) with the lower index winning ties, reduced across the wave with shuffles.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHamTile = 512;
+
+__global__ void __launch_bounds__(256) k_hamming(const uint32_t* __restrict__ query, int nq, const uint32_t* __restrict__ train, int nt, int* __restrict__ out2) {
+    __shared__ uint32_t tile[kHamTile * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + wave;
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = qi < nq ? query[(size_t)qi * 8 + k] : 0u;
+    int bestD = INT_MAX, bestJ = INT_MAX;
+    for (int base = 0; base < nt; base += kHamTile) {
+        const int cnt = min(kHamTile, nt - base);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[e] = train[(size_t)base * 8 + e];
+        __syncthreads();
+        for (int j = lane; j < cnt; j += 64) {
+            int d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[j * 8 + k]);
+            if (d < bestD) { bestD = d; bestJ = base + j; }      // ascending j per lane: strict < keeps the lowest index
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int od = __shfl_xor(bestD, off), oj = __shfl_xor(bestJ, off);
+        if (od < bestD || (od == bestD && oj < bestJ)) { bestD = od; bestJ = oj; }
+    }
+    if (lane == 0 && qi < nq) { out2[2 * qi] = bestJ; out2[2 * qi + 1] = bestD; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+void launch_orb_blur(const uint8_t* atlas, uint8_t* blurred, const OrbLevelSet& S, hipStream_t s) {
+    dim3 grid((S.lv[0].w + 2 * kOrbBorder + 255) / 256, S.lv[0].h + 2 * kOrbBorder, S.n);
+    hipLaunchKernelGGL(k_orb_blur, grid, dim3(256), 0, s, atlas, blurred, S);
+}
+void launch_orb_describe(const uint8_t* blurred, const OrbLevelSet& S, const int* kp, const float* cos_sin, int n, uint8_t* desc, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_orb_describe, dim3((n * 32 + 255) / 256), dim3(256), 0, s, blurred, S, kp, (const float2*)cos_sin, n, desc);
+}
+void launch_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out2, hipStream_t s) {
+    if (nq > 0) hipLaunchKernelGGL(k_hamming, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint32_t*)query, nq, (const uint32_t*)train, nt, out2);
+}
+
 void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8_t* atlas, const OrbLevelSet& S, hipStream_t s) {
     for (int l = 0; l < S.n; ++l) {
         const OrbLevel& L = S.lv[l];

@@ -160,4 +160,66 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
     return (int)fin.size();
 }
 
+// ORB::compute(image, keypoints, descriptors), WTA_K = 2 (orb.cpp:219-285,1148-1216).  kps7 in cv::KeyPoint field order.
+int OrbDetector::describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out) {
+    if (n <= 0) return 0;
+    ORB_CHK(prepare(w, h));
+    if (n > kp_cap) { err = "keypoint buffer overflow"; return -1; }
+    int nlev = 0;
+    for (int i = 0; i < n; ++i) {
+        int oct = (int)kps7[(size_t)i * 7 + 5];
+        if (oct < 0 || oct >= kOrbLevels) { err = "keypoint octave out of range"; return -1; }
+        nlev = std::max(nlev, oct + 1);
+    }
+    OrbLevelSet Sd = S; Sd.n = nlev;
+    ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, hipMemcpyHostToDevice, s));
+    launch_orb_pyramid(d_img, w, h, w, d_atlas, Sd, s);
+    launch_orb_blur(d_atlas, d_blur, Sd, s);
+    float* cs = h_val;                                   // 2 floats per keypoint: room is kp_cap floats, so stage in halves
+    std::vector<float> csv((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        const float* k = kps7 + (size_t)i * 7;
+        const int oct = (int)k[5];
+        const float scale = 1.f / S.lv[oct].scale;
+        float angle = k[3];
+        angle *= (float)(M_PI / 180.f);
+        csv[2 * i] = cosf(angle); csv[2 * i + 1] = sinf(angle);     // float overloads, as in the reference TU
+        h_kp[3 * i] = oct; h_kp[3 * i + 1] = round_half_even(k[0] * scale); h_kp[3 * i + 2] = round_half_even(k[1] * scale);
+        const OrbLevel& L = S.lv[oct];
+        if (h_kp[3 * i + 1] < 23 - kOrbBorder || h_kp[3 * i + 1] >= L.w + kOrbBorder - 23 || h_kp[3 * i + 2] < 23 - kOrbBorder || h_kp[3 * i + 2] >= L.h + kOrbBorder - 23) {
+            err = "keypoint too close to the border for a 31x31 steered patch"; return -1;
+        }
+    }
+    (void)cs;
+    float* d_cs = nullptr;
+    ORB_CHK(hipMalloc((void**)&d_cs, (size_t)n * 2 * sizeof(float)));
+    hipError_t e1 = hipMemcpyAsync(d_kp, h_kp, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, s);
+    hipError_t e2 = hipMemcpyAsync(d_cs, csv.data(), (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s);
+    launch_orb_describe(d_blur, S, d_kp, d_cs, n, d_desc, s);
+    hipError_t e3 = hipMemcpyAsync(desc_out, d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s);
+    hipError_t e4 = hipStreamSynchronize(s);
+    (void)hipFree(d_cs);
+    ORB_CHK(e1); ORB_CHK(e2); ORB_CHK(e3); ORB_CHK(e4);
+    return n;
+}
+
+int OrbDetector::hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, hipStream_t s, int* out3) {
+    if (nq <= 0 || nt <= 0) return 0;
+    uint8_t *dq = nullptr, *dt = nullptr; int* dout = nullptr;
+    ORB_CHK(hipMalloc((void**)&dq, (size_t)nq * 32));
+    hipError_t e = hipMalloc((void**)&dt, (size_t)nt * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)nq * 2 * sizeof(int));
+    std::vector<int> tmp((size_t)nq * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { launch_hamming_match(dq, nq, dt, nt, dout, s); e = hipMemcpyAsync(tmp.data(), dout, tmp.size() * sizeof(int), hipMemcpyDeviceToHost, s); }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (dq) (void)hipFree(dq);
+    if (dt) (void)hipFree(dt);
+    if (dout) (void)hipFree(dout);
+    ORB_CHK(e);
+    for (int i = 0; i < nq; ++i) { out3[3 * i] = i; out3[3 * i + 1] = tmp[2 * i]; out3[3 * i + 2] = tmp[2 * i + 1]; }
+    return nq;
+}
+
 }  // namespace poppy_hip

@@ -13,6 +13,10 @@ public:
     ~OrbDetector() { release(); }
     // ORB::create(nfeatures)->detect(gray): host image in, keypoints (order significant) out.  <0 on error (see err).
     int detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out);
+    // ORB::compute: 32 bytes per keypoint (kps7 rows in cv::KeyPoint field order); returns n or <0
+    int describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out);
+    // BFMatcher(NORM_HAMMING).match on 32-byte descriptors: out3 rows (queryIdx, trainIdx, distance)
+    int hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, hipStream_t s, int* out3);
     void release();
     std::string err;
 

@@ -505,6 +505,23 @@ int poppy_hip_orb_detect(poppy_hip_ctx* c, const uint8_t* gray, size_t stride, i
     return POPPY_OK;
 }
 
+int poppy_hip_orb_describe(poppy_hip_ctx* c, const uint8_t* gray, size_t stride, int W, int H, const float* kps7, int n, uint8_t* desc) {
+    if (!c || !gray || W <= 0 || H <= 0 || stride < (size_t)W || n < 0 || (n && (!kps7 || !desc))) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = c->orb.describe(gray, stride, W, H, kps7, n, c->stream, desc);
+    if (rc < 0) { c->err = "orb_describe: " + c->orb.err; return rc == -2 ? POPPY_E_DEVICE : POPPY_E_ARG; }
+    return POPPY_OK;
+}
+
+int poppy_hip_hamming_match(poppy_hip_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt, int* out3, int* n_matches) {
+    if (!c || nq < 0 || nt < 0 || !n_matches || (nq && !query) || (nt && !train) || (nq && nt && !out3)) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = c->orb.hamming(query, nq, train, nt, c->stream, out3);
+    if (rc < 0) { c->err = "hamming_match: " + c->orb.err; return POPPY_E_DEVICE; }
+    *n_matches = rc;
+    return POPPY_OK;
+}
+
 int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
     if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
     std::vector<P2f> a(n), b(n);

@@ -276,3 +276,12 @@ def match_prepare(p1, p2, w, h, tol, imd):
     o1 = np.zeros((len(p1) + 4, 2), np.float32); o2 = np.zeros((len(p1) + 4, 2), np.float32)
     n = lib().orc_match_prepare(_vp(p1), _vp(p2), len(p1), w, h, C.c_double(tol), C.c_double(imd), _vp(o1), _vp(o2))
     return o1[:n].copy(), o2[:n].copy()
+
+
+def orb_describe(img, kps7, trig_mode=0):
+    g = np.ascontiguousarray(img, np.uint8)
+    k = _f(kps7)
+    h, w = g.shape
+    out = np.zeros((len(k), 32), np.uint8)
+    lib().orc_orb_describe(_vp(g), w, h, _vp(k), len(k), _vp(out), trig_mode)
+    return out

@@ -62,3 +62,28 @@ def test_pair_begin_raw_is_unsupported_not_approximated(ctx):
     a = synth.textured_bgr(64, 48, 1)
     rc = capi.lib().poppy_hip_pair_begin(ctx.h, capi._p(a), 64 * 3, capi._p(a), 64 * 3, 64, 48)
     assert rc == -6
+
+
+@pytest.mark.parametrize("case,nf", [("o_256x256", 300), ("o_256x256", 516), ("o_640x480", 500), ("o_1920x1080", 516)])
+def test_orb_describe_and_hamming_vs_opencv(ctx, case, nf):
+    """ORB::compute + BFMatcher(NORM_HAMMING).match (no call site in Poppy; pinned against OpenCV's outputs)."""
+    inp = G.orb_inputs(case)
+    descs = {}
+    for im in ("1", "2"):
+        kp = G.full(case, f"n{nf}_kp{im}")
+        d = ctx.orb_describe(inp["g" + im], kp)
+        G.check(case, f"n{nf}_desc{im}", d)
+        descs[im] = d
+    G.check(case, f"n{nf}_bfmatch", ctx.hamming_match(descs["1"], descs["2"]))
+
+
+def test_hamming_ties_and_ragged(ctx):
+    rng = np.random.RandomState(5)
+    q = rng.randint(0, 256, (77, 32)).astype(np.uint8)
+    t = rng.randint(0, 256, (1301, 32)).astype(np.uint8)
+    t[900] = t[3]; t[17] = q[5]; t[1200] = q[5]          # exact duplicates: the lowest train index must win
+    got = ctx.hamming_match(q, t)
+    want = O.hamming_match(q, t)
+    assert (got == want).all()
+    assert got[5, 1] == 17 and got[5, 2] == 0
+    assert len(ctx.hamming_match(q, t[:0])) == 0

@@ -78,3 +78,13 @@ def test_real_pipeline_orb_on_reference_inputs():
     nf = int(G.full(case, "detail")[3])
     G.check(case, "kp1", O.orb_detect(G.full(case, "g1"), nf))
     G.check(case, "kp2", O.orb_detect(G.full(case, "g2"), nf))
+
+
+@pytest.mark.parametrize("case,nf", [("o_256x256", 300), ("o_640x480", 500)])
+def test_orb_describe_and_bfmatch_bit_exact(case, nf):
+    inp = G.orb_inputs(case)
+    d = {}
+    for im in ("1", "2"):
+        d[im] = O.orb_describe(inp["g" + im], G.full(case, f"n{nf}_kp{im}"))
+        G.check(case, f"n{nf}_desc{im}", d[im])
+    G.check(case, f"n{nf}_bfmatch", O.hamming_match(d["1"], d["2"]))
