@@ -288,9 +288,85 @@ __global__ void __launch_bounds__(256) k_warp(const int32_t* __restrict__ triMap
     tr1[p * 3] = o1[0]; tr1[p * 3 + 1] = o1[1]; tr1[p * 3 + 2] = o1[2];
     tr2[p * 3] = o2[0]; tr2[p * 3 + 1] = o2[1]; tr2[p * 3 + 2] = o2[2];
 }
+// --- 4 pixels per thread (W % 4 == 0) ---------------------------------------------------------------
+// One 16-byte load of the id map, the two inverse matrices fetched once per run of equal ids, each 2x2
+// footprint fetched as two unaligned 8-byte loads (6 useful bytes: two BGR pixels) when it lies inside the
+// image, and 12 contiguous output bytes per image written as three dwords.  Source buffers carry 16 bytes of
+// tail padding so the 8-byte loads of the last footprint stay inside the allocation.
+__device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t sample3_packed(const uint8_t* __restrict__ src, int W, int H, float mx, float my) {
+    int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
+    int w00, w01, w10, w11;
+    bilinear_weights(sx & 31, sy & 31, w00, w01, w10, w11);
+    int ix = sx >> 5, iy = sy >> 5;
+    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
+    uint32_t out = 0;
+    if (ix >= 0 && ix < W - 1 && iy >= 0 && iy < H - 1) {
+        const uint8_t* p = src + ((size_t)iy * W + ix) * 3;
+        const uint64_t a = ld_u64_unaligned(p), b = ld_u64_unaligned(p + (size_t)W * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int v00 = (int)((a >> (8 * k)) & 255), v01 = (int)((a >> (24 + 8 * k)) & 255);
+            int v10 = (int)((b >> (8 * k)) & 255), v11 = (int)((b >> (24 + 8 * k)) & 255);
+            int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+            out |= (uint32_t)sat_u8((acc + (1 << 14)) >> 15) << (8 * k);
+        }
+    } else {
+        uint8_t o[3];
+        sample3(src, W, H, mx, my, o);
+        out = o[0] | (o[1] << 8) | (o[2] << 16);
+    }
+    return out;
+}
+
+__global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4, const float* __restrict__ inv1, const float* __restrict__ inv2,
+                                               const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
+                                               uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H) {
+    const int W4 = W >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;      // index of the 4-pixel group inside the row
+    const int y = blockIdx.y;
+    if (q >= W4) return;
+    const int4 ids = triMap4[(size_t)y * W4 + q];
+    const int id[4] = {ids.x - 1, ids.y - 1, ids.z - 1, ids.w - 1};
+    uint32_t p1[4], p2[4];
+    float h1[9], h2[9];
+    int cur = -1;
+    const float fy = (float)y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = q * 4 + k;
+        float mx1 = (float)x, my1 = fy, mx2 = mx1, my2 = fy;
+        if (id[k] >= 0) {
+            if (id[k] != cur) {
+                cur = id[k];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) { h1[e] = inv1[(size_t)cur * 9 + e]; h2[e] = inv2[(size_t)cur * 9 + e]; }
+            }
+            map_point(h1, x, y, mx1, my1);
+            map_point(h2, x, y, mx2, my2);
+        }
+        p1[k] = sample3_packed(c1, W, H, mx1, my1);
+        p2[k] = sample3_packed(c2, W, H, mx2, my2);
+    }
+    // 4 BGR pixels -> 3 dwords
+    const size_t o = ((size_t)y * W4 + q) * 3;
+    tr1[o] = p1[0] | (p1[1] << 24);            tr2[o] = p2[0] | (p2[1] << 24);
+    tr1[o + 1] = (p1[1] >> 8) | (p1[2] << 16); tr2[o + 1] = (p2[1] >> 8) | (p2[2] << 16);
+    tr1[o + 2] = (p1[2] >> 16) | (p1[3] << 8); tr2[o + 2] = (p2[2] >> 16) | (p2[3] << 8);
+}
+
 void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
                  uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s) {
-    hipLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
+    if ((w & 3) == 0)
+        hipLaunchKernelGGL(k_warp4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, s, (const int4*)triMap, inv1, inv2, c1, c2,
+                           (uint32_t*)tr1, (uint32_t*)tr2, w, h);
+    else
+        hipLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------

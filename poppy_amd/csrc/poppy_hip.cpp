@@ -186,9 +186,10 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
     if (((size_t)3 * c->tail_n3 + c->tail_n1 + 3 * 257) * 4 > 64 * 1024)
         return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
-    HIPCHK(c, hipMalloc((void**)&c->c1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3));
-    HIPCHK(c, hipMalloc((void**)&c->tr1, P * 3)); HIPCHK(c, hipMalloc((void**)&c->tr2, P * 3));
-    HIPCHK(c, hipMalloc((void**)&c->frame[0], P * 3)); HIPCHK(c, hipMalloc((void**)&c->frame[1], P * 3));
+    // +16: k_warp4 fetches footprints with 8-byte loads (6 bytes used), the last one may run 2 bytes past the image
+    HIPCHK(c, hipMalloc((void**)&c->c1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3 + 16));
+    HIPCHK(c, hipMalloc((void**)&c->tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->tr2, P * 3 + 16));
+    HIPCHK(c, hipMalloc((void**)&c->frame[0], P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->frame[1], P * 3 + 16));
     HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12)); HIPCHK(c, hipMalloc((void**)&c->m2, P * 4));
     HIPCHK(c, hipMalloc((void**)&c->triMap, P * 4));
     HIPCHK(c, hipMalloc((void**)&c->pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&c->pyrR, off3 * 4));
