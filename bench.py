@@ -78,7 +78,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=["chain", "phase"], default=None, help="default: chain at N=1, phase at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=None, help="override the 1080p headline size (e.g. 3840 for BASELINE configs[2])")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 60)")
     args = ap.parse_args()
+    global W, H, FRAMES
+    if args.width and args.height:
+        W, H = args.width, args.height
+    if args.frames:
+        FRAMES = args.frames
 
     import torch
     import torch.distributed as dist
@@ -179,7 +187,7 @@ def main():
         wk = kernels.get("warp", {})
         achieved = wk.get("GBps") or 0.0
         out = {
-            "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped",
+            "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H) == (1920, 1080) else f"morph frames/sec at {W}x{H}; Mpix/s warped",
             "value": round(fps, 2), "unit": "frames/s",
             "mpix_per_s": round(fps * P / 1e6, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,7 +195,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 pixels / f32 pyramid (bit-compatible with the reference: no FMA contraction)",
             "data": "synthetic (integer-defined shapes pair, synthetic mask field and 436+4 point pairs; poppy_amd/synth.py)",
-            "config": {"workload": f"1920x1080 pair, {FRAMES}-frame morph per GPU ({total_frames} frames total), "
+            "config": {"workload": f"{W}x{H} pair, {FRAMES}-frame morph per GPU ({total_frames} frames total), "
                                    f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
                                    "pyramid_levels 64, per-frame operator on a resident pair",
                        "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
