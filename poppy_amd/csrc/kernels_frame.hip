@@ -463,6 +463,44 @@ __device__ __forceinline__ float mix_lr(float l, float r, float m) {
     return a + b;
 }
 
+// kDownStrip vertically adjacent outputs of one element column per thread: the horizontal sums of the
+// 2*kDownStrip + 3 source rows they share are computed once (the per-element form recomputes 5 rows per output).
+// The H association depends only on the element column and the V association only on the element column too,
+// so every output is the same expression tree as pyrdown_elem.  Strips that touch a border fall back to it.
+constexpr int kDownStrip = 4;
+
+template <bool U8>
+__device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g, int y0, int xe, float* __restrict__ dst) {
+    const int cn = g.cn, dwe = g.dw * cn;
+    const int px = xe / cn, c = xe - px * cn;
+    const bool interior = px >= 1 && 2 * px + 2 <= g.sw - 1 && y0 >= 1 && 2 * (y0 + kDownStrip - 1) + 2 <= g.sh - 1;
+    if (!interior) {
+        for (int k = 0; k < kDownStrip; ++k)
+            if (y0 + k < g.dh) dst[(size_t)(y0 + k) * dwe + xe] = pyrdown_elem<U8>(src, g, y0 + k, xe);
+        return;
+    }
+    const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
+    const bool vBody = xe < g.vBodyEnd;
+    const size_t rowlen = (size_t)g.sw * cn;
+    const size_t col = (size_t)(2 * px - 2) * cn + c;
+    float r[2 * kDownStrip + 3];
+#pragma unroll
+    for (int k = 0; k < 2 * kDownStrip + 3; ++k) {
+        const size_t base = (size_t)(2 * y0 - 2 + k) * rowlen + col;
+        float t0 = ld<U8>(src, base), t1 = ld<U8>(src, base + cn), t2 = ld<U8>(src, base + 2 * cn);
+        float t3 = ld<U8>(src, base + 3 * cn), t4 = ld<U8>(src, base + 4 * cn);
+        r[k] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                     : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+    }
+    const float s = 1.f / 256;
+#pragma unroll
+    for (int k = 0; k < kDownStrip; ++k) {
+        const float *q = r + 2 * k;
+        dst[(size_t)(y0 + k) * dwe + xe] = vBody ? ((q[1] + q[3] + q[2]) * 4.f + (q[0] + q[4] + (q[2] + q[2]))) * s
+                                                : (q[2] * 6.f + (q[1] + q[3]) * 4.f + q[0] + q[4]) * s;
+    }
+}
+
 // --- one reduction step, L / R / mask selected by blockIdx.z -------------------------------------
 template <bool U8>
 __global__ void __launch_bounds__(256) k_pyrdown(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
@@ -470,21 +508,20 @@ __global__ void __launch_bounds__(256) k_pyrdown(const void* __restrict__ srcL, 
                                                  DownGeom g3, DownGeom g1) {
     const int which = blockIdx.z;
     const int xe = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * kDownStrip;
     if (which == 2) {
         if (xe >= g1.dw) return;
-        dstM[(size_t)y * g1.dw + xe] = pyrdown_elem<false>(srcM, g1, y, xe);
+        pyrdown_strip<false>(srcM, g1, y0, xe, dstM);
     } else {
         if (xe >= g3.dw * 3) return;
-        const void* src = which ? srcR : srcL;
-        float* dst = which ? dstR : dstL;
-        dst[(size_t)y * g3.dw * 3 + xe] = pyrdown_elem<U8>(src, g3, y, xe);
+        if (which) pyrdown_strip<U8>(srcR, g3, y0, xe, dstR);
+        else       pyrdown_strip<U8>(srcL, g3, y0, xe, dstL);
     }
 }
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
                     float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
     DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
-    dim3 grid((g3.dw * 3 + 255) / 256, g3.dh, 3);
+    dim3 grid((g3.dw * 3 + 255) / 256, (g3.dh + kDownStrip - 1) / kDownStrip, 3);
     if (src_u8) hipLaunchKernelGGL(k_pyrdown<true>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
     else        hipLaunchKernelGGL(k_pyrdown<false>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
 }
@@ -501,18 +538,65 @@ __device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, c
     return pyrup_elem(nB, nw, nh, 3, y, xe) + res;
 }
 
+// Thread = one low-resolution element (sy, sxe = sx*3 + c) -> the 2x2 output quad above it, one channel.
+// The 3x3 low-resolution neighbourhood of each of the three upsampled images (L, R, blended) is loaded once
+// and serves all four outputs (the per-element form reloads it four times).  Interior quads take this path;
+// quads on the first/last low-resolution row or column, where pyrUp uses its edge formulas, fall back to
+// collapse_elem.  The arithmetic per output is the same expression tree as pyrup_elem + mix_lr.
+struct UpQuad { float ee, eo, oe, oo; };     // (even row, even col), (even, odd), (odd, even), (odd, odd)
+
+__device__ __forceinline__ UpQuad pyrup_quad(const float* __restrict__ p, int stride) {
+    // p -> centre element of the 3x3 neighbourhood; +-3 = neighbouring pixel, +-stride = neighbouring row
+    float he[3], ho[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* q = p + (r - 1) * stride;
+        float a = q[-3], b = q[0], c = q[3];
+        he[r] = a + b * 6.f + c;
+        ho[r] = (b + c) * 4.f;
+    }
+    const float s = 1.f / 64;
+    UpQuad u;
+    u.ee = (he[0] + he[1] * 6.f + he[2]) * s;
+    u.eo = (ho[0] + ho[1] * 6.f + ho[2]) * s;
+    u.oe = ((he[1] + he[2]) * 4.f) * s;
+    u.oo = ((ho[1] + ho[2]) * 4.f) * s;
+    return u;
+}
+
 template <bool U8>
 __global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                   const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
                                                   float* __restrict__ outB, int w, int h, int nw, int nh) {
-    const int xe = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (xe >= w * 3) return;
-    outB[(size_t)y * w * 3 + xe] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, xe);
+    const int sxe = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sy = blockIdx.y;
+    if (sxe >= nw * 3) return;
+    const int sx = sxe / 3, c = sxe - sx * 3;
+    const int x0 = 2 * sx, y0 = 2 * sy;
+    if (sx >= 1 && sx <= nw - 2 && sy >= 1 && sy <= nh - 2) {
+        const int ns = nw * 3;
+        const size_t lo = (size_t)sy * ns + sxe;
+        const UpQuad uL = pyrup_quad(nL + lo, ns), uR = pyrup_quad(nR + lo, ns), uB = pyrup_quad(nB + lo, ns);
+        const size_t e00 = ((size_t)y0 * w + x0) * 3 + c, e10 = e00 + (size_t)w * 3;
+        const size_t m00 = (size_t)y0 * w + x0, m10 = m00 + w;
+        outB[e00]     = uB.ee + mix_lr(ld<U8>(gL, e00) - uL.ee,     ld<U8>(gR, e00) - uR.ee,     gM[m00]);
+        outB[e00 + 3] = uB.eo + mix_lr(ld<U8>(gL, e00 + 3) - uL.eo, ld<U8>(gR, e00 + 3) - uR.eo, gM[m00 + 1]);
+        outB[e10]     = uB.oe + mix_lr(ld<U8>(gL, e10) - uL.oe,     ld<U8>(gR, e10) - uR.oe,     gM[m10]);
+        outB[e10 + 3] = uB.oo + mix_lr(ld<U8>(gL, e10 + 3) - uL.oo, ld<U8>(gR, e10 + 3) - uR.oo, gM[m10 + 1]);
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = x0 + dx, y = y0 + dy;
+                if (x < w && y < h)
+                    outB[((size_t)y * w + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
+            }
+    }
 }
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
                      float* outB, int w, int h, int nw, int nh, hipStream_t s) {
-    dim3 grid((w * 3 + 255) / 256, h);
+    dim3 grid((nw * 3 + 255) / 256, nh);
     if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
     else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
 }
