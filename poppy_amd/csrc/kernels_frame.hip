@@ -467,15 +467,13 @@ __device__ __forceinline__ float mix_lr(float l, float r, float m) {
 // 2*kDownStrip + 3 source rows they share are computed once (the per-element form recomputes 5 rows per output).
 // The H association depends only on the element column and the V association only on the element column too,
 // so every output is the same expression tree as pyrdown_elem.  Strips that touch a border fall back to it.
-constexpr int kDownStrip = 4;
-
-template <bool U8>
+template <bool U8, int V>
 __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g, int y0, int xe, float* __restrict__ dst) {
     const int cn = g.cn, dwe = g.dw * cn;
     const int px = xe / cn, c = xe - px * cn;
-    const bool interior = px >= 1 && 2 * px + 2 <= g.sw - 1 && y0 >= 1 && 2 * (y0 + kDownStrip - 1) + 2 <= g.sh - 1;
+    const bool interior = px >= 1 && 2 * px + 2 <= g.sw - 1 && y0 >= 1 && 2 * (y0 + V - 1) + 2 <= g.sh - 1;
     if (!interior) {
-        for (int k = 0; k < kDownStrip; ++k)
+        for (int k = 0; k < V; ++k)
             if (y0 + k < g.dh) dst[(size_t)(y0 + k) * dwe + xe] = pyrdown_elem<U8>(src, g, y0 + k, xe);
         return;
     }
@@ -483,9 +481,9 @@ __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g
     const bool vBody = xe < g.vBodyEnd;
     const size_t rowlen = (size_t)g.sw * cn;
     const size_t col = (size_t)(2 * px - 2) * cn + c;
-    float r[2 * kDownStrip + 3];
+    float r[2 * V + 3];
 #pragma unroll
-    for (int k = 0; k < 2 * kDownStrip + 3; ++k) {
+    for (int k = 0; k < 2 * V + 3; ++k) {
         const size_t base = (size_t)(2 * y0 - 2 + k) * rowlen + col;
         float t0 = ld<U8>(src, base), t1 = ld<U8>(src, base + cn), t2 = ld<U8>(src, base + 2 * cn);
         float t3 = ld<U8>(src, base + 3 * cn), t4 = ld<U8>(src, base + 4 * cn);
@@ -494,7 +492,7 @@ __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g
     }
     const float s = 1.f / 256;
 #pragma unroll
-    for (int k = 0; k < kDownStrip; ++k) {
+    for (int k = 0; k < V; ++k) {
         const float *q = r + 2 * k;
         dst[(size_t)(y0 + k) * dwe + xe] = vBody ? ((q[1] + q[3] + q[2]) * 4.f + (q[0] + q[4] + (q[2] + q[2]))) * s
                                                 : (q[2] * 6.f + (q[1] + q[3]) * 4.f + q[0] + q[4]) * s;
@@ -502,28 +500,43 @@ __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g
 }
 
 // --- one reduction step, L / R / mask selected by blockIdx.z -------------------------------------
-template <bool U8>
+template <bool U8, int V>
 __global__ void __launch_bounds__(256) k_pyrdown(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
                                                  float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
                                                  DownGeom g3, DownGeom g1) {
     const int which = blockIdx.z;
     const int xe = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = blockIdx.y * kDownStrip;
+    const int y0 = blockIdx.y * V;
     if (which == 2) {
         if (xe >= g1.dw) return;
-        pyrdown_strip<false>(srcM, g1, y0, xe, dstM);
+        pyrdown_strip<false, V>(srcM, g1, y0, xe, dstM);
     } else {
         if (xe >= g3.dw * 3) return;
-        if (which) pyrdown_strip<U8>(srcR, g3, y0, xe, dstR);
-        else       pyrdown_strip<U8>(srcL, g3, y0, xe, dstL);
+        if (which) pyrdown_strip<U8, V>(srcR, g3, y0, xe, dstR);
+        else       pyrdown_strip<U8, V>(srcL, g3, y0, xe, dstL);
     }
+}
+template <bool U8, int V>
+static void launch_pyrdown_v(const void* srcL, const void* srcR, const float* srcM, float* dstL, float* dstR, float* dstM,
+                             const DownGeom& g3, const DownGeom& g1, hipStream_t s) {
+    dim3 grid((g3.dw * 3 + 255) / 256, (g3.dh + V - 1) / V, 3);
+    hipLaunchKernelGGL((k_pyrdown<U8, V>), grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
 }
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
                     float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
     DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
-    dim3 grid((g3.dw * 3 + 255) / 256, (g3.dh + kDownStrip - 1) / kDownStrip, 3);
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown<true>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
-    else        hipLaunchKernelGGL(k_pyrdown<false>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
+    // taller strips share more row sums but leave fewer threads: only worth it when the level is large
+    const size_t outputs = (size_t)g3.dw * g3.dh * 3;
+    const int V = outputs >= (size_t)5000000 ? 4 : outputs >= (size_t)1000000 ? 2 : 1;
+    if (src_u8) {
+        if (V == 4) launch_pyrdown_v<true, 4>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+        else if (V == 2) launch_pyrdown_v<true, 2>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+        else launch_pyrdown_v<true, 1>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+    } else {
+        if (V == 4) launch_pyrdown_v<false, 4>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+        else if (V == 2) launch_pyrdown_v<false, 2>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+        else launch_pyrdown_v<false, 1>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, s);
+    }
 }
 
 // --- one collapse step ----------------------------------------------------------------------------
@@ -779,8 +792,91 @@ __global__ void __launch_bounds__(256) k_median_apply(const float* __restrict__ 
     out[p + 2] = sat_u8(cv_round_x86(v2 * 255.f + 0.f));
 }
 
+// --- fused, LDS-tiled form -------------------------------------------------------------------------
+// One workgroup produces a kUTx x kUTy pixel tile of the final 8-bit frame: the source tile with a halo of 5
+// (4 for the 9-tap Gaussian + 1 for the 3x3 median) is staged in LDS once with reflect-101 addressing, the row
+// pass, the column pass + difference and the median/threshold/apply run out of LDS.  HBM traffic drops from
+// 87 B/px (three kernels through two f32 scratch images) to ~26 B/px read + 3 B/px written.  Every value is the
+// same expression tree as in the three-kernel form above (kept for 1-pixel-wide images).
+constexpr int kUTx = 32, kUTy = 16;
+constexpr int kUSx = kUTx + 10, kUSy = kUTy + 10;      // staged source tile
+constexpr int kURx = kUTx + 2;                          // row-pass / diff tile width (halo 1 for the median)
+constexpr int kUDy = kUTy + 2;
+
+__global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
+                                                      int W, int H, float amount, float threshold) {
+    __shared__ float S[kUSy * kUSx * 3];
+    __shared__ float R[kUSy * kURx * 3];
+    __shared__ float D[kUDy * kURx * 3];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * kUTx, ty0 = blockIdx.y * kUTy;
+    // 1. stage: S(r, c) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + c))
+    for (int i = tid; i < kUSy * kUSx; i += 256) {
+        const int r = i / kUSx, c = i - r * kUSx;
+        const int yy = reflect101(ty0 - 5 + r, H), xx = reflect101(tx0 - 5 + c, W);
+        const float* p = src + ((size_t)yy * W + xx) * 3;
+        S[i * 3] = p[0]; S[i * 3 + 1] = p[1]; S[i * 3 + 2] = p[2];
+    }
+    __syncthreads();
+    // 2. row pass for tile columns -1 .. kUTx (R column j <-> S column j + 4)
+    for (int i = tid; i < kUSy * kURx * 3; i += 256) {
+        const int r = i / (kURx * 3), e = i - r * (kURx * 3);
+        const float* s = S + (r * kUSx) * 3 + e;             // S column j, channel: taps at columns j .. j+8
+        float acc = s[0] * c_gauss9[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) acc = s[k * 3] * c_gauss9[k] + acc;
+        R[i] = acc;
+    }
+    __syncthreads();
+    // 3. column pass + difference for tile rows -1 .. kUTy (D row q <-> R row q + 4, S row q + 4, S column j + 4)
+    for (int i = tid; i < kUDy * kURx * 3; i += 256) {
+        const int q = i / (kURx * 3), e = i - q * (kURx * 3);
+        const float* rr = R + ((q + 4) * kURx) * 3 + e;
+        float acc = c_gauss9[4] * rr[0] + 0.f;
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) acc = c_gauss9[4 + k] * (rr[k * kURx * 3] + rr[-k * kURx * 3]) + acc;
+        D[i] = S[((q + 4) * kUSx + 4) * 3 + e] - acc;
+    }
+    __syncthreads();
+    // 4. median of the difference (replicated image edges), threshold, apply, convert
+    for (int i = tid; i < kUTx * kUTy; i += 256) {
+        const int ly = i / kUTx, lx = i - ly * kUTx;
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= W || y >= H) continue;
+        const int xm = (x > 0 ? x - 1 : x) - tx0 + 1, xc = lx + 1, xp = (x < W - 1 ? x + 1 : x) - tx0 + 1;   // D columns
+        const int ym = (y > 0 ? y - 1 : y) - ty0 + 1, yc = ly + 1, yp = (y < H - 1 ? y + 1 : y) - ty0 + 1;   // D rows
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p0 = D[(ym * kURx + xm) * 3 + c], p1 = D[(ym * kURx + xc) * 3 + c], p2 = D[(ym * kURx + xp) * 3 + c];
+            float p3 = D[(yc * kURx + xm) * 3 + c], p4 = D[(yc * kURx + xc) * 3 + c], p5 = D[(yc * kURx + xp) * 3 + c];
+            float p6 = D[(yp * kURx + xm) * 3 + c], p7 = D[(yp * kURx + xc) * 3 + c], p8 = D[(yp * kURx + xp) * 3 + c];
+            mnmx(p1, p2); mnmx(p4, p5); mnmx(p7, p8); mnmx(p0, p1);
+            mnmx(p3, p4); mnmx(p6, p7); mnmx(p1, p2); mnmx(p4, p5);
+            mnmx(p7, p8); mnmx(p0, p3); mnmx(p5, p8); mnmx(p4, p7);
+            mnmx(p3, p6); mnmx(p1, p4); mnmx(p2, p5); mnmx(p4, p7);
+            mnmx(p4, p2); mnmx(p6, p4); mnmx(p4, p2);
+            d[c] = p4;
+        }
+        const double nrm2 = (double)d[0] * (double)d[0] + (double)d[1] * (double)d[1] + (double)d[2] * (double)d[2];
+        const float* sv = S + ((ly + 5) * kUSx + (lx + 5)) * 3;
+        float v0 = sv[0], v1 = sv[1], v2 = sv[2];
+        if (sqrt(nrm2) >= (double)threshold) { v0 = v0 + amount * d[0]; v1 = v1 + amount * d[1]; v2 = v2 + amount * d[2]; }
+        const size_t p = ((size_t)y * W + x) * 3;
+        if (outF) { outF[p] = v0; outF[p + 1] = v1; outF[p + 2] = v2; }
+        out[p] = sat_u8(cv_round_x86(v0 * 255.f + 0.f));
+        out[p + 1] = sat_u8(cv_round_x86(v1 * 255.f + 0.f));
+        out[p + 2] = sat_u8(cv_round_x86(v2 * 255.f + 0.f));
+    }
+}
+
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
                     int w, int h, float amount, float threshold, hipStream_t s) {
+    if (w > 1 && h > 1) {
+        dim3 grid((w + kUTx - 1) / kUTx, (h + kUTy - 1) / kUTy);
+        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, threshold);
+        return;
+    }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);
     hipLaunchKernelGGL(k_gauss_row, ge, dim3(256), 0, s, src, tmpRow, w, h);
     hipLaunchKernelGGL(k_gauss_col_diff, ge, dim3(256), 0, s, src, tmpRow, diff, w, h);

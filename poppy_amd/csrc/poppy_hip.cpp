@@ -59,7 +59,8 @@ struct poppy_hip_ctx {
     uint8_t* h_blob[kRing] = {};  uint8_t* d_blob[kRing] = {};
     size_t blob_bytes = 0;
     int tail_n3 = 0, tail_n1 = 0;
-    hipEvent_t ring_done[kRing] = {};
+    hipEvent_t ring_done[kRing] = {}, uploaded[kRing] = {};
+    hipStream_t copy_stream = nullptr;
     int ring_pos = 0;
     FramePlan plan;
     OrbDetector orb;
@@ -107,7 +108,11 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     c->device = device;
     if (settings) c->cfg = *settings; else poppy_settings_default(&c->cfg);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) (void)hipEventCreateWithFlags(&c->ring_done[i], hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
+        (void)hipEventCreateWithFlags(&c->ring_done[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->uploaded[i], hipEventDisableTiming);
+    }
     return c;
 }
 
@@ -133,7 +138,9 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     free_pair(c);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) (void)hipEventDestroy(c->ring_done[i]);
+    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) { (void)hipEventDestroy(c->ring_done[i]); (void)hipEventDestroy(c->uploaded[i]); }
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -181,7 +188,7 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     }
     c->first_tail = L;
     for (int i = 1; i <= L; ++i)
-        if ((size_t)c->levels[i].w * c->levels[i].h <= 1024) { c->first_tail = i; break; }
+        if ((size_t)c->levels[i].w * c->levels[i].h <= 160) { c->first_tail = i; break; }   // everything below runs in ONE workgroup: keep it tiny
     c->tail_n3 = c->tail_n1 = 0;
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
     if (((size_t)3 * c->tail_n3 + c->tail_n1 + 3 * 257) * 4 > 64 * 1024)
@@ -277,13 +284,16 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     hipStream_t s = c->stream;
     Timer tm(c);
     tm.mark(nullptr);
-    if (used) HIPCHK(c, hipMemcpyAsync(c->d_blob[slot], c->h_blob[slot], used, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipEventRecord(c->ring_done[slot], s));
+    // the plan blob goes up on its own stream so it overlaps the previous frame's kernels
+    if (used) HIPCHK(c, hipMemcpyAsync(c->d_blob[slot], c->h_blob[slot], used, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->uploaded[slot], c->copy_stream));
     HIPCHK(c, hipMemsetAsync(c->triMap, 0, (size_t)W * H * 4, s));
+    HIPCHK(c, hipStreamWaitEvent(s, c->uploaded[slot], 0));
     tm.mark("upload+clear");
     launch_raster(d_tri, d_work, n_work, c->triMap, W, H, s);
     tm.mark("raster");
     launch_warp(c->triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
+    HIPCHK(c, hipEventRecord(c->ring_done[slot], s));            // last reader of this slot's device blob
     tm.mark("warp");
     launch_mask(c->m2, c->pyrM, W * H, 1.0 - mask, -mask, s);
     tm.mark("mask");
