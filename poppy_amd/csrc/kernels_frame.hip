@@ -623,15 +623,20 @@ void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
 constexpr int kTailMaxLevels = 257;
 
 __global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL, const float* __restrict__ gR, const float* __restrict__ gM,
-                                                   float* __restrict__ gB, const PyrLevel* __restrict__ lv, int first, int levels,
+                                                   float* __restrict__ gB, const PyrLevel* __restrict__ glv, int first, int levels,
                                                    int n3, int n1) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sL = lds;                 // n3 floats each, indexed by (off3 - base3)
+    // the level table is read ~10 times per level by every thread: keep it in LDS (one coalesced copy) instead of
+    // chasing it through global memory inside the sequential chains
+    PyrLevel* lv = (PyrLevel*)lds;   // indexed by absolute level; entries first..levels are filled
+    float* sL = (float*)(lv + (levels + 1));     // n3 floats each, indexed by (off3 - base3)
     float* sR = sL + n3;
     float* sB = sR + n3;
     float* sM = sB + n3;             // n1 floats, indexed by (off1 - base1)
     float* sMp = sM + n1;            // 3 x kTailMaxLevels private mask chains
     const int tid = threadIdx.x, nth = blockDim.x;
+    for (int i = first + tid; i <= levels; i += nth) lv[i] = glv[i];
+    __syncthreads();
     const size_t base3 = lv[first].off3, base1 = lv[first].off1;
 
     {   // stage level `first` (produced by the previous pyrDown launch)
@@ -711,7 +716,7 @@ __global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL,
 }
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
                      int n3, int n1, hipStream_t s) {
-    size_t lds = ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float);
+    size_t lds = ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;
     hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(1024), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, n3, n1);
 }
 

@@ -22,10 +22,12 @@
 #include "point_match.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace poppy_hip;
@@ -247,13 +249,78 @@ struct Timer {
     }
 };
 
+static int submit_frame(poppy_hip_ctx* c, double mask, bool chain);
+
 // one frame on the resident pair; result in frame[slot]
 static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain) {
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
     if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
-    const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
-    int rc = plan_frame(W, H, c->pts1, c->pts2, shape, c->plan);
+    int rc = plan_frame(c->W, c->H, c->pts1, c->pts2, shape, c->plan);
     if (rc) return fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)");
+    return submit_frame(c, mask, chain);
+}
+
+// Multi-frame calls plan on a small pool of host threads: only the POINT chain is sequential in chained mode
+// (src/poppy.hpp:178-179,218: srcPoints1 <- morphedPoints), and that is a few hundred multiply-adds per frame; the
+// triangulation and matrix work of the frames is independent once each frame's input points are known.
+static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* mask, int n, bool chain, poppy_write_cb write, void* user) {
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
+    if (n <= 0) return POPPY_OK;
+    const int W = c->W, H = c->H;
+    std::vector<std::vector<P2f>> src1(n);
+    src1[0] = c->pts1;
+    if (chain)
+        for (int j = 0; j + 1 < n; ++j) {                            // morph_points + clip_points of frame j
+            const float s = (float)shape[j];
+            std::vector<P2f> a = src1[j], b = c->pts2;
+            clip_points_ref(a, W, H); clip_points_ref(b, W, H);
+            std::vector<P2f>& m = src1[j + 1];
+            m.resize(a.size());
+            for (size_t i = 0; i < a.size(); ++i) {
+                m[i].x = (float)((1.0 - s) * a[i].x + s * b[i].x);
+                m[i].y = (float)((1.0 - s) * a[i].y + s * b[i].y);
+            }
+            clip_points_ref(m, W, H);
+        }
+    std::vector<FramePlan> plans(n);
+    std::vector<int> rcs(n, 0);
+    std::vector<std::atomic<int>> ready(n);
+    for (auto& r : ready) r.store(0);
+    std::atomic<int> next{0};
+    const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency() - 1}));
+    auto worker = [&]() {
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= n) return;
+            rcs[j] = plan_frame(W, H, chain ? src1[j] : src1[0], c->pts2, shape[j], plans[j]);
+            ready[j].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    int rc = POPPY_OK;
+    const size_t row = (size_t)W * 3;
+    for (int j = 0; j < n && rc == POPPY_OK; ++j) {
+        while (!ready[j].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (rcs[j]) { rc = fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)"); break; }
+        c->plan = std::move(plans[j]);
+        if (chain) c->pts1 = src1[j];
+        rc = submit_frame(c, mask[j], chain);
+        if (rc == POPPY_OK && write) {
+            hipError_t e = hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * H, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; break; }
+            write(user, c->h_stage, W, H, row);
+        }
+    }
+    next.store(n);                         // on an error: let the workers drain
+    for (auto& t : pool) t.join();
+    return rc;
+}
+
+static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
+    const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
     const int T = c->plan.n_tris;
     if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
 
@@ -417,19 +484,11 @@ int poppy_hip_morph_frames(poppy_hip_ctx* c, double phase, poppy_write_cb write,
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->cfg.number_of_frames;
-    const size_t row = (size_t)c->W * 3;
-    if (write) { int rc = stage_host(c, row * c->H); if (rc) return rc; }
-    for (int j = 0; j < N; ++j) {
-        const double shape = poppy_frame_ratio(j, N, phase);
-        int rc = render_frame(c, shape, shape, true); if (rc) return rc;
-        if (write) {
-            HIPCHK(c, hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * c->H, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            write(user, c->h_stage, c->W, c->H, row);
-        }
-        if (phase >= 0) break;                                 // src/poppy.hpp:234-235
-    }
-    return POPPY_OK;
+    if (write) { int rc = stage_host(c, (size_t)c->W * 3 * c->H); if (rc) return rc; }
+    const int n = phase >= 0 ? 1 : N;                          // phase mode: exactly one frame (src/poppy.hpp:234-235)
+    std::vector<double> ratio(n);
+    for (int j = 0; j < n; ++j) ratio[j] = poppy_frame_ratio(j, N, phase);
+    return render_sequence(c, ratio.data(), ratio.data(), n, true, write, user);
 }
 
 int poppy_hip_dissolve(poppy_hip_ctx* c, const uint8_t* img1, size_t s1, const uint8_t* img2, size_t s2, int W, int H, double phase,
@@ -604,17 +663,8 @@ int poppy_hip_render_many(poppy_hip_ctx* c, const double* shape, const double* m
     if (!c || !shape || !mask || n < 0) return POPPY_E_ARG;
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t row = (size_t)c->W * 3;
-    if (write) { int rc = stage_host(c, row * c->H); if (rc) return rc; }
-    for (int j = 0; j < n; ++j) {
-        int rc = render_frame(c, shape[j], mask[j], chain != 0); if (rc) return rc;
-        if (write) {
-            HIPCHK(c, hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * c->H, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            write(user, c->h_stage, c->W, c->H, row);
-        }
-    }
-    return POPPY_OK;
+    if (write) { int rc = stage_host(c, (size_t)c->W * 3 * c->H); if (rc) return rc; }
+    return render_sequence(c, shape, mask, n, chain != 0, write, user);
 }
 
 }  // extern "C"
