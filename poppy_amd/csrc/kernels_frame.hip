@@ -522,75 +522,9 @@ static void launch_pyrdown_v(const void* srcL, const void* srcR, const float* sr
     dim3 grid((g3.dw * 3 + 255) / 256, (g3.dh + V - 1) / V, 3);
     hipLaunchKernelGGL((k_pyrdown<U8, V>), grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
 }
-// --- LDS-tiled reduction step (large levels) -----------------------------------------------------------
-// A workgroup produces a kDTx x kDTy tile of output pixels of one image (blockIdx.z: L, R = 3 channels, mask = 1):
-// the (2*kDTx+3) x (2*kDTy+3) source patch is staged in LDS once as float (reflect-101 addressing, u8 widened on
-// the way in), the horizontal 1-4-6-4-1 sums of its rows go to a second LDS array, the vertical pass reads those.
-// Each source element is fetched from memory once per tile (the per-element form fetches it ~6 times); sums use
-// the association the reference uses for that element column (hBodyEnd / vBodyEnd), so results are bit-identical.
-constexpr int kDTx = 32, kDTy = 8;
-constexpr int kDSx = 2 * kDTx + 3, kDSy = 2 * kDTy + 3;
-
-template <bool U8>
-__global__ void __launch_bounds__(256) k_pyrdown_tile(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
-                                                      float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
-                                                      DownGeom g3, DownGeom g1) {
-    __shared__ float S[kDSy * kDSx * 3];
-    __shared__ float Hs[kDSy * kDTx * 3];
-    const int which = blockIdx.z;
-    const DownGeom g = which == 2 ? g1 : g3;
-    const int cn = g.cn;
-    const void* src = which == 2 ? (const void*)srcM : which ? srcR : srcL;
-    float* dst = which == 2 ? dstM : which ? dstR : dstL;
-    const bool u8 = U8 && which != 2;
-    const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * kDTx, ty0 = blockIdx.y * kDTy;
-    const int srow = kDSx * cn, hrow = kDTx * cn;
-    // 1. stage the source patch: S(r, j) = src(reflect(2*ty0 - 2 + r), reflect(2*tx0 - 2 + j))
-    for (int i = tid; i < kDSy * kDSx; i += 256) {
-        const int r = i / kDSx, j = i - r * kDSx;
-        const int yy = reflect101(2 * ty0 - 2 + r, g.sh), xx = reflect101(2 * tx0 - 2 + j, g.sw);
-        const size_t o = ((size_t)yy * g.sw + xx) * cn;
-        for (int c = 0; c < cn; ++c)
-            S[r * srow + j * cn + c] = u8 ? (float)((const uint8_t*)src)[o + c] * kInv255 : ((const float*)src)[o + c];
-    }
-    __syncthreads();
-    // 2. horizontal sums: Hs(r, e) for output element e = lx*cn + c  <-  S columns 2*lx .. 2*lx + 4
-    for (int i = tid; i < kDSy * hrow; i += 256) {
-        const int r = i / hrow, e = i - r * hrow;
-        const int lx = e / cn, c = e - lx * cn;
-        const int xe = (tx0 + lx) * cn + c;
-        const float* t = S + r * srow + (2 * lx) * cn + c;
-        const float t0 = t[0], t1 = t[cn], t2 = t[2 * cn], t3 = t[3 * cn], t4 = t[4 * cn];
-        const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
-        Hs[i] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
-                      : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
-    }
-    __syncthreads();
-    // 3. vertical sums
-    const float s = 1.f / 256;
-    for (int i = tid; i < kDTy * hrow; i += 256) {
-        const int ly = i / hrow, e = i - ly * hrow;
-        const int lx = e / cn, c = e - lx * cn;
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= g.dw || y >= g.dh) continue;
-        const int xe = x * cn + c;
-        const float* q = Hs + (2 * ly) * hrow + e;
-        const float r0 = q[0], r1 = q[hrow], r2 = q[2 * hrow], r3 = q[3 * hrow], r4 = q[4 * hrow];
-        dst[((size_t)y * g.dw + x) * cn + c] = (xe < g.vBodyEnd) ? ((r1 + r3 + r2) * 4.f + (r0 + r4 + (r2 + r2))) * s
-                                                                 : (r2 * 6.f + (r1 + r3) * 4.f + r0 + r4) * s;
-    }
-}
-
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
                     float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
     DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
-    if ((size_t)g3.dw * g3.dh >= (size_t)16384) {       // large level: tiled form
-        dim3 grid((g3.dw + kDTx - 1) / kDTx, (g3.dh + kDTy - 1) / kDTy, 3);
-        if (src_u8) hipLaunchKernelGGL(k_pyrdown_tile<true>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
-        else        hipLaunchKernelGGL(k_pyrdown_tile<false>, grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
-        return;
-    }
     // taller strips share more row sums but leave fewer threads: only worth it when the level is large
     const size_t outputs = (size_t)g3.dw * g3.dh * 3;
     const int V = outputs >= (size_t)5000000 ? 4 : outputs >= (size_t)1000000 ? 2 : 1;
@@ -673,62 +607,8 @@ __global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, c
             }
     }
 }
-// --- LDS-tiled collapse step (large levels) -------------------------------------------------------------
-// A workgroup handles a kCTx x kCTy patch of LOW-resolution pixels (= 2kCTx x 2kCTy outputs): the patch plus a
-// one-pixel ring of each of the three low-resolution images is staged in LDS once; every thread then expands
-// interior quads from LDS (pyrup_quad), border quads use the exact edge formulas through collapse_elem.
-constexpr int kCTx = 32, kCTy = 8;
-constexpr int kCPx = kCTx + 2, kCPy = kCTy + 2;
-
-template <bool U8>
-__global__ void __launch_bounds__(256) k_collapse_tile(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
-                                                       const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                       float* __restrict__ outB, int w, int h, int nw, int nh) {
-    __shared__ float P[3][kCPy * kCPx * 3];
-    const int tid = threadIdx.x;
-    const int sx0 = blockIdx.x * kCTx, sy0 = blockIdx.y * kCTy;
-    for (int i = tid; i < kCPy * kCPx; i += 256) {
-        const int r = i / kCPx, j = i - r * kCPx;
-        const int yy = min(max(sy0 - 1 + r, 0), nh - 1), xx = min(max(sx0 - 1 + j, 0), nw - 1);   // clamped entries are never used
-        const size_t o = ((size_t)yy * nw + xx) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { P[0][i * 3 + c] = nL[o + c]; P[1][i * 3 + c] = nR[o + c]; P[2][i * 3 + c] = nB[o + c]; }
-    }
-    __syncthreads();
-    for (int i = tid; i < kCTy * kCTx * 3; i += 256) {
-        const int ly = i / (kCTx * 3), e = i - ly * (kCTx * 3);
-        const int lx = e / 3, c = e - lx * 3;
-        const int sx = sx0 + lx, sy = sy0 + ly;
-        if (sx >= nw || sy >= nh) continue;
-        const int x0 = 2 * sx, y0 = 2 * sy;
-        if (sx >= 1 && sx <= nw - 2 && sy >= 1 && sy <= nh - 2) {
-            const int po = ((ly + 1) * kCPx + (lx + 1)) * 3 + c;
-            const UpQuad uL = pyrup_quad(&P[0][po], kCPx * 3), uR = pyrup_quad(&P[1][po], kCPx * 3), uB = pyrup_quad(&P[2][po], kCPx * 3);
-            const size_t e00 = ((size_t)y0 * w + x0) * 3 + c, e10 = e00 + (size_t)w * 3;
-            const size_t m00 = (size_t)y0 * w + x0, m10 = m00 + w;
-            outB[e00]     = uB.ee + mix_lr(ld<U8>(gL, e00) - uL.ee,     ld<U8>(gR, e00) - uR.ee,     gM[m00]);
-            outB[e00 + 3] = uB.eo + mix_lr(ld<U8>(gL, e00 + 3) - uL.eo, ld<U8>(gR, e00 + 3) - uR.eo, gM[m00 + 1]);
-            outB[e10]     = uB.oe + mix_lr(ld<U8>(gL, e10) - uL.oe,     ld<U8>(gR, e10) - uR.oe,     gM[m10]);
-            outB[e10 + 3] = uB.oo + mix_lr(ld<U8>(gL, e10 + 3) - uL.oo, ld<U8>(gR, e10 + 3) - uR.oo, gM[m10 + 1]);
-        } else {
-            for (int dy = 0; dy < 2; ++dy)
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int x = x0 + dx, y = y0 + dy;
-                    if (x < w && y < h)
-                        outB[((size_t)y * w + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
-                }
-        }
-    }
-}
-
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
                      float* outB, int w, int h, int nw, int nh, hipStream_t s) {
-    if ((size_t)nw * nh >= (size_t)16384) {
-        dim3 grid((nw + kCTx - 1) / kCTx, (nh + kCTy - 1) / kCTy);
-        if (g_u8) hipLaunchKernelGGL(k_collapse_tile<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
-        else      hipLaunchKernelGGL(k_collapse_tile<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
-        return;
-    }
     dim3 grid((nw * 3 + 255) / 256, nh);
     if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
     else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
