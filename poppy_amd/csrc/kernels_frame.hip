@@ -10,6 +10,7 @@
 // Reference routines are cited per kernel (OCV = third/opencv-4.6.0/modules).
 #include "kernels.h"
 #include <climits>
+#include <cmath>
 
 namespace poppy_hip {
 
@@ -237,8 +238,9 @@ void launch_raster(const int* tri_xy, const int* work, int n_work, int32_t* triM
 __device__ __forceinline__ void bilinear_weights(int fx, int fy, int& w00, int& w01, int& w10, int& w11) {
     // BilinearTab_i: saturate_cast<short>((1-fy/32)(1-fx/32)*32768) etc.  All products are exact; only the
     // very first entry saturates (32768 -> 32767) and its deficit goes to tap [1][1] (imgwarp.cpp:251-267).
-    w00 = (32 - fx) * (32 - fy) * 32; w01 = fx * (32 - fy) * 32;
-    w10 = (32 - fx) * fy * 32;        w11 = fx * fy * 32;
+    // operands are < 2^24: 24-bit multiplies are full rate on CDNA, 32-bit ones quarter rate
+    w00 = __mul24(32 - fx, 32 - fy) << 5; w01 = __mul24(fx, 32 - fy) << 5;
+    w10 = __mul24(32 - fx, fy) << 5;      w11 = __mul24(fx, fy) << 5;
     if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
 }
 
@@ -256,7 +258,7 @@ __device__ __forceinline__ void sample3(const uint8_t* __restrict__ src, int W, 
     for (int k = 0; k < 3; ++k) {
         int v00 = (x0 && y0) ? p00[k] : 0, v01 = (x1 && y0) ? p00[3 + k] : 0;
         int v10 = (x0 && y1) ? p10[k] : 0, v11 = (x1 && y1) ? p10[3 + k] : 0;
-        int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        int acc = __mul24(v00, w00) + __mul24(v01, w01) + __mul24(v10, w10) + __mul24(v11, w11);
         out[k] = sat_u8((acc + (1 << 14)) >> 15);
     }
 }
@@ -313,7 +315,7 @@ __device__ __forceinline__ uint32_t sample3_packed(const uint8_t* __restrict__ s
         for (int k = 0; k < 3; ++k) {
             int v00 = (int)((a >> (8 * k)) & 255), v01 = (int)((a >> (24 + 8 * k)) & 255);
             int v10 = (int)((b >> (8 * k)) & 255), v11 = (int)((b >> (24 + 8 * k)) & 255);
-            int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+            int acc = __mul24(v00, w00) + __mul24(v01, w01) + __mul24(v10, w10) + __mul24(v11, w11);
             out |= (uint32_t)sat_u8((acc + (1 << 14)) >> 15) << (8 * k);
         }
     } else {
@@ -809,7 +811,7 @@ constexpr int kURx = kUTx + 2;                          // row-pass / diff tile 
 constexpr int kUDy = kUTy + 2;
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                      int W, int H, float amount, float threshold) {
+                                                      int W, int H, float amount, double norm2_min) {
     __shared__ float S[kUSy * kUSx * 3];
     __shared__ float R[kUSy * kURx * 3];
     __shared__ float D[kUDy * kURx * 3];
@@ -866,7 +868,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
         const double nrm2 = (double)d[0] * (double)d[0] + (double)d[1] * (double)d[1] + (double)d[2] * (double)d[2];
         const float* sv = S + ((ly + 5) * kUSx + (lx + 5)) * 3;
         float v0 = sv[0], v1 = sv[1], v2 = sv[2];
-        if (sqrt(nrm2) >= (double)threshold) { v0 = v0 + amount * d[0]; v1 = v1 + amount * d[1]; v2 = v2 + amount * d[2]; }
+        if (nrm2 >= norm2_min) { v0 = v0 + amount * d[0]; v1 = v1 + amount * d[1]; v2 = v2 + amount * d[2]; }
         const size_t p = ((size_t)y * W + x) * 3;
         if (outF) { outF[p] = v0; outF[p + 1] = v1; outF[p + 2] = v2; }
         out[p] = sat_u8(cv_round_x86(v0 * 255.f + 0.f));
@@ -878,8 +880,16 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
                     int w, int h, float amount, float threshold, hipStream_t s) {
     if (w > 1 && h > 1) {
+        // norm(d) >= threshold with norm = correctly rounded sqrt of a double: equivalent to |d|^2 >= x*, where x* is the
+        // smallest double whose square root rounds to >= threshold (found here with the host's IEEE sqrt).
+        const double t = (double)threshold;
+        double x = t <= 0 ? 0.0 : t * t;
+        if (t > 0) {
+            while (x > 0 && std::sqrt(std::nextafter(x, 0.0)) >= t) x = std::nextafter(x, 0.0);
+            while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
+        }
         dim3 grid((w + kUTx - 1) / kUTx, (h + kUTy - 1) / kUTy);
-        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, threshold);
+        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, x);
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);
