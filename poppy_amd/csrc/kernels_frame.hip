@@ -301,59 +301,84 @@ __device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t* p) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t sample3_packed(const uint8_t* __restrict__ src, int W, int H, float mx, float my) {
+struct Tap { int w00, w01, w10, w11; int ix, iy; bool inside; };
+
+__device__ __forceinline__ Tap make_tap(float mx, float my, int W, int H) {
+    Tap t;
     int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
-    int w00, w01, w10, w11;
-    bilinear_weights(sx & 31, sy & 31, w00, w01, w10, w11);
-    int ix = sx >> 5, iy = sy >> 5;
-    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
+    bilinear_weights(sx & 31, sy & 31, t.w00, t.w01, t.w10, t.w11);
+    t.ix = max(-32768, min(32767, sx >> 5)); t.iy = max(-32768, min(32767, sy >> 5));
+    t.inside = t.ix >= 0 && t.ix < W - 1 && t.iy >= 0 && t.iy < H - 1;
+    return t;
+}
+
+__device__ __forceinline__ uint32_t blend_tap(const Tap& t, uint64_t a, uint64_t b) {
     uint32_t out = 0;
-    if (ix >= 0 && ix < W - 1 && iy >= 0 && iy < H - 1) {
-        const uint8_t* p = src + ((size_t)iy * W + ix) * 3;
-        const uint64_t a = ld_u64_unaligned(p), b = ld_u64_unaligned(p + (size_t)W * 3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            int v00 = (int)((a >> (8 * k)) & 255), v01 = (int)((a >> (24 + 8 * k)) & 255);
-            int v10 = (int)((b >> (8 * k)) & 255), v11 = (int)((b >> (24 + 8 * k)) & 255);
-            int acc = __mul24(v00, w00) + __mul24(v01, w01) + __mul24(v10, w10) + __mul24(v11, w11);
-            out |= (uint32_t)sat_u8((acc + (1 << 14)) >> 15) << (8 * k);
-        }
-    } else {
-        uint8_t o[3];
-        sample3(src, W, H, mx, my, o);
-        out = o[0] | (o[1] << 8) | (o[2] << 16);
+    for (int k = 0; k < 3; ++k) {
+        int v00 = (int)((a >> (8 * k)) & 255), v01 = (int)((a >> (24 + 8 * k)) & 255);
+        int v10 = (int)((b >> (8 * k)) & 255), v11 = (int)((b >> (24 + 8 * k)) & 255);
+        int acc = __mul24(v00, t.w00) + __mul24(v01, t.w01) + __mul24(v10, t.w10) + __mul24(v11, t.w11);
+        out |= (uint32_t)sat_u8((acc + (1 << 14)) >> 15) << (8 * k);
     }
     return out;
 }
 
+// The kernel is written as straight-line phases (ids -> matrices -> coordinates -> ALL footprint loads -> blends)
+// so that a thread has its 16 footprint loads in flight at once; the rare footprints that touch the image border
+// are recomputed by the byte-wise path afterwards.  Block = 64 x 4: the four waves of a block work on four
+// consecutive rows, which share source rows in the CU's L1.
 __global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4, const float* __restrict__ inv1, const float* __restrict__ inv2,
                                                const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H) {
     const int W4 = W >> 2;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;      // index of the 4-pixel group inside the row
-    const int y = blockIdx.y;
-    if (q >= W4) return;
+    const int q = blockIdx.x * 64 + threadIdx.x;               // index of the 4-pixel group inside the row
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (q >= W4 || y >= H) return;
     const int4 ids = triMap4[(size_t)y * W4 + q];
     const int id[4] = {ids.x - 1, ids.y - 1, ids.z - 1, ids.w - 1};
-    uint32_t p1[4], p2[4];
-    float h1[9], h2[9];
-    int cur = -1;
-    const float fy = (float)y;
+    float mx[2][4], my[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int x = q * 4 + k;
-        float mx1 = (float)x, my1 = fy, mx2 = mx1, my2 = fy;
-        if (id[k] >= 0) {
-            if (id[k] != cur) {
-                cur = id[k];
+        const size_t m = (size_t)max(id[k], 0) * 9;
+        float h1[9], h2[9];
 #pragma unroll
-                for (int e = 0; e < 9; ++e) { h1[e] = inv1[(size_t)cur * 9 + e]; h2[e] = inv2[(size_t)cur * 9 + e]; }
-            }
-            map_point(h1, x, y, mx1, my1);
-            map_point(h2, x, y, mx2, my2);
+        for (int e = 0; e < 9; ++e) { h1[e] = inv1[m + e]; h2[e] = inv2[m + e]; }
+        float ax, ay, bx, by;
+        map_point(h1, x, y, ax, ay);
+        map_point(h2, x, y, bx, by);
+        const bool mapped = id[k] >= 0;
+        mx[0][k] = mapped ? ax : (float)x; my[0][k] = mapped ? ay : (float)y;
+        mx[1][k] = mapped ? bx : (float)x; my[1][k] = mapped ? by : (float)y;
+    }
+    Tap t[2][4];
+    uint64_t ra[2][4], rb[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[0][k] = make_tap(mx[0][k], my[0][k], W, H);
+        t[1][k] = make_tap(mx[1][k], my[1][k], W, H);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint8_t* src = im ? c2 : c1;
+            const size_t o = t[im][k].inside ? ((size_t)t[im][k].iy * W + t[im][k].ix) * 3 : 0;
+            ra[im][k] = ld_u64_unaligned(src + o);
+            rb[im][k] = ld_u64_unaligned(src + o + (size_t)W * 3);
         }
-        p1[k] = sample3_packed(c1, W, H, mx1, my1);
-        p2[k] = sample3_packed(c2, W, H, mx2, my2);
+    }
+    uint32_t p1[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p1[k] = blend_tap(t[0][k], ra[0][k], rb[0][k]);
+        p2[k] = blend_tap(t[1][k], ra[1][k], rb[1][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                               // footprints crossing the border: exact byte-wise path
+        if (!t[0][k].inside) { uint8_t o[3]; sample3(c1, W, H, mx[0][k], my[0][k], o); p1[k] = o[0] | (o[1] << 8) | (o[2] << 16); }
+        if (!t[1][k].inside) { uint8_t o[3]; sample3(c2, W, H, mx[1][k], my[1][k], o); p2[k] = o[0] | (o[1] << 8) | (o[2] << 16); }
     }
     // 4 BGR pixels -> 3 dwords
     const size_t o = ((size_t)y * W4 + q) * 3;
@@ -364,8 +389,8 @@ __global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4,
 
 void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
                  uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s) {
-    if ((w & 3) == 0)
-        hipLaunchKernelGGL(k_warp4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, s, (const int4*)triMap, inv1, inv2, c1, c2,
+    if ((w & 3) == 0 && w >= 8 && h >= 2)
+        hipLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, (const int4*)triMap, inv1, inv2, c1, c2,
                            (uint32_t*)tr1, (uint32_t*)tr2, w, h);
     else
         hipLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
