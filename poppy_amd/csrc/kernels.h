@@ -37,6 +37,12 @@ void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
                      const float* nL, const float* nR, const float* nB, float* outB,
                      int w, int h, int nw, int nh, hipStream_t s);
 
+// wide-access forms (kernels_pyramid_vec.hip); return false when the level's geometry does not allow them
+bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s);
+bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s);
+
 // all remaining (small) levels in one workgroup: reductions down to level `levels`, the smallest-level
 // mix and the collapse back up to level `first`; writes B_first.
 // n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS).

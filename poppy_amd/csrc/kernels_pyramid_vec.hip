@@ -1,0 +1,265 @@
+// kernels_pyramid_vec.hip — wide-access forms of the two pyramid kernels that carry most of a frame's bytes
+// (pyrDown and the fused collapse step) for levels whose rows are 16-byte aligned (width % 4 == 0).
+//
+// Why a second form: the per-element kernels in kernels_frame.hip issue one 4-byte (or 1-byte) access per lane
+// and walk 3-channel rows with a stride of 3 elements, so a wave needs ~10x more memory instructions than the
+// bytes justify and the address pipeline, not HBM, sets the pace (profiles/r01_c_pmc_4k.md).  Here every thread
+// owns 4 horizontally adjacent OUTPUT pixels of one row (12 floats = three 16-byte stores), pulls its inputs with
+// 16-/12-byte loads and keeps the stencil in registers.  Each output is the same expression tree as in the
+// per-element form (pyrdown_elem / pyrup_elem / mix_lr), so results stay bit-identical; threads whose stencil
+// touches an image border, where the reference switches formulas, call the per-element functions.
+#include "kernels.h"
+#include "pyramid_device.h"
+
+namespace poppy_hip {
+
+// ------------------------------------------------------------------------------------------------
+// pyrDown, 3 channels.  Thread (t, y): output pixels 4t..4t+3 of output row y.
+// source pixels 8t-2 .. 8t+8 (11 pixels = 33 elements) of rows 2y-2 .. 2y+2.
+// ------------------------------------------------------------------------------------------------
+template <bool U8>
+__device__ __forceinline__ void load_row33(const void* src, size_t row_elems, int row, int t, float* v /*36: elements 24t-8 .. 24t+27*/) {
+    if (U8) {
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)src + (size_t)row * row_elems + (size_t)(24 * t - 8));
+        uint32_t w[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) v[i] = (float)((w[i >> 2] >> (8 * (i & 3))) & 255u) * kInv255;
+    } else {
+        const float4* p = (const float4*)((const float*)src + (size_t)row * row_elems + (size_t)(24 * t - 8));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+    }
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ srcL, const void* __restrict__ srcR,
+                                                      float* __restrict__ dstL, float* __restrict__ dstR, DownGeom g) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int nt = g.dw >> 2;
+    if (t >= nt || y >= g.dh) return;
+    const void* src = blockIdx.z ? srcR : srcL;
+    float* dst = blockIdx.z ? dstR : dstL;
+    const int dwe = g.dw * 3;
+    const size_t srow = (size_t)g.sw * 3;
+    // interior: every tap inside the image (columns 8t-2 >= 0 and 8t+8 <= sw-1 plus the 2 spare elements of the
+    // aligned window; rows 2y-2 >= 0 and 2y+2 <= sh-1)
+    const bool interior = t >= 1 && 24 * t + 27 < g.sw * 3 && y >= 1 && 2 * y + 2 <= g.sh - 1;
+    if (!interior) {
+        for (int e = 0; e < 12; ++e) dst[(size_t)y * dwe + 12 * t + e] = pyrdown_elem<U8>(src, g, y, 12 * t + e);
+        return;
+    }
+    float r[5][12];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float v[36];
+        load_row33<U8>(src, srow, 2 * y - 2 + k, t, v);
+        // element e of output pixel j: taps at source elements (8t + 2j - 2 + m)*3 + c  ->  window index 2 + 6j + 3m + c
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int j = e / 3, c = e - 3 * j;
+            const int b = 2 + 6 * j + c;
+            const float t0 = v[b], t1 = v[b + 3], t2 = v[b + 6], t3 = v[b + 9], t4 = v[b + 12];
+            const int xe = 12 * t + e;
+            const bool hBody = (xe >= 3) && (xe < g.hBodyEnd);
+            r[k][e] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                            : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+        }
+    }
+    const float s = 1.f / 256;
+    float o[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const int xe = 12 * t + e;
+        o[e] = (xe < g.vBodyEnd) ? ((r[1][e] + r[3][e] + r[2][e]) * 4.f + (r[0][e] + r[4][e] + (r[2][e] + r[2][e]))) * s
+                                 : (r[2][e] * 6.f + (r[1][e] + r[3][e]) * 4.f + r[0][e] + r[4][e]) * s;
+    }
+    float4* d = (float4*)(dst + (size_t)y * dwe + 12 * t);
+    d[0] = make_float4(o[0], o[1], o[2], o[3]);
+    d[1] = make_float4(o[4], o[5], o[6], o[7]);
+    d[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
+// pyrDown, 1 channel (mask).  Thread (t, y): output pixels 4t..4t+3; source pixels 8t-2 .. 8t+8 of rows 2y-2 .. 2y+2,
+// fetched as four float4 from the aligned window 8t-4 .. 8t+11.
+__global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ src, float* __restrict__ dst, DownGeom g) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int nt = g.dw >> 2;
+    if (t >= nt || y >= g.dh) return;
+    const bool interior = t >= 1 && 8 * t + 11 < g.sw && y >= 1 && 2 * y + 2 <= g.sh - 1;
+    if (!interior) {
+        for (int e = 0; e < 4; ++e) dst[(size_t)y * g.dw + 4 * t + e] = pyrdown_elem<false>(src, g, y, 4 * t + e);
+        return;
+    }
+    float r[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float4* p = (const float4*)(src + (size_t)(2 * y - 2 + k) * g.sw + (8 * t - 4));
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = 2 + 2 * e;                       // source pixel 8t + 2e - 2 -> window index 2 + 2e
+            const float t0 = v[b], t1 = v[b + 1], t2 = v[b + 2], t3 = v[b + 3], t4 = v[b + 4];
+            const int xe = 4 * t + e;
+            const bool hBody = (xe >= 1) && (xe < g.hBodyEnd);
+            r[k][e] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                            : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+        }
+    }
+    const float s = 1.f / 256;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int xe = 4 * t + e;
+        o[e] = (xe < g.vBodyEnd) ? ((r[1][e] + r[3][e] + r[2][e]) * 4.f + (r[0][e] + r[4][e] + (r[2][e] + r[2][e]))) * s
+                                 : (r[2][e] * 6.f + (r[1][e] + r[3][e]) * 4.f + r[0][e] + r[4][e]) * s;
+    }
+    *(float4*)(dst + (size_t)y * g.dw + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
+    const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+    if ((g3.dw & 3) != 0 || (sw & 3) != 0 || g3.dw < 16 || g3.dh < 4) return false;
+    dim3 block(64, 4), grid3((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4, 2), grid1((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown3_vec<true>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3);
+    else        hipLaunchKernelGGL(k_pyrdown3_vec<false>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3);
+    hipLaunchKernelGGL(k_pyrdown1_vec, grid1, block, 0, s, srcM, dstM, g1);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Collapse step.  Thread (t, sy): low-resolution pixels 2t, 2t+1 of low-resolution row sy -> output pixels
+// 4t..4t+3 of rows 2sy and 2sy+1 (24 floats, six 16-byte stores).  Low-resolution pixels 2t-1 .. 2t+2 of rows
+// sy-1 .. sy+1 are fetched as 12-byte loads for each of the three upsampled images in turn.
+// ------------------------------------------------------------------------------------------------
+struct float3u { float x, y, z; };     // 12-byte load unit (4-byte aligned)
+
+// up[r][j][c]: pyrUp of one image at output row r (0: even row 2sy, 1: odd row 2sy+1), output pixel j (0..3), channel c
+__device__ __forceinline__ void up_2x4(const float* __restrict__ n, size_t nrow, int sy, int t, float up[2][4][3]) {
+    float he[3][2][3], ho[3][2][3];     // [low-res row][low-res pixel 2t / 2t+1][channel]
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float3u* p = (const float3u*)(n + (size_t)(sy - 1 + r) * nrow + (size_t)(2 * t - 1) * 3);
+        const float3u a = p[0], b = p[1], c = p[2], d = p[3];
+        const float A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z}, C[3] = {c.x, c.y, c.z}, D[3] = {d.x, d.y, d.z};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            he[r][0][ch] = A[ch] + B[ch] * 6.f + C[ch];
+            ho[r][0][ch] = (B[ch] + C[ch]) * 4.f;
+            he[r][1][ch] = B[ch] + C[ch] * 6.f + D[ch];
+            ho[r][1][ch] = (C[ch] + D[ch]) * 4.f;
+        }
+    }
+    const float s = 1.f / 64;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            up[0][2 * q][ch]     = (he[0][q][ch] + he[1][q][ch] * 6.f + he[2][q][ch]) * s;
+            up[0][2 * q + 1][ch] = (ho[0][q][ch] + ho[1][q][ch] * 6.f + ho[2][q][ch]) * s;
+            up[1][2 * q][ch]     = ((he[1][q][ch] + he[2][q][ch]) * 4.f) * s;
+            up[1][2 * q + 1][ch] = ((ho[1][q][ch] + ho[2][q][ch]) * 4.f) * s;
+        }
+}
+
+template <bool U8>
+__device__ __forceinline__ void load_g12(const void* g, size_t elem_off, float v[12]) {
+    if (U8) {
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)g + elem_off);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (float)((w0 >> (8 * i)) & 255u) * kInv255;
+            v[4 + i] = (float)((w1 >> (8 * i)) & 255u) * kInv255;
+            v[8 + i] = (float)((w2 >> (8 * i)) & 255u) * kInv255;
+        }
+    } else {
+        const float4* p = (const float4*)((const float*)g + elem_off);
+        const float4 a = p[0], b = p[1], c = p[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    }
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_collapse_vec(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                      const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                      float* __restrict__ outB, int w, int h, int nw, int nh) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int sy = blockIdx.y * 4 + threadIdx.y;
+    if (t >= (nw >> 1) || sy >= nh) return;
+    const bool interior = t >= 1 && 2 * t + 2 <= nw - 1 && sy >= 1 && sy <= nh - 2;
+    if (!interior) {
+        for (int dy = 0; dy < 2; ++dy)
+            for (int e = 0; e < 12; ++e) {
+                const int y = 2 * sy + dy, xe = 12 * t + e;
+                if (y < h) outB[(size_t)y * w * 3 + xe] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, xe);
+            }
+        return;
+    }
+    const size_t nrow = (size_t)nw * 3, orow = (size_t)w * 3;
+    float res[2][12];
+    float m[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float4 q = *(const float4*)(gM + (size_t)(2 * sy + r) * w + 4 * t);
+        m[r][0] = q.x; m[r][1] = q.y; m[r][2] = q.z; m[r][3] = q.w;
+    }
+    {   // A = (G_L - up(nL)) * m
+        float up[2][4][3];
+        up_2x4(nL, nrow, sy, t, up);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float g[12];
+            load_g12<U8>(gL, (size_t)(2 * sy + r) * orow + 12 * t, g);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) res[r][e] = (g[e] - up[r][e / 3][e % 3]) * m[r][e / 3];
+        }
+    }
+    {   // + (G_R - up(nR)) * (1 - m)
+        float up[2][4][3];
+        up_2x4(nR, nrow, sy, t, up);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float g[12];
+            load_g12<U8>(gR, (size_t)(2 * sy + r) * orow + 12 * t, g);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const float anti = 1.f - m[r][e / 3];
+                const float b = (g[e] - up[r][e / 3][e % 3]) * anti;
+                res[r][e] = res[r][e] + b;
+            }
+        }
+    }
+    {   // out = up(nB) + res
+        float up[2][4][3];
+        up_2x4(nB, nrow, sy, t, up);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float o[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) o[e] = up[r][e / 3][e % 3] + res[r][e];
+            float4* d = (float4*)(outB + (size_t)(2 * sy + r) * orow + 12 * t);
+            d[0] = make_float4(o[0], o[1], o[2], o[3]);
+            d[1] = make_float4(o[4], o[5], o[6], o[7]);
+            d[2] = make_float4(o[8], o[9], o[10], o[11]);
+        }
+    }
+}
+
+bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s) {
+    if ((w & 3) != 0 || nw * 2 != w || nw < 8 || nh < 4) return false;
+    dim3 block(64, 4), grid((nw / 2 + 63) / 64, (nh + 3) / 4);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_vec<true>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    else      hipLaunchKernelGGL(k_collapse_vec<false>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    return true;
+}
+
+}  // namespace poppy_hip

@@ -1,0 +1,129 @@
+// pyramid_device.h — device-side primitives shared by the pyramid kernels (kernels_frame.hip, kernels_pyramid_vec.hip).
+// Per-element forms of pyrDown / pyrUp / the Laplacian mix, written so that every output is one fixed expression
+// tree equal to the reference's (OCV/imgproc/src/pyramids.cpp, src/blend.hpp); the wide kernels reuse them for
+// border handling and as the definition they must match.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+
+namespace poppy_hip {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// cvRound(float) on x86 (cvtss2si): half-to-even; NaN / |v| >= 2^31 -> 0x80000000
+__device__ __forceinline__ int cv_round_x86(float v) {
+    return (fabsf(v) < 2147483648.f) ? __float2int_rn(v) : INT_MIN;
+}
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+constexpr float kInv255 = (float)(1.0 / 255.0);
+
+template <bool U8> __device__ __forceinline__ float ld(const void* p, size_t i) {
+    if (U8) return (float)((const uint8_t*)p)[i] * kInv255;      // convertTo(CV_32F, 1/255): v*a + 0
+    return ((const float*)p)[i];
+}
+
+struct DownGeom {            // host-computed constants of one pyrDown (source sw x sh, cn channels)
+    int sw, sh, dw, dh, cn;
+    int w0;                  // width0 in pixels: columns reachable without the right border table
+    int hBodyEnd;            // element index where the SIMD-body association of the H pass stops
+    int vBodyEnd;            // same for the V pass: (dw*cn/4)*4
+};
+
+__host__ __device__ inline DownGeom make_down_geom(int sw, int sh, int cn) {
+    DownGeom g;
+    g.sw = sw; g.sh = sh; g.cn = cn; g.dw = (sw + 1) / 2; g.dh = (sh + 1) / 2;
+    int w0 = (sw - 3) / 2 + 1;                 // C division truncates toward zero, as in the reference
+    g.w0 = w0 < g.dw ? w0 : g.dw;
+    int width = g.w0 * cn - cn;                // elements offered to the SIMD body (starts after pixel 0)
+    int covered = 0;
+    if (width >= 4) covered = (cn == 1) ? ((width - 4) / 4 + 1) * 4 : ((width - 4) / 3 + 1) * 3;
+    g.hBodyEnd = cn + covered;
+    g.vBodyEnd = (g.dw * cn / 4) * 4;
+    return g;
+}
+
+template <bool U8>
+__device__ __forceinline__ float pyrdown_elem(const void* src, const DownGeom& g, int y, int xe) {
+    const int cn = g.cn;
+    const int px = xe / cn, c = xe - px * cn;
+    const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
+    int col[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) col[k] = reflect101(2 * px + k - 2, g.sw) * cn + c;
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int sy = reflect101(2 * y + k - 2, g.sh);
+        size_t base = (size_t)sy * g.sw * cn;
+        float t0 = ld<U8>(src, base + col[0]), t1 = ld<U8>(src, base + col[1]), t2 = ld<U8>(src, base + col[2]);
+        float t3 = ld<U8>(src, base + col[3]), t4 = ld<U8>(src, base + col[4]);
+        r[k] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                     : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+    }
+    const float s = 1.f / 256;
+    return (xe < g.vBodyEnd) ? ((r[1] + r[3] + r[2]) * 4.f + (r[0] + r[4] + (r[2] + r[2]))) * s
+                             : (r[2] * 6.f + (r[1] + r[3]) * 4.f + r[0] + r[4]) * s;
+}
+
+// horizontal pyrUp value of source row `row` at destination element dxe
+__device__ __forceinline__ float pyrup_h(const float* __restrict__ row, int sw, int cn, int dxe) {
+    const int dpx = dxe / cn, c = dxe - dpx * cn;
+    const int spx = dpx >> 1;
+    const bool odd = dpx & 1;
+    if (sw == 1) return row[c] * 8.f;
+    if (spx == 0) {
+        float s0 = row[c], s1 = row[cn + c];
+        return odd ? (s0 + s1) * 4.f : s0 * 6.f + s1 * 2.f;
+    }
+    if (spx >= sw - 1) {
+        float sm = row[(sw - 2) * cn + c], s0 = row[(sw - 1) * cn + c];
+        return odd ? s0 * 8.f : sm + s0 * 7.f;
+    }
+    float sm = row[(spx - 1) * cn + c], s0 = row[spx * cn + c], sp = row[(spx + 1) * cn + c];
+    return odd ? (s0 + sp) * 4.f : sm + s0 * 6.f + sp;
+}
+
+__device__ __forceinline__ float pyrup_elem(const float* __restrict__ src, int sw, int sh, int cn, int dy, int dxe) {
+    const int sy = dy >> 1;
+    const size_t stride = (size_t)sw * cn;
+    const float s = 1.f / 64;
+    if (dy & 1) {
+        int syp = reflect101((sy + 1) * 2, sh * 2) >> 1;
+        float r1 = pyrup_h(src + sy * stride, sw, cn, dxe), r2 = pyrup_h(src + syp * stride, sw, cn, dxe);
+        return ((r1 + r2) * 4.f) * s;
+    }
+    int sym = reflect101((sy - 1) * 2, sh * 2) >> 1, syp = reflect101((sy + 1) * 2, sh * 2) >> 1;
+    float r0 = pyrup_h(src + sym * stride, sw, cn, dxe), r1 = pyrup_h(src + sy * stride, sw, cn, dxe);
+    float r2 = pyrup_h(src + syp * stride, sw, cn, dxe);
+    return (r0 + r1 * 6.f + r2) * s;
+}
+
+// blend of one Laplacian level (blend.hpp:67-77): A = lapL*m; B = lapR*(1-m); A + B
+__device__ __forceinline__ float mix_lr(float l, float r, float m) {
+    float a = l * m;
+    float anti = 1.f - m;
+    float b = r * anti;
+    return a + b;
+}
+
+template <bool U8>
+__device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
+                                               const float* nB, int w, int h, int nw, int nh, int y, int xe) {
+    const size_t i = (size_t)y * w * 3 + xe;
+    const float m = gM[(size_t)y * w + xe / 3];
+    float lapL = ld<U8>(gL, i) - pyrup_elem(nL, nw, nh, 3, y, xe);
+    float lapR = ld<U8>(gR, i) - pyrup_elem(nR, nw, nh, 3, y, xe);
+    float res = mix_lr(lapL, lapR, m);
+    return pyrup_elem(nB, nw, nh, 3, y, xe) + res;
+}
+
+}  // namespace poppy_hip
