@@ -10,8 +10,55 @@
 // touches an image border, where the reference switches formulas, call the per-element functions.
 #include "kernels.h"
 #include "pyramid_device.h"
+#include <algorithm>
 
 namespace poppy_hip {
+
+// Interior = the threads whose whole stencil lies inside the image: t in [1, t1], row in [1, y1].  Everything else
+// (a frame of a few pixels around the level) is produced by the per-element border kernels below, so that no wave
+// of the wide kernels ever takes the slow path.
+struct VecBounds { int t1, y1; };
+
+// enumerates the output pixels outside the interior rectangle [x0, x1] x [y0, y1] of a w x h image
+__device__ __forceinline__ bool border_pixel(int i, int w, int h, int x0, int x1, int y0, int y1, int& x, int& y) {
+    const int top = y0 * w, bottom = (h - 1 - y1) * w, mid_h = y1 - y0 + 1, left = x0, right = w - 1 - x1;
+    if (i < top) { y = i / w; x = i - y * w; return true; }
+    i -= top;
+    if (i < bottom) { y = y1 + 1 + i / w; x = i % w; return true; }
+    i -= bottom;
+    if (i < left * mid_h) { y = y0 + i / left; x = i % left; return true; }
+    i -= left * mid_h;
+    if (i < right * mid_h) { y = y0 + i / right; x = x1 + 1 + i % right; return true; }
+    return false;
+}
+__host__ __device__ inline int border_count(int w, int h, int x0, int x1, int y0, int y1) {
+    return y0 * w + (h - 1 - y1) * w + (x0 + (w - 1 - x1)) * (y1 - y0 + 1);
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_pyrdown_border(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                        float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                        DownGeom g3, DownGeom g1, int x0, int x1, int y0, int y1) {
+    int x, y;
+    if (!border_pixel(blockIdx.x * blockDim.x + threadIdx.x, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dstL[((size_t)y * g3.dw + x) * 3 + c] = pyrdown_elem<U8>(srcL, g3, y, x * 3 + c);
+        dstR[((size_t)y * g3.dw + x) * 3 + c] = pyrdown_elem<U8>(srcR, g3, y, x * 3 + c);
+    }
+    dstM[(size_t)y * g1.dw + x] = pyrdown_elem<false>(srcM, g1, y, x);
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_collapse_border(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                         const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                         float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1) {
+    int x, y;
+    if (!border_pixel(blockIdx.x * blockDim.x + threadIdx.x, w, h, x0, x1, y0, y1, x, y)) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        outB[((size_t)y * w + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
+}
 
 // ------------------------------------------------------------------------------------------------
 // pyrDown, 3 channels.  Thread (t, y): output pixels 4t..4t+3 of output row y.
@@ -35,7 +82,7 @@ __device__ __forceinline__ void load_row33(const void* src, size_t row_elems, in
 
 template <bool U8>
 __global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ srcL, const void* __restrict__ srcR,
-                                                      float* __restrict__ dstL, float* __restrict__ dstR, DownGeom g) {
+                                                      float* __restrict__ dstL, float* __restrict__ dstR, DownGeom g, VecBounds b) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int nt = g.dw >> 2;
@@ -46,11 +93,7 @@ __global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ s
     const size_t srow = (size_t)g.sw * 3;
     // interior: every tap inside the image (columns 8t-2 >= 0 and 8t+8 <= sw-1 plus the 2 spare elements of the
     // aligned window; rows 2y-2 >= 0 and 2y+2 <= sh-1)
-    const bool interior = t >= 1 && 24 * t + 27 < g.sw * 3 && y >= 1 && 2 * y + 2 <= g.sh - 1;
-    if (!interior) {
-        for (int e = 0; e < 12; ++e) dst[(size_t)y * dwe + 12 * t + e] = pyrdown_elem<U8>(src, g, y, 12 * t + e);
-        return;
-    }
+    if (!(t >= 1 && t <= b.t1 && y >= 1 && y <= b.y1)) return;        // border outputs: k_pyrdown_border
     float r[5][12];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -84,16 +127,12 @@ __global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ s
 
 // pyrDown, 1 channel (mask).  Thread (t, y): output pixels 4t..4t+3; source pixels 8t-2 .. 8t+8 of rows 2y-2 .. 2y+2,
 // fetched as four float4 from the aligned window 8t-4 .. 8t+11.
-__global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ src, float* __restrict__ dst, DownGeom g) {
+__global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ src, float* __restrict__ dst, DownGeom g, VecBounds b) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int nt = g.dw >> 2;
     if (t >= nt || y >= g.dh) return;
-    const bool interior = t >= 1 && 8 * t + 11 < g.sw && y >= 1 && 2 * y + 2 <= g.sh - 1;
-    if (!interior) {
-        for (int e = 0; e < 4; ++e) dst[(size_t)y * g.dw + 4 * t + e] = pyrdown_elem<false>(src, g, y, 4 * t + e);
-        return;
-    }
+    if (!(t >= 1 && t <= b.t1 && y >= 1 && y <= b.y1)) return;        // border outputs: k_pyrdown_border
     float r[5][4];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -125,11 +164,21 @@ __global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ 
 bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
                         float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
     const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
-    if ((g3.dw & 3) != 0 || (sw & 3) != 0 || g3.dw < 16 || g3.dh < 4) return false;
+    if ((g3.dw & 3) != 0 || (sw & 3) != 0 || g3.dw < 32 || g3.dh < 8) return false;
+    // interior threads: 24t + 27 < 3 sw  (this also covers the 1-channel window 8t + 11 < sw) and 2y + 2 <= sh - 1
+    VecBounds b;
+    b.t1 = std::min(g3.dw / 4 - 1, (3 * sw - 28) / 24);
+    b.t1 = std::min(b.t1, (sw - 12) / 8);
+    b.y1 = std::min(g3.dh - 1, (sh - 3) / 2);
+    if (b.t1 < 1 || b.y1 < 1) return false;
     dim3 block(64, 4), grid3((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4, 2), grid1((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4);
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown3_vec<true>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3);
-    else        hipLaunchKernelGGL(k_pyrdown3_vec<false>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3);
-    hipLaunchKernelGGL(k_pyrdown1_vec, grid1, block, 0, s, srcM, dstM, g1);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown3_vec<true>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3, b);
+    else        hipLaunchKernelGGL(k_pyrdown3_vec<false>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3, b);
+    hipLaunchKernelGGL(k_pyrdown1_vec, grid1, block, 0, s, srcM, dstM, g1, b);
+    const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
+    const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown_border<true>, dim3((nb + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+    else        hipLaunchKernelGGL(k_pyrdown_border<false>, dim3((nb + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
     return true;
 }
 
@@ -194,15 +243,7 @@ __global__ void __launch_bounds__(256) k_collapse_vec(const void* __restrict__ g
     const int t = blockIdx.x * 64 + threadIdx.x;
     const int sy = blockIdx.y * 4 + threadIdx.y;
     if (t >= (nw >> 1) || sy >= nh) return;
-    const bool interior = t >= 1 && 2 * t + 2 <= nw - 1 && sy >= 1 && sy <= nh - 2;
-    if (!interior) {
-        for (int dy = 0; dy < 2; ++dy)
-            for (int e = 0; e < 12; ++e) {
-                const int y = 2 * sy + dy, xe = 12 * t + e;
-                if (y < h) outB[(size_t)y * w * 3 + xe] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, xe);
-            }
-        return;
-    }
+    if (!(t >= 1 && 2 * t + 2 <= nw - 1 && sy >= 1 && sy <= nh - 2)) return;     // border outputs: k_collapse_border
     const size_t nrow = (size_t)nw * 3, orow = (size_t)w * 3;
     float res[2][12];
     float m[2][4];
@@ -255,10 +296,15 @@ __global__ void __launch_bounds__(256) k_collapse_vec(const void* __restrict__ g
 
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
                          float* outB, int w, int h, int nw, int nh, hipStream_t s) {
-    if ((w & 3) != 0 || nw * 2 != w || nw < 8 || nh < 4) return false;
+    if ((w & 3) != 0 || nw * 2 != w || nw < 16 || nh < 8) return false;
+    const int t1 = (nw - 3) / 2;                      // last interior thread: 2t + 2 <= nw - 1
     dim3 block(64, 4), grid((nw / 2 + 63) / 64, (nh + 3) / 4);
     if (g_u8) hipLaunchKernelGGL(k_collapse_vec<true>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
     else      hipLaunchKernelGGL(k_collapse_vec<false>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
+    const int nb = border_count(w, h, x0, x1, y0, y1);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_border<true>, dim3((nb + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+    else      hipLaunchKernelGGL(k_collapse_border<false>, dim3((nb + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
     return true;
 }
 
