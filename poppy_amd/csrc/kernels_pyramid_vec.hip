@@ -35,29 +35,29 @@ __host__ __device__ inline int border_count(int w, int h, int x0, int x1, int y0
     return y0 * w + (h - 1 - y1) * w + (x0 + (w - 1 - x1)) * (y1 - y0 + 1);
 }
 
+// one thread per border ELEMENT (7 per pixel for pyrDown: 3 + 3 + mask; 3 per pixel for the collapse)
 template <bool U8>
 __global__ void __launch_bounds__(256) k_pyrdown_border(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
                                                         float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
                                                         DownGeom g3, DownGeom g1, int x0, int x1, int y0, int y1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pix = i / 7, k = i - pix * 7;
     int x, y;
-    if (!border_pixel(blockIdx.x * blockDim.x + threadIdx.x, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        dstL[((size_t)y * g3.dw + x) * 3 + c] = pyrdown_elem<U8>(srcL, g3, y, x * 3 + c);
-        dstR[((size_t)y * g3.dw + x) * 3 + c] = pyrdown_elem<U8>(srcR, g3, y, x * 3 + c);
-    }
-    dstM[(size_t)y * g1.dw + x] = pyrdown_elem<false>(srcM, g1, y, x);
+    if (!border_pixel(pix, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
+    if (k < 3)      dstL[((size_t)y * g3.dw + x) * 3 + k] = pyrdown_elem_wide<U8>(srcL, g3, y, x * 3 + k);
+    else if (k < 6) dstR[((size_t)y * g3.dw + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8>(srcR, g3, y, x * 3 + (k - 3));
+    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false>(srcM, g1, y, x);
 }
 
 template <bool U8>
 __global__ void __launch_bounds__(256) k_collapse_border(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                          const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
                                                          float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pix = i / 3, c = i - pix * 3;
     int x, y;
-    if (!border_pixel(blockIdx.x * blockDim.x + threadIdx.x, w, h, x0, x1, y0, y1, x, y)) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        outB[((size_t)y * w + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
+    if (!border_pixel(pix, w, h, x0, x1, y0, y1, x, y)) return;
+    outB[((size_t)y * w + x) * 3 + c] = collapse_elem_wide<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,8 +177,8 @@ bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, b
     hipLaunchKernelGGL(k_pyrdown1_vec, grid1, block, 0, s, srcM, dstM, g1, b);
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown_border<true>, dim3((nb + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
-    else        hipLaunchKernelGGL(k_pyrdown_border<false>, dim3((nb + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown_border<true>, dim3((nb * 7 + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+    else        hipLaunchKernelGGL(k_pyrdown_border<false>, dim3((nb * 7 + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
     return true;
 }
 
@@ -303,8 +303,8 @@ bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float*
     else      hipLaunchKernelGGL(k_collapse_vec<false>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
     const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
     const int nb = border_count(w, h, x0, x1, y0, y1);
-    if (g_u8) hipLaunchKernelGGL(k_collapse_border<true>, dim3((nb + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
-    else      hipLaunchKernelGGL(k_collapse_border<false>, dim3((nb + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_border<true>, dim3((nb * 3 + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+    else      hipLaunchKernelGGL(k_collapse_border<false>, dim3((nb * 3 + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
     return true;
 }
 

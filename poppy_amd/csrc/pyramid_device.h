@@ -126,4 +126,70 @@ __device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, c
     return pyrup_elem(nB, nw, nh, 3, y, xe) + res;
 }
 
+// ---- branch-free variants for levels of at least 3 x 3 pixels ------------------------------------------------
+// Same expression trees as above; only the ADDRESSING is restated without data-dependent control flow (one
+// reflection suffices when the level is at least 3 wide/high), so all loads of an output can be in flight at once.
+// They serve the border frames of the wide kernels, where a few thousand outputs would otherwise sit on a long
+// chain of dependent branches and loads.
+__device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
+
+template <bool U8>
+__device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGeom& g, int y, int xe) {
+    const int cn = g.cn;
+    const int px = xe / cn, c = xe - px * cn;
+    const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
+    int col[5];
+    size_t rowo[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        col[k] = reflect101_once(2 * px + k - 2, g.sw) * cn + c;
+        rowo[k] = (size_t)reflect101_once(2 * y + k - 2, g.sh) * g.sw * cn;
+    }
+    float t[5][5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) t[k][m] = ld<U8>(src, rowo[k] + col[m]);
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        r[k] = hBody ? t[k][2] * 6.f + ((t[k][1] + t[k][3]) * 4.f + (t[k][0] + t[k][4]))
+                     : t[k][2] * 6.f + (t[k][1] + t[k][3]) * 4.f + t[k][0] + t[k][4];
+    const float s = 1.f / 256;
+    return (xe < g.vBodyEnd) ? ((r[1] + r[3] + r[2]) * 4.f + (r[0] + r[4] + (r[2] + r[2]))) * s
+                             : (r[2] * 6.f + (r[1] + r[3]) * 4.f + r[0] + r[4]) * s;
+}
+
+// horizontal pyrUp value from three unconditionally loaded neighbours (sw >= 2)
+__device__ __forceinline__ float pyrup_h_wide(const float* __restrict__ row, int sw, int dxe) {
+    const int dpx = dxe / 3, c = dxe - dpx * 3;
+    const int spx = dpx >> 1;
+    const bool odd = dpx & 1;
+    const float sm = row[max(spx - 1, 0) * 3 + c], s0 = row[spx * 3 + c], sp = row[min(spx + 1, sw - 1) * 3 + c];
+    const bool left = spx == 0, right = spx >= sw - 1;
+    const float ev = left ? s0 * 6.f + sp * 2.f : right ? sm + s0 * 7.f : sm + s0 * 6.f + sp;
+    const float od = right ? s0 * 8.f : (s0 + sp) * 4.f;
+    return odd ? od : ev;
+}
+
+__device__ __forceinline__ float pyrup_elem_wide(const float* __restrict__ src, int sw, int sh, int dy, int dxe) {
+    const int sy = dy >> 1;
+    const size_t stride = (size_t)sw * 3;
+    const int sym = sy >= 1 ? sy - 1 : 1, syp = sy + 1 <= sh - 1 ? sy + 1 : sh - 1;      // sh >= 2
+    const float r0 = pyrup_h_wide(src + sym * stride, sw, dxe), r1 = pyrup_h_wide(src + sy * stride, sw, dxe);
+    const float r2 = pyrup_h_wide(src + syp * stride, sw, dxe);
+    const float s = 1.f / 64;
+    return (dy & 1) ? ((r1 + r2) * 4.f) * s : (r0 + r1 * 6.f + r2) * s;
+}
+
+template <bool U8>
+__device__ __forceinline__ float collapse_elem_wide(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
+                                                    const float* nB, int w, int h, int nw, int nh, int y, int xe) {
+    const size_t i = (size_t)y * w * 3 + xe;
+    const float m = gM[(size_t)y * w + xe / 3];
+    const float gl = ld<U8>(gL, i), gr = ld<U8>(gR, i);
+    const float uL = pyrup_elem_wide(nL, nw, nh, y, xe), uR = pyrup_elem_wide(nR, nw, nh, y, xe), uB = pyrup_elem_wide(nB, nw, nh, y, xe);
+    return uB + mix_lr(gl - uL, gr - uR, m);
+}
+
 }  // namespace poppy_hip
