@@ -37,10 +37,10 @@ __host__ __device__ inline int border_count(int w, int h, int x0, int x1, int y0
 
 // one thread per border ELEMENT (7 per pixel for pyrDown: 3 + 3 + mask; 3 per pixel for the collapse)
 template <bool U8>
-__global__ void __launch_bounds__(256) k_pyrdown_border(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
-                                                        float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
-                                                        DownGeom g3, DownGeom g1, int x0, int x1, int y0, int y1) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pyrdown_border_body(int block, const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                    float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                    const DownGeom& g3, const DownGeom& g1, int x0, int x1, int y0, int y1) {
+    const int i = block * 256 + threadIdx.y * 64 + threadIdx.x;
     const int pix = i / 7, k = i - pix * 7;
     int x, y;
     if (!border_pixel(pix, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
@@ -50,10 +50,10 @@ __global__ void __launch_bounds__(256) k_pyrdown_border(const void* __restrict__
 }
 
 template <bool U8>
-__global__ void __launch_bounds__(256) k_collapse_border(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
-                                                         const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                         float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void collapse_border_body(int block, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                     const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                     float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1) {
+    const int i = block * 256 + threadIdx.y * 64 + threadIdx.x;
     const int pix = i / 3, c = i - pix * 3;
     int x, y;
     if (!border_pixel(pix, w, h, x0, x1, y0, y1, x, y)) return;
@@ -81,14 +81,11 @@ __device__ __forceinline__ void load_row33(const void* src, size_t row_elems, in
 }
 
 template <bool U8>
-__global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ srcL, const void* __restrict__ srcR,
-                                                      float* __restrict__ dstL, float* __restrict__ dstR, DownGeom g, VecBounds b) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+__device__ __forceinline__ void pyrdown3_body(int bx, int by, const void* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b) {
+    const int t = bx * 64 + threadIdx.x;
+    const int y = by * 4 + threadIdx.y;
     const int nt = g.dw >> 2;
     if (t >= nt || y >= g.dh) return;
-    const void* src = blockIdx.z ? srcR : srcL;
-    float* dst = blockIdx.z ? dstR : dstL;
     const int dwe = g.dw * 3;
     const size_t srow = (size_t)g.sw * 3;
     // interior: every tap inside the image (columns 8t-2 >= 0 and 8t+8 <= sw-1 plus the 2 spare elements of the
@@ -127,9 +124,9 @@ __global__ void __launch_bounds__(256) k_pyrdown3_vec(const void* __restrict__ s
 
 // pyrDown, 1 channel (mask).  Thread (t, y): output pixels 4t..4t+3; source pixels 8t-2 .. 8t+8 of rows 2y-2 .. 2y+2,
 // fetched as four float4 from the aligned window 8t-4 .. 8t+11.
-__global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ src, float* __restrict__ dst, DownGeom g, VecBounds b) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+__device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b) {
+    const int t = bx * 64 + threadIdx.x;
+    const int y = by * 4 + threadIdx.y;
     const int nt = g.dw >> 2;
     if (t >= nt || y >= g.dh) return;
     if (!(t >= 1 && t <= b.t1 && y >= 1 && y <= b.y1)) return;        // border outputs: k_pyrdown_border
@@ -161,6 +158,26 @@ __global__ void __launch_bounds__(256) k_pyrdown1_vec(const float* __restrict__ 
     *(float4*)(dst + (size_t)y * g.dw + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// One launch per level: blocks [0, 3*nbi) are the interior tiles of L, R and the mask, the rest enumerate the border
+// elements.  The role of a block is uniform, so nothing diverges inside a wave.
+template <bool U8>
+__global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                       float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                       DownGeom g3, DownGeom g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1) {
+    const int nbi = gx * gy;
+    int blk = blockIdx.x;
+    if (blk >= nborder) {                 // border blocks come first: their load chains are the longest
+        blk -= nborder;
+        const int which = blk / nbi; blk -= which * nbi;
+        const int by = blk / gx, bx = blk - by * gx;
+        if (which == 0)      pyrdown3_body<U8>(bx, by, srcL, dstL, g3, b);
+        else if (which == 1) pyrdown3_body<U8>(bx, by, srcR, dstR, g3, b);
+        else                 pyrdown1_body(bx, by, srcM, dstM, g1, b);
+    } else {
+        pyrdown_border_body<U8>(blk, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+    }
+}
+
 bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
                         float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
     const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
@@ -171,14 +188,12 @@ bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, b
     b.t1 = std::min(b.t1, (sw - 12) / 8);
     b.y1 = std::min(g3.dh - 1, (sh - 3) / 2);
     if (b.t1 < 1 || b.y1 < 1) return false;
-    dim3 block(64, 4), grid3((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4, 2), grid1((g3.dw / 4 + 63) / 64, (g3.dh + 3) / 4);
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown3_vec<true>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3, b);
-    else        hipLaunchKernelGGL(k_pyrdown3_vec<false>, grid3, block, 0, s, srcL, srcR, dstL, dstR, g3, b);
-    hipLaunchKernelGGL(k_pyrdown1_vec, grid1, block, 0, s, srcM, dstM, g1, b);
+    const int gx = (g3.dw / 4 + 63) / 64, gy = (g3.dh + 3) / 4;
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown_border<true>, dim3((nb * 7 + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
-    else        hipLaunchKernelGGL(k_pyrdown_border<false>, dim3((nb * 7 + 255) / 256), dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+    const int nborder = (nb * 7 + 255) / 256, blocks = 3 * gx * gy + nborder;
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1);
+    else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1);
     return true;
 }
 
@@ -237,11 +252,11 @@ __device__ __forceinline__ void load_g12(const void* g, size_t elem_off, float v
 }
 
 template <bool U8>
-__global__ void __launch_bounds__(256) k_collapse_vec(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
-                                                      const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                      float* __restrict__ outB, int w, int h, int nw, int nh) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int sy = blockIdx.y * 4 + threadIdx.y;
+__device__ __forceinline__ void collapse_body(int bx, int by, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                              const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                              float* __restrict__ outB, int w, int h, int nw, int nh) {
+    const int t = bx * 64 + threadIdx.x;
+    const int sy = by * 4 + threadIdx.y;
     if (t >= (nw >> 1) || sy >= nh) return;
     if (!(t >= 1 && 2 * t + 2 <= nw - 1 && sy >= 1 && sy <= nh - 2)) return;     // border outputs: k_collapse_border
     const size_t nrow = (size_t)nw * 3, orow = (size_t)w * 3;
@@ -294,17 +309,31 @@ __global__ void __launch_bounds__(256) k_collapse_vec(const void* __restrict__ g
     }
 }
 
+template <bool U8>
+__global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                        const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                        float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
+                                                        int x0, int x1, int y0, int y1) {
+    int blk = blockIdx.x;
+    if (blk >= nborder) {
+        blk -= nborder;
+        const int by = blk / gx, bx = blk - by * gx;
+        collapse_body<U8>(bx, by, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    } else {
+        collapse_border_body<U8>(blk, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+    }
+}
+
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
                          float* outB, int w, int h, int nw, int nh, hipStream_t s) {
     if ((w & 3) != 0 || nw * 2 != w || nw < 16 || nh < 8) return false;
     const int t1 = (nw - 3) / 2;                      // last interior thread: 2t + 2 <= nw - 1
-    dim3 block(64, 4), grid((nw / 2 + 63) / 64, (nh + 3) / 4);
-    if (g_u8) hipLaunchKernelGGL(k_collapse_vec<true>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
-    else      hipLaunchKernelGGL(k_collapse_vec<false>, grid, block, 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    const int gx = (nw / 2 + 63) / 64, gy = (nh + 3) / 4;
     const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
     const int nb = border_count(w, h, x0, x1, y0, y1);
-    if (g_u8) hipLaunchKernelGGL(k_collapse_border<true>, dim3((nb * 3 + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
-    else      hipLaunchKernelGGL(k_collapse_border<false>, dim3((nb * 3 + 255) / 256), dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+    const int nborder = (nb * 3 + 255) / 256, blocks = gx * gy + nborder;
+    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1);
+    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1);
     return true;
 }
 
