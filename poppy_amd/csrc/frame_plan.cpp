@@ -257,6 +257,56 @@ inline void homogeneous(const int* xy, float* m) {
 
 }  // namespace
 
+// Runs FillConvexPoly's edge walk (drawing.cpp:1164-1252) for every triangle and records what it decides: the rows
+// painted and each chain's (first row, x at that row, dx per row) segments.  All divisions of the walk happen here.
+static void build_raster(FramePlan& plan, int w, int h) {
+    const int T = plan.n_tris;
+    plan.raster.assign(T, RasterTri{});
+    plan.work.clear();
+    for (int t = 0; t < T; ++t) {
+        const int* v = &plan.tri_xy[(size_t)t * 6];
+        const int vx[3] = {v[0], v[2], v[4]}, vy[3] = {v[1], v[3], v[5]};
+        RasterTri& r = plan.raster[t];
+        int imin = 0, xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+        for (int i = 0; i < 3; ++i) {
+            if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+            ymax = std::max(ymax, vy[i]); xmax = std::max(xmax, vx[i]); xmin = std::min(xmin, vx[i]);
+        }
+        r.ymin = ymin; r.ystop = ymin;
+        if (!(xmax < 0 || ymax < 0 || xmin >= w || ymin >= h)) {
+            ymax = std::min(ymax, h - 1);
+            int eidx[2] = {imin, imin}, eye[2] = {ymin, ymin}, nseg[2] = {0, 0};
+            const int edi[2] = {1, 2};
+            int edges = 3, y = ymin;
+            for (; y <= ymax; ++y) {
+                for (int i = 0; i < 2; ++i) {
+                    if (y < eye[i]) continue;
+                    int idx0 = eidx[i], idx = (idx0 + edi[i]) % 3;
+                    for (; edges-- > 0;) {
+                        const int ty = vy[idx];
+                        if (ty > y) {
+                            const long long xs = (long long)vx[idx0] << 16, xe = (long long)vx[idx] << 16;
+                            const int k = i * 2 + std::min(nseg[i], 1);
+                            r.ybeg[k] = y; r.ex[k] = xs;
+                            r.edx[k] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                            ++nseg[i];
+                            eye[i] = ty; eidx[i] = idx;
+                            break;
+                        }
+                        idx0 = idx; idx = (idx + edi[i]) % 3;
+                    }
+                }
+                if (edges < 0) break;
+            }
+            r.ystop = y;
+            r.n0 = nseg[0]; r.n1 = nseg[1];
+        }
+        const int rows = r.ystop - r.ymin;
+        const int chunks = rows > 0 ? (rows + kPlanRasterRows - 1) / kPlanRasterRows : 1;   // chunk 0 also draws the outline
+        for (int k = 0; k < chunks; ++k) { plan.work.push_back(t); plan.work.push_back(k); }
+    }
+}
+
 int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f>& src2, double shape_ratio, FramePlan& plan) {
     const size_t n = src1.size();
     std::vector<P2f> a = src1, b = src2;
@@ -315,6 +365,7 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
         invert3x3(M1, &plan.inv1[(size_t)t * 9]);
         invert3x3(M2, &plan.inv2[(size_t)t * 9]);
     }
+    build_raster(plan, w, h);
     return 0;
 }
 

@@ -10,14 +10,28 @@ namespace poppy_hip {
 
 struct P2f { float x, y; };
 
+// Fill edges of one triangle, precomputed from FillConvexPoly's two-chain state machine (drawing.cpp:1164-1252):
+// chain i (0: vertices imin, imin+1, ...; 1: imin, imin+2, ...) has at most two segments; segment k of chain i is
+// slot i*2+k and holds the first row it is valid for, the 16.16 position on that row and the per-row increment.
+// Rows [ymin, ystop) are painted.  The device evaluates a row with one multiply-add per chain.
+struct RasterTri {
+    int ymin, ystop, n0, n1;
+    int ybeg[4];
+    long long ex[4], edx[4];
+};
+static_assert(sizeof(RasterTri) == 96, "RasterTri is shared with the device");
+
 struct FramePlan {
     std::vector<P2f> morphed;        // n   (after clip_points)
     std::vector<int> idx3;           // T*3 indices into the point sets
     std::vector<int> tri_xy;         // T*6 truncated morphed corners (x0,y0,x1,y1,x2,y2)
     std::vector<float> M1, M2;       // T*9 forward matrices (diagnostics)
     std::vector<float> inv1, inv2;   // T*9 inverse matrices, what create_map actually uses
+    std::vector<RasterTri> raster;   // T fill-edge tables
+    std::vector<int> work;           // raster work list: (triangle, row chunk) pairs
     int n_tris = 0;
 };
+constexpr int kPlanRasterRows = 16;  // rows of one triangle per raster work item
 
 // Returns 0, or -3 (POPPY_E_RANGE) when a point is outside [0,w)x[0,h) where Subdiv2D::insert throws.
 int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f>& src2,

@@ -18,7 +18,8 @@ void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s);
 // triangle-id map: exact fillConvexPoly raster of every triangle, later index wins (atomicMax)
 // `work` = (triangle, row-chunk) pairs, kRasterChunkRows rows per chunk, built by the host per frame
 constexpr int kRasterChunkRows = 16;
-void launch_raster(const int* tri_xy, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s);
+// `edges` = one RasterTri (frame_plan.h) per triangle: the fill-edge segments decided by the host plan
+void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s);
 
 // fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2
 void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
@@ -45,9 +46,10 @@ bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float*
 
 // all remaining (small) levels in one workgroup: reductions down to level `levels`, the smallest-level
 // mix and the collapse back up to level `first`; writes B_first.
-// n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS).
+// n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS);
+// k1 = first level in [first, levels] that is a single pixel, or `levels` when there is none.
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels,
-                     int first, int levels, int n3, int n1, hipStream_t s);
+                     int first, int levels, int k1, int n3, int n1, hipStream_t s);
 
 // unsharp_mask(lapBlend, 1, amount, 0.3) + convertTo(CV_8U, 255)  (src/util.cpp:113-148, src/algo.cpp:263-265)
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,

@@ -117,89 +117,47 @@ __device__ void outline_segment(int32_t* map, int W, int H, int ax, int ay, int 
     }
 }
 
-// Replays FillConvexPoly's two-edge state machine (drawing.cpp:1164-1252) up to row `target` without
-// visiting the rows in between: between two vertex transitions an edge advances by a constant dx per row,
-// so its 16.16 position at any row follows from the last transition.  Returns false when the reference
-// loop would already have stopped (edges exhausted) or never reaches `target`.
-__device__ bool fill_span_at(const int* vx, const int* vy, int imin, int ymin, int ymax, int target, long long& xl, long long& xr) {
-    int eidx[2] = {imin, imin}, eye[2] = {ymin, ymin};
-    const int edi[2] = {1, 2};
-    long long ex[2] = {-65536, -65536}, edx[2] = {0, 0};
-    int edges = 3;
-    int y = ymin;
-    while (y <= ymax) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (y >= eye[i]) {
-                int idx0 = eidx[i], di = edi[i];
-                int idx = idx0 + di; if (idx >= 3) idx -= 3;
-                for (; edges-- > 0;) {
-                    int ty = vy[idx];
-                    if (ty > y) {
-                        long long xs = (long long)vx[idx0] << 16, xe = (long long)vx[idx] << 16;
-                        eye[i] = ty;
-                        edx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
-                        ex[i] = xs;
-                        eidx[i] = idx;
-                        break;
-                    }
-                    idx0 = idx;
-                    idx += di; if (idx >= 3) idx -= 3;
-                }
-            }
-        }
-        if (edges < 0) return false;
-        int next = min(eye[0], eye[1]);            // first row at which another transition fires
-        if (next <= y) next = y + 1;               // (a finished chain keeps an old ye; advance row by row)
-        if (target < next) {
-            long long d = target - y;
-            long long a = ex[0] + d * edx[0], b = ex[1] + d * edx[1];
-            xl = a > b ? b : a; xr = a > b ? a : b;
-            return true;
-        }
-        long long d = next - y;
-        ex[0] += d * edx[0]; ex[1] += d * edx[1];
-        y = next;
-    }
-    return false;
-}
+// work item = (triangle, chunk of kRasterChunkRows rows).  256 threads: 4 waves take rows round-robin, lanes split
+// the span.  Chunk 0 also draws the outline (one segment per wave).  The fill edges come from the host plan
+// (RasterTri, frame_plan.h): FillConvexPoly's two-chain walk (drawing.cpp:1164-1252) is decided there once per
+// triangle, a row here is one 64-bit multiply-add per chain.
+struct RasterTriDev {
+    int ymin, ystop, n0, n1;
+    int ybeg[4];
+    long long ex[4], edx[4];
+};
 
-constexpr int kRasterRows = 16;      // rows of one triangle handled by one workgroup
-
-// work item = (triangle, chunk of kRasterRows rows).  256 threads: 4 waves take rows round-robin,
-// lanes split the span.  Chunk 0 also draws the outline (one segment per wave).
-__global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, const int2* __restrict__ work, int n_work,
-                                                int32_t* __restrict__ map, int W, int H) {
+__global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, const RasterTriDev* __restrict__ edges,
+                                                const int2* __restrict__ work, int n_work, int32_t* __restrict__ map, int W, int H) {
     if ((int)blockIdx.x >= n_work) return;
     const int2 item = work[blockIdx.x];
     const int t = item.x, chunk = item.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int value = t + 1;
-    int vx[3], vy[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
 
     if (chunk == 0 && wave < 3) {      // outline: (v2->v0), (v0->v1), (v1->v2)
+        int vx[3], vy[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
         const int a = wave == 0 ? 2 : wave - 1, b = wave == 0 ? 0 : wave;
         outline_segment(map, W, H, vx[a], vy[a], vx[b], vy[b], value, lane);
     }
 
-    int imin = 0;
-    int xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
-        ymax = max(ymax, vy[i]); xmax = max(xmax, vx[i]); xmin = min(xmin, vx[i]);
-    }
-    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
-    ymax = min(ymax, H - 1);
+    const RasterTriDev& r = edges[t];
+    const int ymin = r.ymin, ystop = r.ystop;
+    const bool two0 = r.n0 > 1, two1 = r.n1 > 1;
+    const int yb00 = r.ybeg[0], yb01 = r.ybeg[1], yb10 = r.ybeg[2], yb11 = r.ybeg[3];
+    const long long ex00 = r.ex[0], ex01 = r.ex[1], ex10 = r.ex[2], ex11 = r.ex[3];
+    const long long dx00 = r.edx[0], dx01 = r.edx[1], dx10 = r.edx[2], dx11 = r.edx[3];
 
-    const int y0 = ymin + chunk * kRasterRows;
-    const int y1 = min(y0 + kRasterRows - 1, ymax);
-    for (int y = y0 + wave; y <= y1; y += 4) {
+    const int y0 = ymin + chunk * kRasterChunkRows;
+    const int y1 = min(y0 + kRasterChunkRows, ystop);
+    for (int y = y0 + wave; y < y1; y += 4) {
         if (y < 0) continue;
-        long long xl, xr;
-        if (!fill_span_at(vx, vy, imin, ymin, ymax, y, xl, xr)) continue;
+        const bool s0 = two0 && y >= yb01, s1 = two1 && y >= yb11;
+        const long long a = (s0 ? ex01 : ex00) + (long long)(y - (s0 ? yb01 : yb00)) * (s0 ? dx01 : dx00);
+        const long long b = (s1 ? ex11 : ex10) + (long long)(y - (s1 ? yb11 : yb10)) * (s1 ? dx11 : dx10);
+        const long long xl = a > b ? b : a, xr = a > b ? a : b;
         int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
         if (xx2 >= 0 && xx1 < W) {
             if (xx1 < 0) xx1 = 0;
@@ -209,8 +167,9 @@ __global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, 
         }
     }
 }
-void launch_raster(const int* tri_xy, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s) {
-    if (n_work > 0) hipLaunchKernelGGL(k_raster, dim3(n_work), dim3(256), 0, s, tri_xy, (const int2*)work, n_work, triMap, w, h);
+void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s) {
+    if (n_work > 0)
+        hipLaunchKernelGGL(k_raster, dim3(n_work), dim3(256), 0, s, tri_xy, (const RasterTriDev*)edges, (const int2*)work, n_work, triMap, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,82 +486,104 @@ void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
 }
 
 // --- all small levels in one workgroup, staged in LDS ---------------------------------------------
-// Levels first..levels live in LDS (at most ~1.4k pixels in total).  Levels with more than one pixel are
-// processed by the whole block with a barrier per level.  Once a level is 1x1 every deeper level is 1x1
-// too (there are ~50 of them at 1080p with pyramid_levels = 64): those form a purely sequential chain of a
-// few flops per level, which three lanes (one per colour channel) walk without any barrier — each lane only
-// ever reads what it wrote itself.  The mask chain is replicated per lane for the same reason.
+// Levels first..levels live in LDS (a few hundred pixels in total).  The kernel is a single workgroup, so its time is
+// the number of instructions each SIMD has to issue: four waves only, branch-free per-element forms for every level
+// of at least 3x3, and no level-table lookups inside the sequential part.
+// Once a level is 1x1 (level k1, found by the host) every deeper level is 1x1 too — ~50 of them at 1080p with
+// pyramid_levels = 64.  Going down, the seven scalar chains (L and R per channel, mask) run on seven lanes.  Going
+// up, everything that does not depend on the running value (the Laplacian residual of each level) is computed for all
+// levels at once, one lane per (level, channel); what remains sequential is  cur = pyrUp(cur) + residual[i].
 constexpr int kTailMaxLevels = 257;
+constexpr int kTailThreads = 256;
 
-__global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL, const float* __restrict__ gR, const float* __restrict__ gM,
-                                                   float* __restrict__ gB, const PyrLevel* __restrict__ glv, int first, int levels,
-                                                   int n3, int n1) {
+__device__ __forceinline__ int div_small(int e, int d, float inv) {     // e / d for 0 <= e < 2^20, inv = 1.f / d
+    int q = (int)((float)e * inv);
+    const int r = e - q * d;
+    return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
+}
+__device__ __forceinline__ float down_1x1(float v) {                    // pyrDown of a single pixel: every tap is the pixel
+    const float h = v * 6.f + (v + v) * 4.f + v + v;
+    return (h * 6.f + (h + h) * 4.f + h + h) * (1.f / 256);
+}
+__device__ __forceinline__ float up_1x1(float v) {                      // pyrUp of a single pixel to a single pixel
+    const float h = v * 8.f;
+    return (h + h * 6.f + h) * (1.f / 64);
+}
+
+__global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restrict__ gL, const float* __restrict__ gR,
+                                                           const float* __restrict__ gM, float* __restrict__ gB,
+                                                           const PyrLevel* __restrict__ glv, int first, int levels, int k1,
+                                                           int n3, int n1) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // the level table is read ~10 times per level by every thread: keep it in LDS (one coalesced copy) instead of
-    // chasing it through global memory inside the sequential chains
-    PyrLevel* lv = (PyrLevel*)lds;   // indexed by absolute level; entries first..levels are filled
+    PyrLevel* lv = (PyrLevel*)lds;   // indexed by absolute level; entries first..min(k1+1, levels) are filled
     float* sL = (float*)(lv + (levels + 1));     // n3 floats each, indexed by (off3 - base3)
     float* sR = sL + n3;
     float* sB = sR + n3;
     float* sM = sB + n3;             // n1 floats, indexed by (off1 - base1)
-    float* sMp = sM + n1;            // 3 x kTailMaxLevels private mask chains
-    const int tid = threadIdx.x, nth = blockDim.x;
-    for (int i = first + tid; i <= levels; i += nth) lv[i] = glv[i];
-    __syncthreads();
-    const size_t base3 = lv[first].off3, base1 = lv[first].off1;
-
+    float* sRes = sM + n1;           // 3 x kTailMaxLevels residuals of the single-pixel levels
+    const int tid = threadIdx.x, nth = kTailThreads;
+    const int wide_end = k1 < levels ? k1 : levels;        // levels [first, wide_end) are reduced block-wide
+    const int tab_end = wide_end + 1 < levels ? wide_end + 1 : levels;
+    for (int i = first + tid; i <= tab_end; i += nth) lv[i] = glv[i];
     {   // stage level `first` (produced by the previous pyrDown launch)
-        const PyrLevel f = lv[first];
+        const PyrLevel f = glv[first];
         const int c3 = f.w * f.h * 3, c1 = f.w * f.h;
         for (int e = tid; e < c3; e += nth) { sL[e] = gL[f.off3 + e]; sR[e] = gR[f.off3 + e]; }
         for (int e = tid; e < c1; e += nth) sM[e] = gM[f.off1 + e];
     }
     __syncthreads();
-
-    int k1 = levels;                 // first level that is a single pixel
-    for (int i = first; i <= levels; ++i)
-        if (lv[i].w == 1 && lv[i].h == 1) { k1 = i; break; }
-    const int wide_end = k1 < levels ? k1 : levels;        // levels [first, wide_end) are reduced block-wide
+    const size_t base3 = lv[first].off3, base1 = lv[first].off1;
 
     for (int i = first; i < wide_end; ++i) {
         const PyrLevel s = lv[i], d = lv[i + 1];
         const DownGeom g3 = make_down_geom(s.w, s.h, 3), g1 = make_down_geom(s.w, s.h, 1);
-        const int c3 = d.w * d.h * 3, c1 = d.w * d.h;
+        const int row3 = d.w * 3, c3 = row3 * d.h, c1 = d.w * d.h;
+        const float inv3 = 1.f / (float)row3, inv1 = 1.f / (float)d.w;
         const int so3 = (int)(s.off3 - base3), do3 = (int)(d.off3 - base3), so1 = (int)(s.off1 - base1), do1 = (int)(d.off1 - base1);
+        const bool big = s.w >= 3 && s.h >= 3;             // one reflection reaches every tap
         for (int e = tid; e < 2 * c3 + c1; e += nth) {
-            if (e < c3) { int y = e / (d.w * 3), xe = e - y * d.w * 3; sL[do3 + e] = pyrdown_elem<false>(sL + so3, g3, y, xe); }
-            else if (e < 2 * c3) { int q = e - c3; int y = q / (d.w * 3), xe = q - y * d.w * 3; sR[do3 + q] = pyrdown_elem<false>(sR + so3, g3, y, xe); }
-            else { int q = e - 2 * c3; int y = q / d.w, xe = q - y * d.w; sM[do1 + q] = pyrdown_elem<false>(sM + so1, g1, y, xe); }
+            if (e < 2 * c3) {
+                const bool right = e >= c3;
+                const int q = right ? e - c3 : e;
+                const int y = div_small(q, row3, inv3), xe = q - y * row3;
+                const float* src = (right ? sR : sL) + so3;
+                const float v = big ? pyrdown_elem_wide<false, 3>(src, g3, y, xe) : pyrdown_elem<false>(src, g3, y, xe);
+                (right ? sR : sL)[do3 + q] = v;
+            } else {
+                const int q = e - 2 * c3;
+                const int y = div_small(q, d.w, inv1), xe = q - y * d.w;
+                sM[do1 + q] = big ? pyrdown_elem_wide<false, 1>(sM + so1, g1, y, xe) : pyrdown_elem<false>(sM + so1, g1, y, xe);
+            }
         }
         __syncthreads();
     }
 
     if (k1 < levels) {
-        // single-pixel chain: lanes 0..2 = channel
+        const int nl = levels - k1;                        // single-pixel reductions; 1x1 levels are 3 (1) floats apart
+        const int o3 = (int)(lv[k1].off3 - base3), o1 = (int)(lv[k1].off1 - base1);
+        if (tid < 7) {
+            float* chain = tid < 3 ? sL + o3 + tid : tid < 6 ? sR + o3 + (tid - 3) : sM + o1;
+            const int step = tid < 6 ? 3 : 1;
+            float v = chain[0];
+            for (int j = 1; j <= nl; ++j) { v = down_1x1(v); chain[j * step] = v; }
+        }
+        __syncthreads();
+        for (int e = tid; e < nl * 3; e += nth) {          // residual of single-pixel level k1 + e/3, channel e%3
+            const int j = e / 3;
+            const float lapL = sL[o3 + e] - up_1x1(sL[o3 + e + 3]), lapR = sR[o3 + e] - up_1x1(sR[o3 + e + 3]);
+            sRes[e] = mix_lr(lapL, lapR, sM[o1 + j]);
+        }
+        __syncthreads();
         if (tid < 3) {
-            const int c = tid;
-            float* mp = sMp + c * kTailMaxLevels;
-            mp[k1] = sM[(int)(lv[k1].off1 - base1)];
-            const float s256 = 1.f / 256, s64 = 1.f / 64;
-            for (int i = k1; i < levels; ++i) {            // pyrDown 1x1 -> 1x1: every tap is the pixel itself
-                const int o = (int)(lv[i].off3 - base3) + c, n = (int)(lv[i + 1].off3 - base3) + c;
-                float v = sL[o], h = v * 6.f + (v + v) * 4.f + v + v;
-                sL[n] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
-                v = sR[o]; h = v * 6.f + (v + v) * 4.f + v + v;
-                sR[n] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
-                v = mp[i]; h = v * 6.f + (v + v) * 4.f + v + v;
-                mp[i + 1] = (h * 6.f + (h + h) * 4.f + h + h) * s256;
-            }
-            const int ol = (int)(lv[levels].off3 - base3) + c;
-            float cur = mix_lr(sL[ol], sR[ol], mp[levels]);
-            sB[ol] = cur;
-            for (int i = levels - 1; i >= k1; --i) {       // pyrUp 1x1 -> 1x1: row value = s*8, (r + r*6 + r)/64
-                const int o = (int)(lv[i].off3 - base3) + c, n = (int)(lv[i + 1].off3 - base3) + c;
-                float hl = sL[n] * 8.f, hr = sR[n] * 8.f, hb = cur * 8.f;
-                float upL = (hl + hl * 6.f + hl) * s64, upR = (hr + hr * 6.f + hr) * s64, upB = (hb + hb * 6.f + hb) * s64;
-                float res = mix_lr(sL[o] - upL, sR[o] - upR, mp[i]);
-                cur = upB + res;
-                sB[o] = cur;
+            const int top = o3 + nl * 3 + tid;
+            float cur = mix_lr(sL[top], sR[top], sM[o1 + nl]);
+            sB[top] = cur;
+            float res = sRes[(nl - 1) * 3 + tid];
+            for (int j = nl - 1; j >= 0; --j) {
+                const float nxt = sRes[(j > 0 ? j - 1 : 0) * 3 + tid];      // fetched while the chain below runs
+                cur = up_1x1(cur) + res;
+                sB[o3 + j * 3 + tid] = cur;
+                res = nxt;
             }
         }
     } else {
@@ -615,9 +596,13 @@ __global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL,
     for (int i = wide_end - 1; i >= first; --i) {
         const PyrLevel c = lv[i], n = lv[i + 1];
         const int co3 = (int)(c.off3 - base3), no3 = (int)(n.off3 - base3), co1 = (int)(c.off1 - base1);
-        for (int e = tid; e < c.w * c.h * 3; e += nth) {
-            int y = e / (c.w * 3), xe = e - y * c.w * 3;
-            sB[co3 + e] = collapse_elem<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe);
+        const int row3 = c.w * 3;
+        const float inv3 = 1.f / (float)row3;
+        const bool big = n.w >= 2 && n.h >= 2;
+        for (int e = tid; e < row3 * c.h; e += nth) {
+            const int y = div_small(e, row3, inv3), xe = e - y * row3;
+            sB[co3 + e] = big ? collapse_elem_wide<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe)
+                              : collapse_elem<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe);
         }
         __syncthreads();
     }
@@ -627,9 +612,9 @@ __global__ void __launch_bounds__(1024) k_pyr_tail(const float* __restrict__ gL,
     }
 }
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
-                     int n3, int n1, hipStream_t s) {
+                     int k1, int n3, int n1, hipStream_t s) {
     size_t lds = ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;
-    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(1024), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, n3, n1);
+    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(kTailThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,9 +44,9 @@ __device__ __forceinline__ void pyrdown_border_body(int block, const void* __res
     const int pix = i / 7, k = i - pix * 7;
     int x, y;
     if (!border_pixel(pix, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
-    if (k < 3)      dstL[((size_t)y * g3.dw + x) * 3 + k] = pyrdown_elem_wide<U8>(srcL, g3, y, x * 3 + k);
-    else if (k < 6) dstR[((size_t)y * g3.dw + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8>(srcR, g3, y, x * 3 + (k - 3));
-    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false>(srcM, g1, y, x);
+    if (k < 3)      dstL[((size_t)y * g3.dw + x) * 3 + k] = pyrdown_elem_wide<U8, 3>(srcL, g3, y, x * 3 + k);
+    else if (k < 6) dstR[((size_t)y * g3.dw + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8, 3>(srcR, g3, y, x * 3 + (k - 3));
+    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false, 1>(srcM, g1, y, x);
 }
 
 template <bool U8>

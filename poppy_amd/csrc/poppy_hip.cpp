@@ -60,7 +60,7 @@ struct poppy_hip_ctx {
     // blob layout: [tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32][raster work items 2*n i32]
     uint8_t* h_blob[kRing] = {};  uint8_t* d_blob[kRing] = {};
     size_t blob_bytes = 0;
-    int tail_n3 = 0, tail_n1 = 0;
+    int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
     hipEvent_t ring_done[kRing] = {}, uploaded[kRing] = {};
     hipStream_t copy_stream = nullptr;
     int ring_pos = 0;
@@ -161,7 +161,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 2);
-    const size_t bytes = (size_t)need * (6 * 4 + 18 * 4) + items * 8;
+    const size_t bytes = (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8;
     for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
         if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
         if (c->d_blob[i]) (void)hipFree(c->d_blob[i]);
@@ -192,6 +192,9 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     for (int i = 1; i <= L; ++i)
         if ((size_t)c->levels[i].w * c->levels[i].h <= 160) { c->first_tail = i; break; }   // everything below runs in ONE workgroup: keep it tiny
     c->tail_n3 = c->tail_n1 = 0;
+    c->tail_k1 = L;
+    for (int i = std::min(c->first_tail, L); i <= L; ++i)
+        if (c->levels[i].w == 1 && c->levels[i].h == 1) { c->tail_k1 = i; break; }
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
     if (((size_t)3 * c->tail_n3 + c->tail_n1 + 3 * 257) * 4 > 64 * 1024)
         return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
@@ -319,6 +322,8 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     return rc;
 }
 
+static_assert(kPlanRasterRows == kRasterChunkRows, "the plan's work list and k_raster must agree on the chunk height");
+
 static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
     const int T = c->plan.n_tris;
@@ -329,25 +334,22 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     HIPCHK(c, hipEventSynchronize(c->ring_done[slot]));          // the copy that last used this slot has drained
     int* h_tri = (int*)c->h_blob[slot];
     float* h_inv = (float*)(h_tri + (size_t)T * 6);
-    int* h_work = (int*)(h_inv + (size_t)T * 18);
-    int n_work = 0;
+    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 96*T: 8-byte aligned
+    int* h_work = (int*)(h_edges + T);
+    const int n_work = (int)(c->plan.work.size() / 2);
+    const size_t used = (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
+    if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     if (T) {
         memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
         memcpy(h_inv, c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
         memcpy(h_inv + (size_t)T * 9, c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
-        for (int t = 0; t < T; ++t) {              // raster work list: (triangle, chunk of kRasterChunkRows rows)
-            const int* v = &c->plan.tri_xy[(size_t)t * 6];
-            int ymin = std::min(v[1], std::min(v[3], v[5])), ymax = std::min(std::max(v[1], std::max(v[3], v[5])), H - 1);
-            int rows = ymax - ymin + 1;
-            int chunks = rows > 0 ? (rows + kRasterChunkRows - 1) / kRasterChunkRows : 1;
-            for (int k = 0; k < chunks; ++k) { h_work[2 * n_work] = t; h_work[2 * n_work + 1] = k; ++n_work; }
-        }
+        memcpy(h_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
+        memcpy(h_work, c->plan.work.data(), (size_t)n_work * 8);
     }
-    const size_t used = (size_t)T * (6 + 18) * 4 + (size_t)n_work * 8;
-    if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     const int* d_tri = (const int*)c->d_blob[slot];
     const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
-    const int* d_work = (const int*)(d_inv + (size_t)T * 18);
+    const RasterTri* d_edges = (const RasterTri*)(d_inv + (size_t)T * 18);
+    const int* d_work = (const int*)(d_edges + T);
     hipStream_t s = c->stream;
     Timer tm(c);
     tm.mark(nullptr);
@@ -357,7 +359,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     HIPCHK(c, hipMemsetAsync(c->triMap, 0, (size_t)W * H * 4, s));
     HIPCHK(c, hipStreamWaitEvent(s, c->uploaded[slot], 0));
     tm.mark("upload+clear");
-    launch_raster(d_tri, d_work, n_work, c->triMap, W, H, s);
+    launch_raster(d_tri, d_edges, d_work, n_work, c->triMap, W, H, s);
     tm.mark("raster");
     launch_warp(c->triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
     HIPCHK(c, hipEventRecord(c->ring_done[slot], s));            // last reader of this slot's device blob
@@ -372,7 +374,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         launch_pyrdown(sl, sr, c->pyrM + a.off1, i == 0, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrM + b.off1, a.w, a.h, s);
     }
     tm.mark("pyrdown");
-    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, c->tail_n3, c->tail_n1, s);
+    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
     tm.mark("pyr_tail");
     for (int i = ft - 1; i >= 0; --i) {
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];

@@ -133,9 +133,9 @@ __device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, c
 // chain of dependent branches and loads.
 __device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
 
-template <bool U8>
+template <bool U8, int CN>
 __device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGeom& g, int y, int xe) {
-    const int cn = g.cn;
+    constexpr int cn = CN;                                   // == g.cn; a constant keeps xe / cn off the division path
     const int px = xe / cn, c = xe - px * cn;
     const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
     int col[5];
