@@ -159,8 +159,12 @@ int poppy_plan_frame(int width, int height, const float* src_points1, const floa
                      double shape_ratio, int max_tris, int* n_tris, int* idx3, int* tri_xy,
                      float* M1, float* M2, float* inv1, float* inv2, float* morphed_pts);
 
-/* Per-kernel timing (HIP events recorded on the ctx stream around every kernel group while timing is on).
- * timing_summary drains the stream and returns, per kernel group, the summed duration and the number of
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
+ *   on = 0  off;
+ *   on = 1  around every kernel group of a frame (the frame is then issued launch by launch instead of through its
+ *           captured graph, so whole-frame throughput is a little lower while this is on);
+ *   on = 2  around the fused map+remap kernel (k_warp4) only; the rest of the frame runs as usual.
+ * timing_summary drains the streams and returns, per kernel group, the summed duration and the number of
  * launches since the last summary / set_timing call; returns the number of entries written.            */
 int poppy_hip_set_timing(poppy_hip_ctx* ctx, int on);
 int poppy_hip_timing_summary(poppy_hip_ctx* ctx, const char** names, float* total_ms, int* launches, int max);

@@ -236,7 +236,8 @@ class Context:
     def set_debug(self, on=True):
         lib().poppy_hip_set_debug(self.h, int(on))
 
-    def set_timing(self, on=True):
+    def set_timing(self, on=1):
+        """0 off, 1 every kernel group (frames issued launch by launch), 2 the map+remap kernel only."""
         lib().poppy_hip_set_timing(self.h, int(on))
 
     def fetch(self, name):

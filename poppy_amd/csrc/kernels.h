@@ -23,7 +23,7 @@ void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_
 
 // fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2
 void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
-                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s);
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // lbmask = clamp((1-mr) - m2*mr)  (double arithmetic, one rounding; src/algo.cpp:254-257)
 void launch_mask(const float* m2, float* mask, int n_px, double alpha, double beta, hipStream_t s);
@@ -52,8 +52,10 @@ void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, fl
                      int first, int levels, int k1, int n3, int n1, hipStream_t s);
 
 // unsharp_mask(lapBlend, 1, amount, 0.3) + convertTo(CV_8U, 255)  (src/util.cpp:113-148, src/algo.cpp:263-265)
+// d_amount (device, may be null): when set, the tile kernel reads the amount from there instead of the argument, so
+// that the launch can sit in a captured graph while the value changes per frame.
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, float threshold, hipStream_t s);
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s);
 
 // u8 cross-dissolve fallback (src/poppy.hpp:129)
 void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s);

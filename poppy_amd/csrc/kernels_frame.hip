@@ -10,6 +10,7 @@
 // Reference routines are cited per kernel (OCV = third/opencv-4.6.0/modules).
 #include "kernels.h"
 #include "pyramid_device.h"
+#include <hip/hip_ext.h>
 #include <climits>
 #include <cmath>
 
@@ -327,13 +328,15 @@ __global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4,
     tr1[o + 2] = (p1[2] >> 16) | (p1[3] << 8); tr2[o + 2] = (p2[2] >> 16) | (p2[3] << 8);
 }
 
+// t0 / t1 (optional): events attached to the dispatch itself, i.e. the kernel's own begin and end timestamps — what a
+// profiler's kernel trace reports — rather than markers queued around it.
 void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
-                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s) {
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if ((w & 3) == 0 && w >= 8 && h >= 2)
-        hipLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, (const int4*)triMap, inv1, inv2, c1, c2,
-                           (uint32_t*)tr1, (uint32_t*)tr2, w, h);
+        hipExtLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, t0, t1, 0, (const int4*)triMap, inv1, inv2,
+                              c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h);
     else
-        hipLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
+        hipExtLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, t0, t1, 0, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -706,7 +709,8 @@ constexpr int kURx = kUTx + 2;                          // row-pass / diff tile 
 constexpr int kUDy = kUTy + 2;
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                      int W, int H, float amount, double norm2_min) {
+                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min) {
+    const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
     __shared__ float S[kUSy * kUSx * 3];
     __shared__ float R[kUSy * kURx * 3];
     __shared__ float D[kUDy * kURx * 3];
@@ -773,7 +777,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
 }
 
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, float threshold, hipStream_t s) {
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s) {
     if (w > 1 && h > 1) {
         // norm(d) >= threshold with norm = correctly rounded sqrt of a double: equivalent to |d|^2 >= x*, where x* is the
         // smallest double whose square root rounds to >= threshold (found here with the host's IEEE sqrt).
@@ -784,7 +788,7 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
         dim3 grid((w + kUTx - 1) / kUTx, (h + kUTy - 1) / kUTy);
-        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, x);
+        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);

@@ -7,13 +7,15 @@
 // HBM layout for a W x H pair (P = W*H):
 //   c1, c2            u8x3   3P each     sources (c1 is replaced by the previous frame in chained mode)
 //   m2                f32    4P          1 - gray(gabor2), loop invariant (algo.cpp:250-252)
+// and per frame SLOT (kSlots of them, each with its own HIP stream, so that the parts of frame j+1 that do not
+// depend on frame j — id-map clear, raster, mask — or, in phase mode, whole frames run beside frame j's long tail
+// of small launch-latency-bound pyramid kernels):
 //   triMap            i32    4P          triangle id per pixel
 //   tr1, tr2          u8x3   3P each     warped sources (never widened to float in memory)
 //   pyrL, pyrR        f32x3  ~4P each    Gaussian levels 1..levels of the warped sources
 //   pyrM              f32    ~5.3P       mask levels 0..levels
 //   pyrB              f32x3  ~16P        blended levels; level 0 is lapBlend
-//   tmp, diff         f32x3  12P each    unsharp scratch
-//   frame[2]          u8x3   3P each     output ring (chained mode feeds one back as c1)
+//   out               u8x3   3P          the frame (chained mode feeds it to the next slot as c1)
 // No CPU fallback exists in this library: every entry point either runs the kernels or fails.
 #include "../../include/poppy_hip.h"
 #include "frame_plan.h"
@@ -34,6 +36,21 @@ using namespace poppy_hip;
 
 static std::string g_create_error;
 
+struct FrameSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;           // end of the frame last rendered here
+    hipEvent_t prepared = nullptr;       // id map and mask of the frame being rendered here are written
+    uint8_t *tr1 = nullptr, *tr2 = nullptr, *out = nullptr;
+    float *pyrL = nullptr, *pyrR = nullptr, *pyrM = nullptr, *pyrB = nullptr;
+    float *tmp = nullptr, *diff = nullptr;      // only for 1-pixel-wide / -high images (separate unsharp passes)
+    float* unsharpF = nullptr;                  // debug copy of the float unsharp result, allocated on demand
+    int32_t* triMap = nullptr;
+    uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
+    hipEvent_t uploaded = nullptr;                  // the device copy is complete
+    hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
+};
+constexpr size_t kBlobHeader = 64;
+
 struct poppy_hip_ctx {
     int device = 0;
     poppy_settings cfg;
@@ -43,32 +60,35 @@ struct poppy_hip_ctx {
     int W = 0, H = 0;
     bool pair_ready = false;
     // resident buffers
-    uint8_t *c1 = nullptr, *c2 = nullptr, *tr1 = nullptr, *tr2 = nullptr, *frame[2] = {nullptr, nullptr};
-    float *gabor2 = nullptr, *m2 = nullptr, *pyrL = nullptr, *pyrR = nullptr, *pyrM = nullptr, *pyrB = nullptr, *tmp = nullptr, *diff = nullptr;
-    float* unsharpF = nullptr;
-    int32_t* triMap = nullptr;
+    uint8_t *c1 = nullptr, *c2 = nullptr;
+    float *gabor2 = nullptr, *m2 = nullptr;
+    std::vector<FrameSlot> slots;        // per-frame working sets, used round-robin
+    hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
     const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
-    int frame_slot = 0, last_slot = -1;
+    hipEvent_t cur1_ready = nullptr;     // producer of cur1 when it is a slot's output, else null
+    hipStream_t cur1_stream = nullptr;   // ... and the stream that producer ran on
+    // Frames that feed on a previous frame all run on `stream`: a cross-stream event on the critical path costs more
+    // than the kernels it would overlap.  Frames that read the loaded image run entirely on their slot's stream
+    // (created on first use: every extra stream competes for the few hardware queues), so in phase mode several
+    // frames are in flight at once.
+    int next_slot = 0, last_slot = -1;
     std::vector<PyrLevel> levels;        // 0..pyramid_levels
     PyrLevel* d_levels = nullptr;
     int first_tail = 1;
     // points
     std::vector<P2f> pts1_0, pts1, pts2;
-    // per-frame plan upload ring (pinned host + device), so the host can plan ahead of the GPU
-    static const int kRing = 4;
+    // per-frame plan blobs (pinned host + device) live in the frame slots, so the host can plan ahead of the GPU
     int max_tris = 0;
-    // blob layout: [tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32][raster work items 2*n i32]
-    uint8_t* h_blob[kRing] = {};  uint8_t* d_blob[kRing] = {};
+    // blob layout: [header 64 B: f32 unsharp amount][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32][RasterTri T][work 2*n i32]
     size_t blob_bytes = 0;
     int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
-    hipEvent_t ring_done[kRing] = {}, uploaded[kRing] = {};
     hipStream_t copy_stream = nullptr;
-    int ring_pos = 0;
     FramePlan plan;
     OrbDetector orb;
     double initial_morph_dist = 0;
     // diagnostics
-    bool debug = false, timing = false;
+    bool debug = false;
+    int timing = 0;                      // 0 off, 1 every kernel group (direct launches), 2 the warp kernel only
     struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
     std::vector<Mark> marks; size_t marks_used = 0;
     // staging for host-image entry points
@@ -111,24 +131,34 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     if (settings) c->cfg = *settings; else poppy_settings_default(&c->cfg);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
-        (void)hipEventCreateWithFlags(&c->ring_done[i], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&c->uploaded[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->inputs_ready, hipEventDisableTiming);
+    int k = 4;                                             // frames in flight
+    if (const char* e = getenv("POPPY_HIP_SLOTS")) k = atoi(e);
+    c->slots.resize(std::max(2, std::min(k, 8)));
+    for (FrameSlot& f : c->slots) {
+        if (hipEventCreateWithFlags(&f.prepared, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f.uploaded, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "hipStreamCreate failed"; delete c; return nullptr;
+        }
     }
     return c;
 }
 
 static void free_pair(poppy_hip_ctx* c) {
-    void* bufs[] = {c->c1, c->c2, c->tr1, c->tr2, c->frame[0], c->frame[1], c->gabor2, c->m2, c->pyrL, c->pyrR, c->pyrM, c->pyrB,
-                    c->tmp, c->diff, c->unsharpF, c->triMap, c->d_levels};
+    void* bufs[] = {c->c1, c->c2, c->gabor2, c->m2, c->d_levels};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    c->c1 = c->c2 = c->tr1 = c->tr2 = c->frame[0] = c->frame[1] = nullptr;
-    c->gabor2 = c->m2 = c->pyrL = c->pyrR = c->pyrM = c->pyrB = c->tmp = c->diff = c->unsharpF = nullptr;
-    c->triMap = nullptr; c->d_levels = nullptr;
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
-        if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
-        if (c->d_blob[i]) (void)hipFree(c->d_blob[i]);
-        c->h_blob[i] = nullptr; c->d_blob[i] = nullptr;
+    c->c1 = c->c2 = nullptr; c->gabor2 = c->m2 = nullptr; c->d_levels = nullptr;
+    for (FrameSlot& f : c->slots) {
+        void* fb[] = {f.tr1, f.tr2, f.out, f.pyrL, f.pyrR, f.pyrM, f.pyrB, f.tmp, f.diff, f.unsharpF, f.triMap};
+        for (void* b : fb) if (b) (void)hipFree(b);
+        f.tr1 = f.tr2 = f.out = nullptr; f.pyrL = f.pyrR = f.pyrM = f.pyrB = f.tmp = f.diff = f.unsharpF = nullptr; f.triMap = nullptr;
+    }
+    for (FrameSlot& f : c->slots) {
+        if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }
+        if (f.h_blob) (void)hipHostFree(f.h_blob);
+        if (f.d_blob) (void)hipFree(f.d_blob);
+        f.h_blob = nullptr; f.d_blob = nullptr;
     }
     c->max_tris = 0; c->W = c->H = 0; c->pair_ready = false;
 }
@@ -137,10 +167,17 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (FrameSlot& f : c->slots) if (f.stream) (void)hipStreamSynchronize(f.stream);
     free_pair(c);
+    for (FrameSlot& f : c->slots) {
+        if (f.done) (void)hipEventDestroy(f.done);
+        if (f.prepared) (void)hipEventDestroy(f.prepared);
+        if (f.uploaded) (void)hipEventDestroy(f.uploaded);
+        if (f.stream) (void)hipStreamDestroy(f.stream);
+    }
+    if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) { (void)hipEventDestroy(c->ring_done[i]); (void)hipEventDestroy(c->uploaded[i]); }
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
@@ -148,8 +185,9 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
 }
 
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
-int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on != 0; c->marks_used = 0; return POPPY_OK; }
+int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+// `stream` waits on every frame as it is queued (submit_frame), so draining it drains the slots' streams too
 int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return POPPY_OK; }
 
 }  // extern "C"
@@ -159,14 +197,17 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     int need = 2 * n_points + 16;            // a planar triangulation of n points has < 2n triangles
     if (need <= c->max_tris) return POPPY_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 2);
-    const size_t bytes = (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8;
-    for (int i = 0; i < poppy_hip_ctx::kRing; ++i) {
-        if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
-        if (c->d_blob[i]) (void)hipFree(c->d_blob[i]);
-        HIPCHK(c, hipHostMalloc((void**)&c->h_blob[i], bytes));
-        HIPCHK(c, hipMalloc((void**)&c->d_blob[i], bytes));
+    const size_t bytes = kBlobHeader + (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8;
+    for (FrameSlot& f : c->slots) {
+        if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob
+        if (f.h_blob) (void)hipHostFree(f.h_blob);
+        if (f.d_blob) (void)hipFree(f.d_blob);
+        f.h_blob = f.d_blob = nullptr;
+        HIPCHK(c, hipHostMalloc((void**)&f.h_blob, bytes));
+        HIPCHK(c, hipMalloc((void**)&f.d_blob, bytes));
     }
     c->blob_bytes = bytes;
     c->max_tris = need;
@@ -176,6 +217,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
 static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     if (c->W == W && c->H == H && c->c1) return POPPY_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (FrameSlot& f : c->slots) if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
     free_pair(c);
     if (c->cfg.pyramid_levels < 1 || c->cfg.pyramid_levels > 256) return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels must be in [1,256]");
     const size_t P = (size_t)W * H;
@@ -200,14 +242,15 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
     // +16: k_warp4 fetches footprints with 8-byte loads (6 bytes used), the last one may run 2 bytes past the image
     HIPCHK(c, hipMalloc((void**)&c->c1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3 + 16));
-    HIPCHK(c, hipMalloc((void**)&c->tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->tr2, P * 3 + 16));
-    HIPCHK(c, hipMalloc((void**)&c->frame[0], P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->frame[1], P * 3 + 16));
     HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12)); HIPCHK(c, hipMalloc((void**)&c->m2, P * 4));
-    HIPCHK(c, hipMalloc((void**)&c->triMap, P * 4));
-    HIPCHK(c, hipMalloc((void**)&c->pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&c->pyrR, off3 * 4));
-    HIPCHK(c, hipMalloc((void**)&c->pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&c->pyrM, off1 * 4));
-    HIPCHK(c, hipMalloc((void**)&c->tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&c->diff, P * 12));
-    HIPCHK(c, hipMalloc((void**)&c->unsharpF, P * 12));
+    for (FrameSlot& f : c->slots) {
+        HIPCHK(c, hipMalloc((void**)&f.tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P * 3 + 16));
+        HIPCHK(c, hipMalloc((void**)&f.out, P * 3 + 16));
+        HIPCHK(c, hipMalloc((void**)&f.triMap, P * 4));
+        HIPCHK(c, hipMalloc((void**)&f.pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrR, off3 * 4));
+        HIPCHK(c, hipMalloc((void**)&f.pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrM, off1 * 4));
+        if (W < 2 || H < 2) { HIPCHK(c, hipMalloc((void**)&f.tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&f.diff, P * 12)); }
+    }
     HIPCHK(c, hipMalloc((void**)&c->d_levels, sizeof(PyrLevel) * (L + 1)));
     HIPCHK(c, hipMemcpy(c->d_levels, c->levels.data(), sizeof(PyrLevel) * (L + 1), hipMemcpyHostToDevice));
     c->W = W; c->H = H;
@@ -225,7 +268,8 @@ static int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n)
 static int finish_pair_load(poppy_hip_ctx* c) {
     launch_gray_inv(c->gabor2, c->m2, c->W * c->H, c->stream);
     HIPCHK(c, hipGetLastError());
-    c->cur1 = c->c1; c->frame_slot = 0; c->last_slot = -1; c->pair_ready = true;
+    HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
+    c->cur1 = c->c1; c->cur1_ready = nullptr; c->last_slot = -1; c->pair_ready = true;
     return POPPY_OK;
 }
 
@@ -242,13 +286,16 @@ static int stage_host(poppy_hip_ctx* c, size_t bytes) {
 // in poppy_hip_timing_summary() after the caller has drained the stream.
 struct Timer {
     poppy_hip_ctx* c;
-    explicit Timer(poppy_hip_ctx* c_) : c(c_) {}
-    void mark(const char* name) {
-        if (!c->timing) return;
+    Timer(poppy_hip_ctx* c_, hipStream_t s_) : c(c_), s(s_) {}
+    hipStream_t s = nullptr;
+    hipEvent_t take(const char* name) {           // next event of the pool, labelled, not recorded
         if (c->marks_used >= c->marks.size()) { hipEvent_t e; (void)hipEventCreate(&e); c->marks.push_back({nullptr, e}); }
         c->marks[c->marks_used].name = name;
-        (void)hipEventRecord(c->marks[c->marks_used].ev, c->stream);
-        ++c->marks_used;
+        return c->marks[c->marks_used++].ev;
+    }
+    void mark(const char* name) {
+        if (!c->timing) return;
+        (void)hipEventRecord(take(name), s);
     }
 };
 
@@ -311,7 +358,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         if (chain) c->pts1 = src1[j];
         rc = submit_frame(c, mask[j], chain);
         if (rc == POPPY_OK && write) {
-            hipError_t e = hipMemcpyAsync(c->h_stage, c->frame[c->last_slot], row * H, hipMemcpyDeviceToHost, c->stream);
+            hipError_t e = hipMemcpyAsync(c->h_stage, c->slots[c->last_slot].out, row * H, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; break; }
             write(user, c->h_stage, W, H, row);
@@ -324,20 +371,63 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
 
 static_assert(kPlanRasterRows == kRasterChunkRows, "the plan's work list and k_raster must agree on the chunk height");
 
-static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
+// pyrdown .. unsharp of one slot.  Every argument is fixed for the life of the pair (the per-frame unsharp amount is
+// read from the slot's plan blob), which is what lets the whole sequence be captured into one graph launch.
+static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* tm, float amount, bool debug) {
     const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
+    const int ft = c->first_tail < L ? c->first_tail : L;
+    for (int i = 0; i < ft; ++i) {
+        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
+        const void* sl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
+        const void* sr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
+        launch_pyrdown(sl, sr, f.pyrM + a.off1, i == 0, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1, a.w, a.h, s);
+    }
+    if (tm) tm->mark("pyrdown");
+    launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
+    if (tm) tm->mark("pyr_tail");
+    for (int i = ft - 1; i >= 0; --i) {
+        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
+        const void* gl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
+        const void* gr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
+        launch_collapse(gl, gr, i == 0, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrB + b.off3, f.pyrB + a.off3,
+                        a.w, a.h, b.w, b.h, s);
+    }
+    if (tm) tm->mark("collapse");
+    launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s);
+    if (tm) tm->mark("unsharp");
+}
+
+static int capture_body(poppy_hip_ctx* c, FrameSlot& f) {
+    hipGraph_t g = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_body(c, f, c->stream, nullptr, 0.f, false);
+    HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+    hipError_t e = hipGraphInstantiate(&f.body, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { f.body = nullptr; c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
+static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
+    const int W = c->W, H = c->H;
     const int T = c->plan.n_tris;
     if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
 
-    const int slot = c->ring_pos;
-    c->ring_pos = (c->ring_pos + 1) % poppy_hip_ctx::kRing;
-    HIPCHK(c, hipEventSynchronize(c->ring_done[slot]));          // the copy that last used this slot has drained
-    int* h_tri = (int*)c->h_blob[slot];
+    // frame slot: the next one in the ring that does not hold the image this frame reads as corrected1
+    int fi = c->next_slot;
+    if (c->slots[fi].out == c->cur1) fi = (fi + 1) % (int)c->slots.size();
+    c->next_slot = (fi + 1) % (int)c->slots.size();
+    FrameSlot& f = c->slots[fi];
+
+    HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
+    const double amount = std::sin(mask * M_PI);
+    *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
+    int* h_tri = (int*)(f.h_blob + kBlobHeader);
     float* h_inv = (float*)(h_tri + (size_t)T * 6);
-    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 96*T: 8-byte aligned
+    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 64 + 96*T: 8-byte aligned
     int* h_work = (int*)(h_edges + T);
     const int n_work = (int)(c->plan.work.size() / 2);
-    const size_t used = (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
+    const size_t used = kBlobHeader + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
     if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     if (T) {
         memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
@@ -346,53 +436,65 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         memcpy(h_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
         memcpy(h_work, c->plan.work.data(), (size_t)n_work * 8);
     }
-    const int* d_tri = (const int*)c->d_blob[slot];
+    const int* d_tri = (const int*)(f.d_blob + kBlobHeader);
     const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
     const RasterTri* d_edges = (const RasterTri*)(d_inv + (size_t)T * 18);
     const int* d_work = (const int*)(d_edges + T);
-    hipStream_t s = c->stream;
-    Timer tm(c);
-    tm.mark(nullptr);
-    // the plan blob goes up on its own stream so it overlaps the previous frame's kernels
-    if (used) HIPCHK(c, hipMemcpyAsync(c->d_blob[slot], c->h_blob[slot], used, hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->uploaded[slot], c->copy_stream));
-    HIPCHK(c, hipMemsetAsync(c->triMap, 0, (size_t)W * H * 4, s));
-    HIPCHK(c, hipStreamWaitEvent(s, c->uploaded[slot], 0));
-    tm.mark("upload+clear");
-    launch_raster(d_tri, d_edges, d_work, n_work, c->triMap, W, H, s);
-    tm.mark("raster");
-    launch_warp(c->triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, c->tr1, c->tr2, W, H, s);
-    HIPCHK(c, hipEventRecord(c->ring_done[slot], s));            // last reader of this slot's device blob
-    tm.mark("warp");
-    launch_mask(c->m2, c->pyrM, W * H, 1.0 - mask, -mask, s);
-    tm.mark("mask");
-    const int ft = c->first_tail < L ? c->first_tail : L;
-    for (int i = 0; i < ft; ++i) {
-        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
-        const void* sl = i == 0 ? (const void*)c->tr1 : (const void*)(c->pyrL + a.off3);
-        const void* sr = i == 0 ? (const void*)c->tr2 : (const void*)(c->pyrR + a.off3);
-        launch_pyrdown(sl, sr, c->pyrM + a.off1, i == 0, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrM + b.off1, a.w, a.h, s);
+
+    // POPPY_HIP_HEADMODE=1 moves a chained frame's clear/raster/mask to the slot's stream so that it overlaps the previous
+    // frame.  Measured on MI355X (profiles/r01_e_streams.md) the cross-queue hand-over costs 12-20 us, more than the
+    // ~45 us head saves once queue sharing is counted, so chained frames stay on one stream by default.
+    static const int head_mode = getenv("POPPY_HIP_HEADMODE") ? atoi(getenv("POPPY_HIP_HEADMODE")) : 0;
+    static const bool no_graph = getenv("POPPY_HIP_NOGRAPH") != nullptr;
+    const bool chained = chain || c->cur1_ready;
+    if (!f.stream && (!chained || head_mode != 0)) HIPCHK(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    hipStream_t s = chained ? c->stream : f.stream;                           // warp .. unsharp
+    hipStream_t head = (chained && head_mode == 0) ? s : f.stream;            // clear, raster, mask
+    if (c->debug && !f.unsharpF) HIPCHK(c, hipMalloc((void**)&f.unsharpF, (size_t)W * H * 12));
+    const bool all_marks = c->timing == 1;
+    const bool use_graph = !no_graph && !c->debug && !all_marks && W > 1 && H > 1;
+    if (use_graph && !f.body) { int rc = capture_body(c, f); if (rc) return rc; }
+
+    Timer th(c, head), tm(c, s);
+    // the plan goes up on its own stream, after the frame that last used this slot has let go of the device copy
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, f.done, 0));
+    HIPCHK(c, hipMemcpyAsync(f.d_blob, f.h_blob, used, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(f.uploaded, c->copy_stream));
+    if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, c->inputs_ready, 0));
+    if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, f.done, 0));    // the frame that last used this slot's buffers
+    if (all_marks) th.mark(nullptr);
+    // -- independent of the previous frame: runs while that frame is still in its pyramid --------------------
+    HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
+    HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
+    if (all_marks) th.mark("upload+clear");
+    launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, head);
+    if (all_marks) th.mark("raster");
+    launch_mask(c->m2, f.pyrM, W * H, 1.0 - mask, -mask, head);
+    if (all_marks) th.mark("mask");
+    if (s != head) {
+        HIPCHK(c, hipEventRecord(f.prepared, head));
+        HIPCHK(c, hipStreamWaitEvent(s, f.prepared, 0));            // (implies inputs_ready)
     }
-    tm.mark("pyrdown");
-    launch_pyr_tail(c->pyrL, c->pyrR, c->pyrM, c->pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
-    tm.mark("pyr_tail");
-    for (int i = ft - 1; i >= 0; --i) {
-        const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
-        const void* gl = i == 0 ? (const void*)c->tr1 : (const void*)(c->pyrL + a.off3);
-        const void* gr = i == 0 ? (const void*)c->tr2 : (const void*)(c->pyrR + a.off3);
-        launch_collapse(gl, gr, i == 0, c->pyrM + a.off1, c->pyrL + b.off3, c->pyrR + b.off3, c->pyrB + b.off3, c->pyrB + a.off3,
-                        a.w, a.h, b.w, b.h, s);
+    // -- chained mode: corrected1 is the previous frame (src/poppy.hpp:217) -------------------------------------
+    if (c->cur1_ready && c->cur1_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->cur1_ready, 0));
+    if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
+        hipEvent_t t0 = tm.take(nullptr), t1 = tm.take("warp");
+        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, s, t0, t1);
+    } else {
+        tm.mark(nullptr);
+        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, s);
+        tm.mark("warp");
     }
-    tm.mark("collapse");
-    const double amount = std::sin(mask * M_PI);
-    uint8_t* out = c->frame[c->frame_slot];
-    launch_unsharp(c->pyrB, c->tmp, c->diff, out, c->debug ? c->unsharpF : nullptr, W, H, (float)(1.0 - amount), (float)0.3, s);
-    tm.mark("unsharp");
+    if (use_graph) HIPCHK(c, hipGraphLaunch(f.body, s));
+    else enqueue_body(c, f, s, all_marks ? &tm : nullptr, (float)(1.0 - amount), c->debug);
     HIPCHK(c, hipGetLastError());
-    c->last_slot = c->frame_slot;
-    c->frame_slot ^= 1;
+    HIPCHK(c, hipEventRecord(f.done, s));
+    if (s != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, f.done, 0));   // anything queued on `stream` later sees this frame
+    c->last_slot = fi;
     if (chain) {                                   // src/poppy.hpp:217-218
-        c->cur1 = out;
+        c->cur1 = f.out;
+        c->cur1_ready = f.done;
+        c->cur1_stream = s;
         c->pts1 = c->plan.morphed;
     }
     return POPPY_OK;
@@ -439,7 +541,7 @@ int poppy_hip_pair_load_device(poppy_hip_ctx* c, const void* d1, const void* d2,
 int poppy_hip_pair_reset(poppy_hip_ctx* c) {
     if (!c) return POPPY_E_ARG;
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
-    c->cur1 = c->c1; c->pts1 = c->pts1_0; c->last_slot = -1;
+    c->cur1 = c->c1; c->cur1_ready = nullptr; c->pts1 = c->pts1_0; c->last_slot = -1;
     return POPPY_OK;
 }
 
@@ -449,13 +551,13 @@ int poppy_hip_render(poppy_hip_ctx* c, double shape, double mask, int chain, uin
     int rc = render_frame(c, shape, mask, chain != 0); if (rc) return rc;
     if (dst) {
         if (dst_stride < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "dst_stride too small");
-        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->frame[c->last_slot], (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->slots[c->last_slot].out, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return POPPY_OK;
 }
 
-const void* poppy_hip_frame_device(poppy_hip_ctx* c) { return (c && c->last_slot >= 0) ? c->frame[c->last_slot] : nullptr; }
+const void* poppy_hip_frame_device(poppy_hip_ctx* c) { return (c && c->last_slot >= 0) ? c->slots[c->last_slot].out : nullptr; }
 
 int poppy_hip_morph_images(poppy_hip_ctx* c, const uint8_t* c1, size_t s1, const uint8_t* c2, size_t s2, const float* gabor2, int W, int H,
                            const float* p1, const float* p2, int n, double shape, double mask, uint8_t* dst, size_t dst_stride, float* morphed) {
@@ -502,9 +604,9 @@ int poppy_hip_dissolve(poppy_hip_ctx* c, const uint8_t* img1, size_t s1, const u
     rc = upload_image(c, c->c1, img1, s1, W, H); if (rc) return rc;
     rc = upload_image(c, c->c2, img2, s2, W, H); if (rc) return rc;
     // Mat blend = img2*phase + img1*(1.0-phase)  ->  addWeighted(img2, phase, img1, 1-phase, 0)
-    launch_dissolve(c->c2, c->c1, c->frame[0], (size_t)W * H * 3, (float)phase, (float)(1.0 - phase), c->stream);
+    launch_dissolve(c->c2, c->c1, c->slots[0].out, (size_t)W * H * 3, (float)phase, (float)(1.0 - phase), c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->frame[0], (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->slots[0].out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pair_ready = false;
     return POPPY_OK;
@@ -516,12 +618,17 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     const size_t P = (size_t)c->W * c->H;
     const void* src = nullptr; size_t need = 0;
     std::string n(name);
-    if (n == "triMap") { src = c->triMap; need = P * 4; }
-    else if (n == "trImg1") { src = c->tr1; need = P * 3; }
-    else if (n == "trImg2") { src = c->tr2; need = P * 3; }
-    else if (n == "lbmask") { src = c->pyrM; need = P * 4; }
-    else if (n == "lapBlend") { src = c->pyrB; need = P * 12; }
-    else if (n == "unsharp") { if (!c->debug) return fail(c, POPPY_E_STATE, "enable debug first"); src = c->unsharpF; need = P * 12; }
+    if (n != "m2" && c->last_slot < 0) return fail(c, POPPY_E_STATE, "no frame rendered yet");
+    const FrameSlot& f = c->slots[c->last_slot < 0 ? 0 : c->last_slot];          // intermediates of the last frame
+    if (n == "triMap") { src = f.triMap; need = P * 4; }
+    else if (n == "trImg1") { src = f.tr1; need = P * 3; }
+    else if (n == "trImg2") { src = f.tr2; need = P * 3; }
+    else if (n == "lbmask") { src = f.pyrM; need = P * 4; }
+    else if (n == "lapBlend") { src = f.pyrB; need = P * 12; }
+    else if (n == "unsharp") {
+        if (!c->debug || !f.unsharpF) return fail(c, POPPY_E_STATE, "enable debug before rendering the frame");
+        src = f.unsharpF; need = P * 12;
+    }
     else if (n == "m2") { src = c->m2; need = P * 4; }
     else return fail(c, POPPY_E_ARG, "unknown debug buffer");
     if (bytes != need) return fail(c, POPPY_E_ARG, "debug buffer size mismatch");
