@@ -12,7 +12,8 @@ Frames stay in HBM (inputs are resident before the timed region, outputs are not
 rate is printed as an extra key, never as `value`.
 
 Output: ONE JSON line on rank 0 (see the driver contract), extended with
-  roofline     : the fused map+remap kernel (k_warp), algorithmic bytes = 16 B/px (faithful path),
+  roofline     : the fused map+remap kernel (k_warp4): 16 B/px (faithful path) + 8 B/px for the lbmask it
+                 computes on the way (m2 in, mask out); the 4 B/px id-map clear it also writes is not counted,
                  average launch duration measured live with HIP events on the library's stream;
   kernels      : the same for every kernel group of the frame (one extra untimed step; "warp" is the timed region's);
   cpu_baseline : oracle/ (CPU restatement, "port") timed on this box's host cores on a bounded sample.
@@ -35,10 +36,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel P
 ALGO_BYTES_PER_PX = {
-    "upload+clear": 4.0,                       # memset of the id map
+    "upload+clear": 0.0,                       # wait for the plan upload (the id map is cleared by the warp kernel)
     "raster": 4.0,                             # every pixel's id written once
-    "warp": 16.0,                              # triMap 4 + c1 3 + c2 3 in, trImg1 3 + trImg2 3 out
-    "mask": 8.0,                               # m2 in, lbmask out
+    "warp": 24.0,                              # triMap 4 + c1 3 + c2 3 in, trImg1 3 + trImg2 3 out; lbmask rider: m2 4 in, mask 4 out
     "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3),      # level 0: u8 L,R + mask in; quarter-size f32 L,R,M out; geometric tail
     "pyr_tail": 0.0,
     "collapse": (6 + 4 + 12) + (36 / 4) * (4 / 3) + 12 * (1 / 3),   # G_i (u8 at level 0), mask, lower level L,R,B in; B_i out
@@ -207,10 +207,10 @@ def main():
                                    f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
                                    "pyramid_levels 64, per-frame operator on a resident pair",
                        "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_warp (fused create_map + remap of both sources)",
+            "roofline": {"bound": "hbm", "kernel": "k_warp4 (fused create_map + remap of both sources + lbmask)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algo_bytes_per_launch": 16 * P, "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n},
+                         "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n},
             "kernels": kernels,
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
             "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,

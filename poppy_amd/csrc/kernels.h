@@ -21,12 +21,21 @@ constexpr int kRasterChunkRows = 16;
 // `edges` = one RasterTri (frame_plan.h) per triangle: the fill-edge segments decided by the host plan
 void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s);
 
-// fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2
-void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
-                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-
-// lbmask = clamp((1-mr) - m2*mr)  (double arithmetic, one rounding; src/algo.cpp:254-257)
-void launch_mask(const float* m2, float* mask, int n_px, double alpha, double beta, hipStream_t s);
+// fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2.
+// The kernel is the only reader of the id map and visits every pixel once, so it carries two per-pixel riders that
+// would otherwise be launches of their own:
+//   clear_ids  zero the id map behind the read, which is the state the next frame's raster needs;
+//   m2 / mask  lbmask = clamp((1-mr) - m2*mr) in double with one rounding (src/algo.cpp:254-257); skipped when m2 is null.
+struct WarpExtras {
+    int clear_ids = 0;
+    const float* m2 = nullptr;
+    float* mask = nullptr;
+    double alpha = 0, beta = 0;
+};
+// t0 / t1 (optional) are attached to the dispatch: the kernel's own begin / end timestamps.
+void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, const WarpExtras& ex, hipStream_t s,
+                 hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // one Gaussian-pyramid reduction step for L, R (3 channels) and the mask (1 channel) in one launch.
 // level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
@@ -48,6 +57,8 @@ bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float*
 // mix and the collapse back up to level `first`; writes B_first.
 // n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS);
 // k1 = first level in [first, levels] that is a single pixel, or `levels` when there is none.
+size_t pyr_tail_lds_bytes(int levels, int n3, int n1);      // dynamic LDS the tail kernel needs
+bool prepare_pyr_tail(size_t lds_bytes);                    // raises the kernel's LDS limit; call outside stream capture
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels,
                      int first, int levels, int k1, int n3, int n1, hipStream_t s);
 

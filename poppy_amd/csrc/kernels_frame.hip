@@ -33,19 +33,13 @@ void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // lbmask                                         arithm.simd.hpp:1160-1216,1808 (double, one rounding)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_mask(const float* __restrict__ m2, float* __restrict__ mask, int n, double alpha, double beta) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double t = (double)m2[i] * beta + 0.0;
+__device__ __forceinline__ float mask_value(float m2, double alpha, double beta) {
+    double t = (double)m2 * beta + 0.0;
     float v = (float)(1.0 * alpha + t);
     if (v < 0.f) v = 0.f;
     if (v > 1.f) v = 1.f;
-    mask[i] = v;
+    return v;
 }
-void launch_mask(const float* m2, float* mask, int n_px, double alpha, double beta, hipStream_t s) {
-    hipLaunchKernelGGL(k_mask, dim3((n_px + 255) / 256), dim3(256), 0, s, m2, mask, n_px, alpha, beta);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Triangle-id raster.  One wave per triangle.
 //   outline: Line(LINE_8) = clipLine + 8-connected Bresenham, x increasing   drawing.cpp:80-297
@@ -212,14 +206,16 @@ __device__ __forceinline__ void map_point(const float* __restrict__ h, int x, in
     my = __fdiv_rn(h[3] * fx + h[4] * fy + h[5], z);
 }
 
-__global__ void __launch_bounds__(256) k_warp(const int32_t* __restrict__ triMap, const float* __restrict__ inv1, const float* __restrict__ inv2,
+__global__ void __launch_bounds__(256) k_warp(int32_t* __restrict__ triMap, const float* __restrict__ inv1, const float* __restrict__ inv2,
                                               const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                              uint8_t* __restrict__ tr1, uint8_t* __restrict__ tr2, int W, int H) {
+                                              uint8_t* __restrict__ tr1, uint8_t* __restrict__ tr2, int W, int H, WarpExtras ex) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
     if (x >= W) return;
     size_t p = (size_t)y * W + x;
     int idx = triMap[p] - 1;
+    if (ex.clear_ids) triMap[p] = 0;
+    if (ex.m2) ex.mask[p] = mask_value(ex.m2[p], ex.alpha, ex.beta);
     float mx1 = (float)x, my1 = (float)y, mx2 = mx1, my2 = my1;
     if (idx >= 0) {
         map_point(inv1 + (size_t)idx * 9, x, y, mx1, my1);
@@ -269,14 +265,21 @@ __device__ __forceinline__ uint32_t blend_tap(const Tap& t, uint64_t a, uint64_t
 // so that a thread has its 16 footprint loads in flight at once; the rare footprints that touch the image border
 // are recomputed by the byte-wise path afterwards.  Block = 64 x 4: the four waves of a block work on four
 // consecutive rows, which share source rows in the CU's L1.
-__global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4, const float* __restrict__ inv1, const float* __restrict__ inv2,
+__global__ void __launch_bounds__(256) k_warp4(int4* __restrict__ triMap4, const float* __restrict__ inv1, const float* __restrict__ inv2,
                                                const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                               uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H) {
+                                               uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, WarpExtras ex) {
     const int W4 = W >> 2;
     const int q = blockIdx.x * 64 + threadIdx.x;               // index of the 4-pixel group inside the row
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (q >= W4 || y >= H) return;
-    const int4 ids = triMap4[(size_t)y * W4 + q];
+    const size_t g = (size_t)y * W4 + q;
+    const int4 ids = triMap4[g];
+    if (ex.clear_ids) triMap4[g] = make_int4(0, 0, 0, 0);      // this kernel is the map's only reader: leave it cleared for the next raster
+    if (ex.m2) {                                               // lbmask of the same four pixels
+        const float4 m = ((const float4*)ex.m2)[g];
+        ((float4*)ex.mask)[g] = make_float4(mask_value(m.x, ex.alpha, ex.beta), mask_value(m.y, ex.alpha, ex.beta),
+                                            mask_value(m.z, ex.alpha, ex.beta), mask_value(m.w, ex.alpha, ex.beta));
+    }
     const int id[4] = {ids.x - 1, ids.y - 1, ids.z - 1, ids.w - 1};
     float mx[2][4], my[2][4];
 #pragma unroll
@@ -330,13 +333,13 @@ __global__ void __launch_bounds__(256) k_warp4(const int4* __restrict__ triMap4,
 
 // t0 / t1 (optional): events attached to the dispatch itself, i.e. the kernel's own begin and end timestamps — what a
 // profiler's kernel trace reports — rather than markers queued around it.
-void launch_warp(const int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
-                 uint8_t* tr1, uint8_t* tr2, int w, int h, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
+                 uint8_t* tr1, uint8_t* tr2, int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if ((w & 3) == 0 && w >= 8 && h >= 2)
-        hipExtLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, t0, t1, 0, (const int4*)triMap, inv1, inv2,
-                              c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h);
+        hipExtLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, t0, t1, 0, (int4*)triMap, inv1, inv2,
+                              c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, ex);
     else
-        hipExtLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, t0, t1, 0, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h);
+        hipExtLaunchKernelGGL(k_warp, dim3((w + 255) / 256, h), dim3(256), 0, s, t0, t1, 0, triMap, inv1, inv2, c1, c2, tr1, tr2, w, h, ex);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,14 +493,15 @@ void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
 
 // --- all small levels in one workgroup, staged in LDS ---------------------------------------------
 // Levels first..levels live in LDS (a few hundred pixels in total).  The kernel is a single workgroup, so its time is
-// the number of instructions each SIMD has to issue: four waves only, branch-free per-element forms for every level
-// of at least 3x3, and no level-table lookups inside the sequential part.
+// a chain of short dependent steps: branch-free per-element forms for every level of at least 3x3 and no
+// level-table lookups inside the sequential part.  (Measured: ~1.8 us per tiny level whatever the thread count; 1024
+// threads pay off once the first level has a few hundred pixels.)
 // Once a level is 1x1 (level k1, found by the host) every deeper level is 1x1 too — ~50 of them at 1080p with
 // pyramid_levels = 64.  Going down, the seven scalar chains (L and R per channel, mask) run on seven lanes.  Going
 // up, everything that does not depend on the running value (the Laplacian residual of each level) is computed for all
 // levels at once, one lane per (level, channel); what remains sequential is  cur = pyrUp(cur) + residual[i].
 constexpr int kTailMaxLevels = 257;
-constexpr int kTailThreads = 256;
+constexpr int kTailThreads = 1024;
 
 __device__ __forceinline__ int div_small(int e, int d, float inv) {     // e / d for 0 <= e < 2^20, inv = 1.f / d
     int q = (int)((float)e * inv);
@@ -524,7 +528,7 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
     float* sB = sR + n3;
     float* sM = sB + n3;             // n1 floats, indexed by (off1 - base1)
     float* sRes = sM + n1;           // 3 x kTailMaxLevels residuals of the single-pixel levels
-    const int tid = threadIdx.x, nth = kTailThreads;
+    const int tid = threadIdx.x, nth = blockDim.x;
     const int wide_end = k1 < levels ? k1 : levels;        // levels [first, wide_end) are reduced block-wide
     const int tab_end = wide_end + 1 < levels ? wide_end + 1 : levels;
     for (int i = first + tid; i <= tab_end; i += nth) lv[i] = glv[i];
@@ -614,9 +618,15 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
         for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
     }
 }
+bool prepare_pyr_tail(size_t lds_bytes) {     // once per pair geometry, outside any stream capture
+    return hipFuncSetAttribute((const void*)k_pyr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+}
+size_t pyr_tail_lds_bytes(int levels, int n3, int n1) {
+    return ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;
+}
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
                      int k1, int n3, int n1, hipStream_t s) {
-    size_t lds = ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;
+    const size_t lds = pyr_tail_lds_bytes(levels, n3, n1);
     hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(kTailThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
 }
 

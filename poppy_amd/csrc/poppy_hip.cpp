@@ -45,6 +45,7 @@ struct FrameSlot {
     float *tmp = nullptr, *diff = nullptr;      // only for 1-pixel-wide / -high images (separate unsharp passes)
     float* unsharpF = nullptr;                  // debug copy of the float unsharp result, allocated on demand
     int32_t* triMap = nullptr;
+    bool map_clean = false;                     // triMap is all zero (the warp kernel clears it behind itself)
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
@@ -231,14 +232,16 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
     c->first_tail = L;
+    static const size_t tail_px = getenv("POPPY_TAIL_PX") ? (size_t)atoi(getenv("POPPY_TAIL_PX")) : 600;
     for (int i = 1; i <= L; ++i)
-        if ((size_t)c->levels[i].w * c->levels[i].h <= 160) { c->first_tail = i; break; }   // everything below runs in ONE workgroup: keep it tiny
+        if ((size_t)c->levels[i].w * c->levels[i].h <= tail_px) { c->first_tail = i; break; }   // everything below runs in ONE workgroup: keep it small
     c->tail_n3 = c->tail_n1 = 0;
     c->tail_k1 = L;
     for (int i = std::min(c->first_tail, L); i <= L; ++i)
         if (c->levels[i].w == 1 && c->levels[i].h == 1) { c->tail_k1 = i; break; }
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
-    if (((size_t)3 * c->tail_n3 + c->tail_n1 + 3 * 257) * 4 > 64 * 1024)
+    const size_t tail_lds = pyr_tail_lds_bytes(L, c->tail_n3, c->tail_n1);
+    if (tail_lds > 160 * 1024 || !prepare_pyr_tail(tail_lds))
         return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
     // +16: k_warp4 fetches footprints with 8-byte loads (6 bytes used), the last one may run 2 bytes past the image
     HIPCHK(c, hipMalloc((void**)&c->c1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3 + 16));
@@ -247,6 +250,7 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         HIPCHK(c, hipMalloc((void**)&f.tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.out, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.triMap, P * 4));
+        f.map_clean = false;
         HIPCHK(c, hipMalloc((void**)&f.pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrR, off3 * 4));
         HIPCHK(c, hipMalloc((void**)&f.pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrM, off1 * 4));
         if (W < 2 || H < 2) { HIPCHK(c, hipMalloc((void**)&f.tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&f.diff, P * 12)); }
@@ -463,26 +467,30 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, c->inputs_ready, 0));
     if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, f.done, 0));    // the frame that last used this slot's buffers
     if (all_marks) th.mark(nullptr);
-    // -- independent of the previous frame: runs while that frame is still in its pyramid --------------------
-    HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
+    // -- independent of the previous frame ---------------------------------------------------------------------
+    // the id map is left cleared by the warp kernel of the frame before (its only reader); only a slot's first frame
+    // and frames after a debug frame (which keeps the map for poppy_hip_debug_fetch) need the memset
+    if (!f.map_clean) HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
     HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
     if (all_marks) th.mark("upload+clear");
     launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, head);
     if (all_marks) th.mark("raster");
-    launch_mask(c->m2, f.pyrM, W * H, 1.0 - mask, -mask, head);
-    if (all_marks) th.mark("mask");
     if (s != head) {
         HIPCHK(c, hipEventRecord(f.prepared, head));
         HIPCHK(c, hipStreamWaitEvent(s, f.prepared, 0));            // (implies inputs_ready)
     }
     // -- chained mode: corrected1 is the previous frame (src/poppy.hpp:217) -------------------------------------
     if (c->cur1_ready && c->cur1_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->cur1_ready, 0));
+    WarpExtras ex;
+    ex.clear_ids = c->debug ? 0 : 1;
+    ex.m2 = c->m2; ex.mask = f.pyrM; ex.alpha = 1.0 - mask; ex.beta = -mask;       // lbmask rides along (level 0 of pyrM)
+    f.map_clean = ex.clear_ids != 0;
     if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
         hipEvent_t t0 = tm.take(nullptr), t1 = tm.take("warp");
-        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, s, t0, t1);
+        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
     } else {
         tm.mark(nullptr);
-        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, s);
+        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
     if (use_graph) HIPCHK(c, hipGraphLaunch(f.body, s));
