@@ -90,7 +90,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from poppy_amd import capi
+    from poppy_amd import capi, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,19 +111,9 @@ def main():
         raise SystemExit("chained mode is sequential by construction (SURVEY.md F5); use --mode phase for N>1")
 
     # ---- inputs: generated on rank 0, broadcast once over RCCL, resident in HBM before timing --------------
-    if rank == 0:
-        a, b, g, p1, p2 = synth_inputs()
-        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
-        tg = torch.from_numpy(g).to(dev)
-        tp = torch.from_numpy(np.stack([p1, p2])).to(dev)
-    else:
-        ta = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        tb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        tg = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-        tp = torch.empty((2, NPTS + 4, 2), dtype=torch.float32, device=dev)
+    ta, tb, tg, tp = sharding.pair_tensors(torch, dev, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
     if world > 1:
-        for t in (ta, tb, tg, tp):
-            dist.broadcast(t, src=0)
+        sharding.broadcast_pair(dist, (ta, tb, tg, tp), src=0)
     torch.cuda.synchronize()
     pts = tp.cpu().numpy()
     p1r, p2r = np.ascontiguousarray(pts[0]), np.ascontiguousarray(pts[1])
@@ -135,7 +125,7 @@ def main():
     if mode == "chain":
         shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
     else:
-        shapes = np.array([(rank * FRAMES + j) / float(total_frames) for j in range(FRAMES)])
+        shapes = sharding.phase_schedule(rank, world, FRAMES)
 
     def step():
         ctx.reset()
@@ -166,10 +156,19 @@ def main():
     summary = ctx.timing_summary()
     ctx.set_timing(0)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    dt_max = sharding.max_over_ranks(torch, dist, dt, dev) if world > 1 else dt
+
+    # N = 1 only: the same 60 frames as independent phase-mode frames t_j = j/60 (what every rank of an N > 1 run
+    # does), so the driver's N-sweep has a like-for-like single-GPU point beside the chained headline
+    phase_fps = None
+    if world == 1 and mode == "chain":
+        ph = sharding.phase_schedule(0, 1, FRAMES)
+        ctx.reset(); ctx.render_many(ph, chain=False); ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.reset(); ctx.render_many(ph, chain=False)
+        ctx.sync()
+        phase_fps = args.steps * FRAMES / (time.perf_counter() - t1)
 
     # PCIe-inclusive rate (frames copied back to pinned host memory), rank 0, short run, not `value`
     pcie_fps = None
@@ -214,6 +213,7 @@ def main():
             "kernels": kernels,
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
             "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
+            "phase_mode_fps": round(phase_fps, 1) if phase_fps else None,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

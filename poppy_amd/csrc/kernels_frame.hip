@@ -707,82 +707,157 @@ __global__ void __launch_bounds__(256) k_median_apply(const float* __restrict__ 
     out[p + 2] = sat_u8(cv_round_x86(v2 * 255.f + 0.f));
 }
 
+// Median of nine as three-input min / max / median instructions: sort the three columns, then
+// med3(max of the minima, median of the medians, min of the maxima).  The reference's exchange network
+// (median_blur.simd.hpp:692-713) returns the same number: the 5th smallest of nine finite values is unique.
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ float median9_cols(float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7, float p8) {
+    const float lo = max3f(min3f(p0, p3, p6), min3f(p1, p4, p7), min3f(p2, p5, p8));
+    const float mi = med3f(med3f(p0, p3, p6), med3f(p1, p4, p7), med3f(p2, p5, p8));
+    const float hi = min3f(max3f(p0, p3, p6), max3f(p1, p4, p7), max3f(p2, p5, p8));
+    return med3f(lo, mi, hi);
+}
+
 // --- fused, LDS-tiled form -------------------------------------------------------------------------
 // One workgroup produces a kUTx x kUTy pixel tile of the final 8-bit frame: the source tile with a halo of 5
 // (4 for the 9-tap Gaussian + 1 for the 3x3 median) is staged in LDS once with reflect-101 addressing, the row
 // pass, the column pass + difference and the median/threshold/apply run out of LDS.  HBM traffic drops from
 // 87 B/px (three kernels through two f32 scratch images) to ~26 B/px read + 3 B/px written.  Every value is the
 // same expression tree as in the three-kernel form above (kept for 1-pixel-wide images).
+//
+// All three LDS arrays are indexed [row][u] with ONE element coordinate u = 1 + (x - (tx0 - 5)) * 3 + channel, so a
+// Gaussian tap is "u + 3k" and a column neighbour "row + k".  The leading pad element makes the staged row start on
+// a 16-byte boundary of the source image (for W % 4 == 0), so interior tiles are staged with 16-byte loads; every
+// later phase is register-blocked over 6 / 8 / 6 neighbouring elements so that one wide LDS read feeds several
+// outputs (LDS read instructions per tile: ~16k instead of ~60k).
 constexpr int kUTx = 32, kUTy = 16;
-constexpr int kUSx = kUTx + 10, kUSy = kUTy + 10;      // staged source tile
-constexpr int kURx = kUTx + 2;                          // row-pass / diff tile width (halo 1 for the median)
-constexpr int kUDy = kUTy + 2;
+constexpr int kUSy = kUTy + 10;                         // staged rows
+constexpr int kUDy = kUTy + 2;                          // difference rows (halo 1 for the median)
+constexpr int kUSs = 132;                               // S row stride in floats: 1 pad + 42 px * 3 + slack, multiple of 4
+constexpr int kURs = 128;                               // R / D row stride
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Col3 { float lo, mi, hi; };
+__device__ __forceinline__ Col3 sort3(float a, float b, float c) { return Col3{min3f(a, b, c), med3f(a, b, c), max3f(a, b, c)}; }
+__device__ __forceinline__ float median_of_cols(const Col3& a, const Col3& b, const Col3& c) {
+    return med3f(max3f(a.lo, b.lo, c.lo), med3f(a.mi, b.mi, c.mi), min3f(a.hi, b.hi, c.hi));
+}
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
                                                       int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min) {
     const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
-    __shared__ float S[kUSy * kUSx * 3];
-    __shared__ float R[kUSy * kURx * 3];
-    __shared__ float D[kUDy * kURx * 3];
+    __shared__ __attribute__((aligned(16))) float S[kUSy * kUSs];
+    __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
+    __shared__ __attribute__((aligned(16))) float D[kUDy * kURs];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * kUTx, ty0 = blockIdx.y * kUTy;
-    // 1. stage: S(r, c) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + c))
-    for (int i = tid; i < kUSy * kUSx; i += 256) {
-        const int r = i / kUSx, c = i - r * kUSx;
-        const int yy = reflect101(ty0 - 5 + r, H), xx = reflect101(tx0 - 5 + c, W);
-        const float* p = src + ((size_t)yy * W + xx) * 3;
-        S[i * 3] = p[0]; S[i * 3 + 1] = p[1]; S[i * 3 + 2] = p[2];
-    }
-    __syncthreads();
-    // 2. row pass for tile columns -1 .. kUTx (R column j <-> S column j + 4)
-    for (int i = tid; i < kUSy * kURx * 3; i += 256) {
-        const int r = i / (kURx * 3), e = i - r * (kURx * 3);
-        const float* s = S + (r * kUSx) * 3 + e;             // S column j, channel: taps at columns j .. j+8
-        float acc = s[0] * c_gauss9[0];
-#pragma unroll
-        for (int k = 1; k < 9; ++k) acc = s[k * 3] * c_gauss9[k] + acc;
-        R[i] = acc;
-    }
-    __syncthreads();
-    // 3. column pass + difference for tile rows -1 .. kUTy (D row q <-> R row q + 4, S row q + 4, S column j + 4)
-    for (int i = tid; i < kUDy * kURx * 3; i += 256) {
-        const int q = i / (kURx * 3), e = i - q * (kURx * 3);
-        const float* rr = R + ((q + 4) * kURx) * 3 + e;
-        float acc = c_gauss9[4] * rr[0] + 0.f;
-#pragma unroll
-        for (int k = 1; k <= 4; ++k) acc = c_gauss9[4 + k] * (rr[k * kURx * 3] + rr[-k * kURx * 3]) + acc;
-        D[i] = S[((q + 4) * kUSx + 4) * 3 + e] - acc;
-    }
-    __syncthreads();
-    // 4. median of the difference (replicated image edges), threshold, apply, convert
-    for (int i = tid; i < kUTx * kUTy; i += 256) {
-        const int ly = i / kUTx, lx = i - ly * kUTx;
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= W || y >= H) continue;
-        const int xm = (x > 0 ? x - 1 : x) - tx0 + 1, xc = lx + 1, xp = (x < W - 1 ? x + 1 : x) - tx0 + 1;   // D columns
-        const int ym = (y > 0 ? y - 1 : y) - ty0 + 1, yc = ly + 1, yp = (y < H - 1 ? y + 1 : y) - ty0 + 1;   // D rows
-        float d[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float p0 = D[(ym * kURx + xm) * 3 + c], p1 = D[(ym * kURx + xc) * 3 + c], p2 = D[(ym * kURx + xp) * 3 + c];
-            float p3 = D[(yc * kURx + xm) * 3 + c], p4 = D[(yc * kURx + xc) * 3 + c], p5 = D[(yc * kURx + xp) * 3 + c];
-            float p6 = D[(yp * kURx + xm) * 3 + c], p7 = D[(yp * kURx + xc) * 3 + c], p8 = D[(yp * kURx + xp) * 3 + c];
-            mnmx(p1, p2); mnmx(p4, p5); mnmx(p7, p8); mnmx(p0, p1);
-            mnmx(p3, p4); mnmx(p6, p7); mnmx(p1, p2); mnmx(p4, p5);
-            mnmx(p7, p8); mnmx(p0, p3); mnmx(p5, p8); mnmx(p4, p7);
-            mnmx(p3, p6); mnmx(p1, p4); mnmx(p2, p5); mnmx(p4, p7);
-            mnmx(p4, p2); mnmx(p6, p4); mnmx(p4, p2);
-            d[c] = p4;
+    // 1. stage: S(r, u(col, c)) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + col))
+    const bool interior = (W & 3) == 0 && tx0 >= 8 && tx0 + 38 <= W && ty0 >= 5 && ty0 + 21 <= H;
+    if (interior) {
+        const float* base = src + ((size_t)(ty0 - 5) * W + (tx0 - 5)) * 3 - 1;      // 16-byte aligned: W % 4 == 0, tx0 % 32 == 0
+        for (int i = tid; i < kUSy * 32; i += 256) {
+            const int r = i >> 5, v = i & 31;
+            *(f4*)(S + r * kUSs + 4 * v) = *(const f4*)(base + (size_t)r * W * 3 + 4 * v);
         }
-        const double nrm2 = (double)d[0] * (double)d[0] + (double)d[1] * (double)d[1] + (double)d[2] * (double)d[2];
-        const float* sv = S + ((ly + 5) * kUSx + (lx + 5)) * 3;
-        float v0 = sv[0], v1 = sv[1], v2 = sv[2];
-        if (nrm2 >= norm2_min) { v0 = v0 + amount * d[0]; v1 = v1 + amount * d[1]; v2 = v2 + amount * d[2]; }
-        const size_t p = ((size_t)y * W + x) * 3;
-        if (outF) { outF[p] = v0; outF[p + 1] = v1; outF[p + 2] = v2; }
-        out[p] = sat_u8(cv_round_x86(v0 * 255.f + 0.f));
-        out[p + 1] = sat_u8(cv_round_x86(v1 * 255.f + 0.f));
-        out[p + 2] = sat_u8(cv_round_x86(v2 * 255.f + 0.f));
+    } else {
+        for (int i = tid; i < kUSy * (kUTx + 10); i += 256) {
+            const int r = i / (kUTx + 10), c = i - r * (kUTx + 10);
+            const int yy = reflect101(ty0 - 5 + r, H), xx = reflect101(tx0 - 5 + c, W);
+            const float* p = src + ((size_t)yy * W + xx) * 3;
+            float* d = S + r * kUSs + 1 + c * 3;
+            d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+        }
+    }
+    __syncthreads();
+    // 2. row pass.  R(r, u) = sum_k S(r, u - 12 + 3k) * g[k] for u in [13, 115); a thread takes 6 neighbouring u.
+    for (int i = tid; i < kUSy * 18; i += 256) {
+        const int r = i / 18, m = i - r * 18;
+        const f2* sp = (const f2*)(S + r * kUSs + 6 * m);          // S(r, u0 - 12 ..), u0 = 12 + 6m
+        f2 v[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) v[k] = sp[k];
+        const float* f = (const float*)v;                            // f[o + 3k] = S(r, u0 + o - 12 + 3k)
+        f2 acc[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            acc[o] = f2{f[2 * o], f[2 * o + 1]} * c_gauss9[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) acc[o] = f2{f[2 * o + 3 * k], f[2 * o + 1 + 3 * k]} * c_gauss9[k] + acc[o];
+        }
+        f2* rp = (f2*)(R + r * kURs + 12 + 6 * m);
+        rp[0] = acc[0]; rp[1] = acc[1]; rp[2] = acc[2];
+    }
+    __syncthreads();
+    // 3. column pass + difference.  D(q, u) for q in [0, 18) <-> image row ty0 - 1 + q <-> S / R row q + 4.
+    //    A thread takes 4 neighbouring u and 2 neighbouring rows: 10 R rows feed 8 outputs.
+    for (int i = tid; i < 26 * 9; i += 256) {
+        const int qi = i / 26, t = i - qi * 26;
+        const int u0 = 12 + 4 * t, q0 = 2 * qi;
+        f4 rr[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) rr[k] = *(const f4*)(R + (q0 + k) * kURs + u0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f4 acc = c_gauss9[4] * rr[4 + j] + 0.f;
+#pragma unroll
+            for (int k = 1; k <= 4; ++k) acc = c_gauss9[4 + k] * (rr[4 + j + k] + rr[4 + j - k]) + acc;
+            *(f4*)(D + (q0 + j) * kURs + u0) = *(const f4*)(S + (q0 + j + 4) * kUSs + u0) - acc;
+        }
+    }
+    __syncthreads();
+    // 4. median of the difference (replicated image edges), threshold, apply, convert.  A thread takes 2 neighbouring
+    //    pixels of a row: 4 sorted columns per channel serve both medians.
+    {
+        const int ly = tid >> 4, pi = tid & 15;
+        const int x0 = tx0 + 2 * pi, y = ty0 + ly;
+        if (x0 < W && y < H) {
+            const bool has1 = x0 + 1 < W;
+            const int qm = y > 0 ? ly : ly + 1, qc = ly + 1, qp = y < H - 1 ? ly + 2 : ly + 1;     // D rows
+            f2 a[7], b[7], c[7];
+            const f2 *ap = (const f2*)(D + qm * kURs + 12 + 6 * pi), *bp = (const f2*)(D + qc * kURs + 12 + 6 * pi),
+                     *cp = (const f2*)(D + qp * kURs + 12 + 6 * pi);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { a[k] = ap[k]; b[k] = bp[k]; c[k] = cp[k]; }
+            const float *fa = (const float*)a, *fb = (const float*)b, *fc = (const float*)c;    // index 1 + 3*col + ch, col 0..3 <-> x0-1 .. x0+2
+            const f2* sp = (const f2*)(S + (ly + 5) * kUSs + 16 + 6 * pi);
+            const f2 s01 = sp[0], s23 = sp[1], s45 = sp[2];
+            const float sv[6] = {s01.x, s01.y, s23.x, s23.y, s45.x, s45.y};
+            const bool left_edge = x0 == 0, right_edge = x0 + 1 >= W - 1;
+            float d0[3], d1[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                Col3 cB = sort3(fa[4 + ch], fb[4 + ch], fc[4 + ch]);
+                Col3 cC = sort3(fa[7 + ch], fb[7 + ch], fc[7 + ch]);
+                Col3 cA = sort3(fa[1 + ch], fb[1 + ch], fc[1 + ch]);
+                Col3 cD = sort3(fa[10 + ch], fb[10 + ch], fc[10 + ch]);
+                if (left_edge) cA = cB;
+                if (right_edge) cD = cC;
+                if (!has1) cC = cB;                                  // x0 is the last column: its right neighbour is itself
+                d0[ch] = median_of_cols(cA, cB, cC);
+                d1[ch] = median_of_cols(cB, cC, cD);
+            }
+            float v[6] = {sv[0], sv[1], sv[2], sv[3], sv[4], sv[5]};
+            const double n0 = (double)d0[0] * (double)d0[0] + (double)d0[1] * (double)d0[1] + (double)d0[2] * (double)d0[2];
+            const double n1 = (double)d1[0] * (double)d1[0] + (double)d1[1] * (double)d1[1] + (double)d1[2] * (double)d1[2];
+            if (n0 >= norm2_min) { v[0] = v[0] + amount * d0[0]; v[1] = v[1] + amount * d0[1]; v[2] = v[2] + amount * d0[2]; }
+            if (n1 >= norm2_min) { v[3] = v[3] + amount * d1[0]; v[4] = v[4] + amount * d1[1]; v[5] = v[5] + amount * d1[2]; }
+            const size_t p = ((size_t)y * W + x0) * 3;
+            uint32_t o[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = sat_u8(cv_round_x86(v[k] * 255.f + 0.f));
+            const int nv = has1 ? 6 : 3;
+            if (outF)
+                for (int k = 0; k < nv; ++k) outF[p + k] = v[k];
+            if (has1 && !(p & 1)) {                                 // the usual case (even W): three aligned 16-bit stores
+                uint16_t* o16 = (uint16_t*)(out + p);
+                o16[0] = (uint16_t)(o[0] | (o[1] << 8)); o16[1] = (uint16_t)(o[2] | (o[3] << 8)); o16[2] = (uint16_t)(o[4] | (o[5] << 8));
+            } else {
+                for (int k = 0; k < nv; ++k) out[p + k] = (uint8_t)o[k];
+            }
+        }
     }
 }
 
