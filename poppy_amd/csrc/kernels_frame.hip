@@ -98,12 +98,21 @@ __device__ void outline_segment(int32_t* map, int W, int H, int ax, int ay, int 
     int major = steep ? dy : dx, minor = steep ? dx : dy;
     // err_0 = major - 2*minor; step j adds -2*minor and, when err_j < 0, +2*major and a minor step.
     // minor offset after k steps: m_k = max(0, ceil((2*minor*k - major) / (2*major)))  (major > 0)
+    // after clipping |coordinates| < 2^15, so 2*minor*k < 2^31: 32-bit arithmetic, and the quotient (< 2^15) comes from
+    // a float reciprocal with one correction step instead of an integer division
     const int count = major + 1;
+    const int den = 2 * major;
+    const float inv = den > 0 ? 1.f / (float)den : 0.f;
     for (int k = lane; k < count; k += 64) {
         int m = 0;
         if (major > 0) {
-            long long num = 2LL * minor * k - major;
-            m = num > 0 ? (int)((num + 2LL * major - 1) / (2LL * major)) : 0;
+            const int num = 2 * minor * k - major;
+            if (num > 0) {
+                const int a = num + den - 1;                      // ceil(num / den) = floor(a / den)
+                m = (int)((float)a * inv);
+                const int r = a - m * den;
+                m += (r >= den) - (r < 0);
+            }
         }
         int x, y;
         if (!steep) { x = x0 + k; y = y0 + sMinor * m; }
@@ -753,7 +762,10 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
     __shared__ __attribute__((aligned(16))) float D[kUDy * kURs];
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * kUTx, ty0 = blockIdx.y * kUTy;
+    const int tiles_x = (W + kUTx - 1) / kUTx;
+    const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_y = blk / tiles_x, tile_x = blk - tile_y * tiles_x;
+    const int tx0 = tile_x * kUTx, ty0 = tile_y * kUTy;
     // 1. stage: S(r, u(col, c)) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + col))
     const bool interior = (W & 3) == 0 && tx0 >= 8 && tx0 + 38 <= W && ty0 >= 5 && ty0 + 21 <= H;
     if (interior) {
@@ -872,7 +884,7 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (x > 0 && std::sqrt(std::nextafter(x, 0.0)) >= t) x = std::nextafter(x, 0.0);
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
-        dim3 grid((w + kUTx - 1) / kUTx, (h + kUTy - 1) / kUTy);
+        dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
         hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
         return;
     }

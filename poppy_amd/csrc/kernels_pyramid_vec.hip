@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ 
                                                        float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
                                                        DownGeom g3, DownGeom g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1) {
     const int nbi = gx * gy;
-    int blk = blockIdx.x;
+    int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {                 // border blocks come first: their load chains are the longest
         blk -= nborder;
         const int which = blk / nbi; blk -= which * nbi;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__
                                                         const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
                                                         float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
                                                         int x0, int x1, int y0, int y1) {
-    int blk = blockIdx.x;
+    int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {
         blk -= nborder;
         const int by = blk / gx, bx = blk - by * gx;

@@ -9,6 +9,16 @@
 
 namespace poppy_hip {
 
+// Workgroups are handed to the 8 XCDs round-robin (hardware block b runs on XCD b % 8) and each XCD has its own L2.
+// Kernels whose neighbouring tiles share halo rows / columns renumber their blocks with this bijection of [0, n) so
+// that the blocks of one XCD form one contiguous run of tiles: the halo is then an L2 hit instead of a second trip
+// to the memory side.
+__device__ __forceinline__ int xcd_swizzle(int b, int n) {
+    const int per = n >> 3, rem = n & 7;
+    const int x = b & 7, s = b >> 3;
+    return x * per + (x < rem ? x : rem) + s;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     if ((unsigned)p < (unsigned)len) return p;
     if (len == 1) return 0;

@@ -1,2 +1,1 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python tools/_exp2.py
