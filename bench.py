@@ -193,6 +193,14 @@ def main():
                              "algo_MB": round(ab / 1e6, 3), "GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 1) if per_launch_ms > 0 else None}
         wk = kernels.get("warp", {})
         achieved = wk.get("GBps") or 0.0
+        traffic, traffic_src = None, None            # PMC counters need their own rocprofv3 passes: quoted from profiles/
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_g_final_pmc.json"))).get(f"{W}x{H}", {}).get("k_warp4")
+            if pm:
+                traffic = pm["fetch_bytes"] + pm["write_bytes"]
+                traffic_src = "profiles/r01_g_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H) == (1920, 1080) else f"morph frames/sec at {W}x{H}; Mpix/s warped",
             "value": round(fps, 2), "unit": "frames/s",
@@ -208,7 +216,7 @@ def main():
                        "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_warp4 (fused create_map + remap of both sources + lbmask)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n},
             "kernels": kernels,
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
