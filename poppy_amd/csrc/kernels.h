@@ -57,6 +57,20 @@ bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float*
 // mix and the collapse back up to level `first`; writes B_first.
 // n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS);
 // k1 = first level in [first, levels] that is a single pixel, or `levels` when there is none.
+// Two levels per launch for levels that are launch-latency bound (kernels_pyramid_fused.hip): the workgroup that owns a
+// tile of the second level computes the part of the intermediate level it needs into LDS itself.
+constexpr size_t kFuseMaxPixels = 150000;          // first level of the pair: 480 x 270 and below
+bool pyrdown2_eligible(int sw, int sh);
+// A (sw x sh) -> B -> C for L, R (3 channels) and the mask (1 channel); B and C are both written.
+void launch_pyrdown2(const float* aL, const float* aR, const float* aM, float* bL, float* bR, float* bM,
+                     float* cL, float* cR, float* cM, int sw, int sh, hipStream_t s);
+bool collapse2_eligible(int w, int h, int w1, int h1, int w2, int h2);
+// blended level k (w x h) from blended level k+2: g* = Gaussian level k, m* = level k+1, n* = level k+2 (nB blended).
+// The blended level k+1 only exists in LDS.
+void launch_collapse2(const float* gL, const float* gR, const float* gM, const float* mL, const float* mR, const float* mM,
+                      const float* nL, const float* nR, const float* nB, float* outB,
+                      int w, int h, int w1, int h1, int w2, int h2, hipStream_t s);
+
 size_t pyr_tail_lds_bytes(int levels, int n3, int n1);      // dynamic LDS the tail kernel needs
 bool prepare_pyr_tail(size_t lds_bytes);                    // raises the kernel's LDS limit; call outside stream capture
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels,

@@ -380,21 +380,41 @@ static_assert(kPlanRasterRows == kRasterChunkRows, "the plan's work list and k_r
 static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* tm, float amount, bool debug) {
     const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
     const int ft = c->first_tail < L ? c->first_tail : L;
-    for (int i = 0; i < ft; ++i) {
+    static const bool fuse = getenv("POPPY_HIP_NOFUSE") == nullptr;
+    for (int i = 0; i < ft;) {
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
+        if (fuse && i >= 1 && i + 2 <= ft && pyrdown2_eligible(a.w, a.h)) {           // two small levels in one launch
+            const PyrLevel& d = c->levels[i + 2];
+            launch_pyrdown2(f.pyrL + a.off3, f.pyrR + a.off3, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1,
+                            f.pyrL + d.off3, f.pyrR + d.off3, f.pyrM + d.off1, a.w, a.h, s);
+            i += 2;
+            continue;
+        }
         const void* sl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
         const void* sr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
         launch_pyrdown(sl, sr, f.pyrM + a.off1, i == 0, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1, a.w, a.h, s);
+        ++i;
     }
     if (tm) tm->mark("pyrdown");
     launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
     if (tm) tm->mark("pyr_tail");
-    for (int i = ft - 1; i >= 0; --i) {
+    for (int j = ft; j > 0;) {                     // blended level j is known; produce level j-2 or j-1
+        if (fuse && j - 2 >= 1) {
+            const PyrLevel &a = c->levels[j - 2], &m = c->levels[j - 1], &n = c->levels[j];
+            if (collapse2_eligible(a.w, a.h, m.w, m.h, n.w, n.h)) {
+                launch_collapse2(f.pyrL + a.off3, f.pyrR + a.off3, f.pyrM + a.off1, f.pyrL + m.off3, f.pyrR + m.off3, f.pyrM + m.off1,
+                                 f.pyrL + n.off3, f.pyrR + n.off3, f.pyrB + n.off3, f.pyrB + a.off3, a.w, a.h, m.w, m.h, n.w, n.h, s);
+                j -= 2;
+                continue;
+            }
+        }
+        const int i = j - 1;
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
         const void* gl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
         const void* gr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
         launch_collapse(gl, gr, i == 0, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrB + b.off3, f.pyrB + a.off3,
                         a.w, a.h, b.w, b.h, s);
+        --j;
     }
     if (tm) tm->mark("collapse");
     launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s);
