@@ -21,6 +21,9 @@ constexpr int kRasterChunkRows = 16;
 // `edges` = one RasterTri (frame_plan.h) per triangle: the fill-edge segments decided by the host plan
 void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s);
 
+// copies `bytes` (rounded up to 16) from pinned, device-mapped host memory to device memory with a kernel
+void launch_upload(const void* host_mapped, void* dst, size_t bytes, hipStream_t s);
+
 // fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2.
 // The kernel is the only reader of the id map and visits every pixel once, so it carries two per-pixel riders that
 // would otherwise be launches of their own:

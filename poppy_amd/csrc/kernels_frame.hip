@@ -895,6 +895,20 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plan upload.  The per-frame plan (~200 KB) sits in pinned, device-mapped host memory; this kernel pulls it over
+// PCIe into the slot's device copy.  A kernel instead of hipMemcpyAsync because of what the call costs the
+// submitting host thread: 60-100 us per frame for the API call against ~5 us for a launch (profiles/r01_e_streams.md).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+void launch_upload(const void* host_mapped, void* dst, size_t bytes, hipStream_t s) {
+    const int n16 = (int)((bytes + 15) / 16);
+    if (n16 > 0) hipLaunchKernelGGL(k_upload, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)host_mapped, (uint4*)dst, n16);
+}
+
+// ------------------------------------------------------------------------------------------------
 // u8 addWeighted fallback: dst = sat(round(a*wa + b*wb))          arithm.simd.hpp:131-135,1705-1755
 // ------------------------------------------------------------------------------------------------
 __global__ void k_dissolve(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ dst, size_t n, float wa, float wb) {

@@ -47,6 +47,7 @@ struct FrameSlot {
     int32_t* triMap = nullptr;
     bool map_clean = false;                     // triMap is all zero (the warp kernel clears it behind itself)
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
+    void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
 };
@@ -201,13 +202,14 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 2);
-    const size_t bytes = kBlobHeader + (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8;
+    const size_t bytes = ((kBlobHeader + (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 + 15) / 16) * 16;
     for (FrameSlot& f : c->slots) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob
         if (f.h_blob) (void)hipHostFree(f.h_blob);
         if (f.d_blob) (void)hipFree(f.d_blob);
         f.h_blob = f.d_blob = nullptr;
-        HIPCHK(c, hipHostMalloc((void**)&f.h_blob, bytes));
+        HIPCHK(c, hipHostMalloc((void**)&f.h_blob, bytes, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer(&f.h_blob_dev, f.h_blob, 0));
         HIPCHK(c, hipMalloc((void**)&f.d_blob, bytes));
     }
     c->blob_bytes = bytes;
@@ -476,13 +478,16 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     hipStream_t head = (chained && head_mode == 0) ? s : f.stream;            // clear, raster, mask
     if (c->debug && !f.unsharpF) HIPCHK(c, hipMalloc((void**)&f.unsharpF, (size_t)W * H * 12));
     const bool all_marks = c->timing == 1;
-    const bool use_graph = !no_graph && !c->debug && !all_marks && W > 1 && H > 1;
+    // The captured body is for frames in flight beside each other (phase mode), where the submitting host thread is the
+    // bottleneck.  On the chained critical path a graph launch leaves the GPU idle ~8 us longer than the same kernels
+    // launched one by one (4600 vs 4785 frames/s, profiles/r01_e_streams.md), and the host keeps up easily.
+    const bool use_graph = !no_graph && !chained && !c->debug && !all_marks && W > 1 && H > 1;
     if (use_graph && !f.body) { int rc = capture_body(c, f); if (rc) return rc; }
 
     Timer th(c, head), tm(c, s);
     // the plan goes up on its own stream, after the frame that last used this slot has let go of the device copy
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, f.done, 0));
-    HIPCHK(c, hipMemcpyAsync(f.d_blob, f.h_blob, used, hipMemcpyHostToDevice, c->copy_stream));
+    launch_upload(f.h_blob_dev, f.d_blob, used, c->copy_stream);
     HIPCHK(c, hipEventRecord(f.uploaded, c->copy_stream));
     if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, c->inputs_ready, 0));
     if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, f.done, 0));    // the frame that last used this slot's buffers
