@@ -475,6 +475,69 @@ static void dump_prims() {
     dump_mat("gauss_k23_s1", getGaussianKernel(23, 1.0, CV_32F));
 }
 
+// ---- pre-ORB filter chain, first part: Extractor::foreground (src/extractor.cpp:136-229) ------------------------------
+// Restates foregroundMask()/foreground() for ONE image with every intermediate written out, then checks the result
+// against the real Extractor::foreground (both of its outputs, since it processes two images the same way).
+static void dump_fstage() {
+    Mat a = read_mat("img1");
+    poppy::init(false, 60, 1.0, false, false, false, false, false, 30, 64, "FFV1", false, 8);
+    Mat grey;
+    cvtColor(a, grey, COLOR_BGR2GRAY);
+    dump_mat("grey", grey);
+
+    const size_t iterations = 12;
+    Mat fgMask = Mat::zeros(grey.rows, grey.cols, grey.type());
+    Mat last = grey.clone();
+    Mat fgMaskBlur, med, flow;
+    auto bs = createBackgroundSubtractorMOG2();
+    bs->apply(grey, flow);
+    dump_mat("flow0", flow);
+    fgMask += (flow * (1.0 / (iterations / 2.0)));
+    dump_mat("acc0", fgMask);
+    for (size_t i = 0; i < 12; ++i) {
+        medianBlur(last, med, i * 8 + 1);
+        bs->apply(med, flow);
+        fgMask += (flow * (1.0 / (iterations / 2.0)));
+        Mat acc = fgMask.clone();
+        GaussianBlur(fgMask, fgMaskBlur, { 23, 23 }, 1);
+        fgMask = fgMaskBlur.clone();
+        last = med.clone();
+        char nm[32];
+        snprintf(nm, sizeof nm, "med%zu", i + 1); dump_mat(nm, med);
+        snprintf(nm, sizeof nm, "flow%zu", i + 1); dump_mat(nm, flow);
+        snprintf(nm, sizeof nm, "acc%zu", i + 1); dump_mat(nm, acc);
+        snprintf(nm, sizeof nm, "blur%zu", i + 1); dump_mat(nm, fgMask);
+    }
+    Mat greyF, maskF, finalMask;
+    grey.convertTo(greyF, CV_32F, 1.0 / 255.0);
+    fgMask.convertTo(maskF, CV_32F, 1.0 / 255.0);
+    maskF.copyTo(finalMask);
+    int logBase = 20;
+    Mat logMask(finalMask.size(), CV_32F);
+    logMask = Scalar::all(logBase);
+    log(logMask, logMask);
+    dump_mat("log20", logMask(Rect(0, 0, 1, 1)));
+    Mat lin = finalMask * (logBase - 1.0) + 1.0;
+    dump_mat("lin", lin);
+    log(lin, finalMask);
+    dump_mat("logged", finalMask);
+    divide(finalMask, logMask, finalMask);
+    dump_mat("finalMask", finalMask);
+    Mat masked;
+    multiply(greyF, finalMask, masked);
+    masked.convertTo(masked, CV_8U, 255.0);
+    dump_mat("masked", masked);
+    Mat fg;
+    equalizeHist(masked, fg);
+    dump_mat("foreground", fg);
+
+    Extractor ex(a, a);
+    Mat f1, f2;
+    ex.foreground(f1, f2);
+    if (countNonZero(f1 != fg) || countNonZero(f2 != fg)) { fprintf(stderr, "FATAL: staged foreground differs from Extractor::foreground\n"); exit(2); }
+    fprintf(stderr, "fstage ok (staged == Extractor::foreground)\n");
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s <bstage|orb|match|astage|prims> <case_dir>\n", argv[0]); return 1; }
     string mode = argv[1], dir = argv[2];
@@ -486,6 +549,7 @@ int main(int argc, char** argv) {
     else if (mode == "match") dump_match();
     else if (mode == "astage") dump_astage();
     else if (mode == "prims") dump_prims();
+    else if (mode == "fstage") dump_fstage();
     else { fprintf(stderr, "unknown mode\n"); return 1; }
     return 0;
 }

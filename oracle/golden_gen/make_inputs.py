@@ -55,6 +55,19 @@ ASTAGE = {
 }
 
 
+FSTAGE = {
+    # name: (w, h, seed): one BGR image through Extractor::foreground (src/extractor.cpp:136-229)
+    "f_160x120": (160, 120, 41),
+    "f_317x211": (317, 211, 42),
+    "f_640x480": (640, 480, 43),
+}
+
+
+def fstage_inputs(name):
+    w, h, seed = FSTAGE[name]
+    return {"img1": synth.textured_bgr(w, h, seed)}
+
+
 def bstage_inputs(name):
     w, h, n, ratios, levels = BSTAGE[name]
     c1 = synth.textured_bgr(w, h, 21)
@@ -116,6 +129,7 @@ def all_cases():
     out += [("match", n, match_inputs) for n in MATCH]
     out += [("astage", n, astage_inputs) for n in ASTAGE]
     out += [("prims", "p_prims", lambda _n: prims_inputs())]
+    out += [("fstage", n, fstage_inputs) for n in FSTAGE]
     return out
 
 
@@ -126,4 +140,5 @@ if __name__ == "__main__":
             continue
         for k, v in fn(name).items():
             write_in(name, k, v)
-        print(mode, name)
+        os.makedirs(os.path.join(CASES_DIR, name, "out"), exist_ok=True)
+        print(mode, name)          # run_all.sh reads these "mode case" lines

@@ -40,6 +40,10 @@ def keep_full(name, arr):
 
 
 def main():
+    """pack.py            repack every case under oracle/_dumps/cases
+    pack.py CASE ...   (re)pack only these and merge them into the existing manifest (npz files are not
+                       byte-reproducible, so untouched cases keep their committed files)"""
+    only = sys.argv[1:]
     os.makedirs(GOLD, exist_ok=True)
     manifest = {
         "provenance": {
@@ -51,8 +55,13 @@ def main():
         },
         "cases": {},
     }
+    mpath = os.path.join(GOLD, "manifest.json")
+    if only and os.path.exists(mpath):
+        manifest["cases"] = json.load(open(mpath))["cases"]
     for cdir in sorted(glob.glob(os.path.join(CASES, "*"))):
         case = os.path.basename(cdir)
+        if only and case not in only:
+            continue
         full = {}
         entries = {}
         for path in sorted(glob.glob(os.path.join(cdir, "out", "*.bin"))):

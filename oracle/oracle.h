@@ -108,4 +108,30 @@ void filter_invalid_points(std::vector<Pt>& p1, std::vector<Pt>& p2, int cols, i
 double morph_distance(const std::vector<Pt>& p1, const std::vector<Pt>& p2, int w, int h);
 void match_prepare(std::vector<Pt>& s1, std::vector<Pt>& s2, int w, int h, double tolerance, double initialMorphDist);
 
+// ---- prefilter.cpp: Extractor::foreground (src/extractor.cpp:136-229) -------------------------
+void bgr_to_gray_u8(const ImageU8& bgr, ImageU8& gray);
+struct Mog2 {                                   // BackgroundSubtractorMOG2(500, 16, true), one channel
+    static const int kModes = 5;
+    int w, h, nframes;
+    std::vector<float> weight, variance, mean;  // [pixel][mode]
+    std::vector<uint8_t> used;
+    Mog2(int w, int h);
+    void apply(const ImageU8& img, ImageU8& mask);
+};
+void accumulate_scaled_u8(ImageU8& acc, const ImageU8& flow, double scale);
+void median_blur_u8(const ImageU8& src, int ksize, ImageU8& dst);
+extern const int kGauss23Sigma1Fx[23];
+void gaussian_blur23_u8(const ImageU8& src, ImageU8& dst);
+// stages (optional): flow0, acc0, then per iteration med, flow, acc, blur
+void foreground_mask(const ImageU8& grey, ImageU8& fgMask, std::vector<ImageU8>* stages = nullptr);
+float cv_log32f(float x);
+void equalize_hist(const ImageU8& src, ImageU8& dst);
+struct ForegroundDebug {
+    ImageU8 grey, masked;
+    std::vector<ImageU8> stages;
+    float ln20 = 0;
+    ImageF lin, logged, final_mask;
+};
+void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg = nullptr);
+
 }  // namespace oracle

@@ -133,4 +133,20 @@ int orc_match_prepare(const float* p1, const float* p2, int n, int w, int h, dou
     auto a = wrap_pts(p1, n), b = wrap_pts(p2, n); match_prepare(a, b, w, h, tol, imd); put((Pt*)o1, a); put((Pt*)o2, b); return (int)a.size();
 }
 
+// Extractor::foreground for one BGR image.  `stages` (optional): 50 u8 images of w*h in the order flow0, acc0, then 12 x
+// (med, flow, acc, blur); `floats` (optional): lin, logged, finalMask (w*h each); misc: grey, masked (u8), ln20.
+void orc_foreground(const uint8_t* bgr, int w, int h, uint8_t* fg, uint8_t* grey, uint8_t* stages, float* floats, uint8_t* masked, float* ln20) {
+    ForegroundDebug dbg; ImageU8 out;
+    foreground(wrap_u8(bgr, w, h, 3), out, &dbg);
+    put_img(fg, out); put_img(grey, dbg.grey); put_img(masked, dbg.masked);
+    const size_t n = (size_t)w * h;
+    if (stages) for (size_t k = 0; k < dbg.stages.size(); ++k) memcpy(stages + k * n, dbg.stages[k].d.data(), n);
+    if (floats) { memcpy(floats, dbg.lin.d.data(), n * 4); memcpy(floats + n, dbg.logged.d.data(), n * 4); memcpy(floats + 2 * n, dbg.final_mask.d.data(), n * 4); }
+    if (ln20) *ln20 = dbg.ln20;
+}
+void orc_median_blur_u8(const uint8_t* s, int w, int h, int ksize, uint8_t* d) { ImageU8 o; median_blur_u8(wrap_u8(s, w, h, 1), ksize, o); put_img(d, o); }
+void orc_gaussian_blur23_u8(const uint8_t* s, int w, int h, uint8_t* d) { ImageU8 o; gaussian_blur23_u8(wrap_u8(s, w, h, 1), o); put_img(d, o); }
+void orc_equalize_hist(const uint8_t* s, int w, int h, uint8_t* d) { ImageU8 o; equalize_hist(wrap_u8(s, w, h, 1), o); put_img(d, o); }
+float orc_log32f(float x) { return cv_log32f(x); }
+
 }  // extern "C"

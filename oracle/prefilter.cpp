@@ -1,0 +1,275 @@
+// oracle/prefilter.cpp — CPU restatement of the first part of the pre-ORB filter chain: Extractor::foreground
+// (src/extractor.cpp:136-229).  TEST INFRASTRUCTURE ONLY (see oracle.h).
+//
+//   grey   = cvtColor(BGR2GRAY)                                   OCV/imgproc/src/color_rgb.simd.hpp:646-730
+//   flow   = BackgroundSubtractorMOG2(500, 16, shadows).apply()   OCV/video/src/bgfg_gaussmix2.cpp:479-523,539-755,847-884
+//   acc   += flow * (1/6)   (u8 convertTo with a float scale, then saturating add)
+//                                                                 OCV/core/src/matrix_expressions.cpp:270-275,1330-1336
+//   med    = medianBlur(last, 8i+1)   (exact median, replicated border)     OCV/imgproc/src/median_blur.simd.hpp
+//   acc    = GaussianBlur(acc, 23x23, sigma 1)  (8-bit fixed-point path)    OCV/imgproc/src/smooth.dispatch.cpp:224-258,611-683,
+//                                                                           smooth.simd.hpp:1136-1199,1780-1866
+//   mask   = log(acc/255 * 19 + 1) / log(20);  fg = equalizeHist(u8(grey/255 * mask * 255))
+//                                                                 OCV/core/src/mathfuncs_core.simd.hpp:683-752,
+//                                                                 OCV/imgproc/src/histogram.cpp:3436-3493
+#include "oracle.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace oracle {
+
+// ---- BGR -> grey, 8 bit: (b*3735 + g*19235 + r*9798 + 2^14) >> 15 --------------------------------------------------
+void bgr_to_gray_u8(const ImageU8& bgr, ImageU8& gray) {
+    gray = ImageU8(bgr.w, bgr.h, 1);
+    const size_t n = (size_t)bgr.w * bgr.h;
+    for (size_t i = 0; i < n; ++i) {
+        const int b = bgr.d[3 * i], g = bgr.d[3 * i + 1], r = bgr.d[3 * i + 2];
+        gray.d[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+// ---- MOG2, one channel, default parameters ---------------------------------------------------------------------------
+Mog2::Mog2(int w_, int h_) : w(w_), h(h_), nframes(0) {
+    const size_t n = (size_t)w * h;
+    weight.assign(n * kModes, 0.f); variance.assign(n * kModes, 0.f); mean.assign(n * kModes, 0.f);
+    used.assign(n, 0);
+}
+
+void Mog2::apply(const ImageU8& img, ImageU8& mask) {
+    const float Tb = 16.f, TB = 0.9f, Tg = 9.f, varInit = 15.f, varMin = 4.f, varMax = 75.f, tau = 0.5f;
+    const double fCT = 0.05f;
+    ++nframes;
+    const double learningRate = 1. / std::min(2 * nframes, 500);
+    const float alphaT = (float)learningRate, alpha1 = 1.f - alphaT, prune = (float)(-learningRate * fCT);
+    mask = ImageU8(w, h, 1);
+    const size_t n = (size_t)w * h;
+    for (size_t p = 0; p < n; ++p) {
+        float* gw = &weight[p * kModes]; float* gv = &variance[p * kModes]; float* mu = &mean[p * kModes];
+        const float data = (float)img.d[p];
+        bool background = false, fitsPDF = false;
+        int nmodes = used[p];
+        float totalWeight = 0.f;
+        for (int mode = 0; mode < nmodes; ++mode) {            // nmodes shrinks inside the loop when a mode is pruned, as in the reference
+            float wgt = alpha1 * gw[mode] + prune;
+            int swap_count = 0;
+            if (!fitsPDF) {
+                const float var = gv[mode];
+                const float dD = mu[mode] - data;
+                float dist2 = 0.f;
+                dist2 += dD * dD;
+                if (totalWeight < TB && dist2 < Tb * var) background = true;
+                if (dist2 < Tg * var) {
+                    fitsPDF = true;
+                    wgt += alphaT;
+                    const float k = alphaT / wgt;
+                    mu[mode] -= k * dD;
+                    float varnew = var + k * (dist2 - var);
+                    varnew = std::max(varnew, varMin);
+                    varnew = std::min(varnew, varMax);
+                    gv[mode] = varnew;
+                    for (int i = mode; i > 0; --i) {
+                        if (wgt < gw[i - 1]) break;
+                        ++swap_count;
+                        std::swap(gw[i], gw[i - 1]); std::swap(gv[i], gv[i - 1]); std::swap(mu[i], mu[i - 1]);
+                    }
+                }
+            }
+            if (wgt < -prune) { wgt = 0.f; --nmodes; }
+            gw[mode - swap_count] = wgt;
+            totalWeight += wgt;
+        }
+        float invWeight = 0.f;
+        if (std::fabs(totalWeight) > 1.1920928955078125e-7f) invWeight = 1.f / totalWeight;
+        for (int mode = 0; mode < nmodes; ++mode) gw[mode] *= invWeight;
+        if (!fitsPDF && alphaT > 0.f) {
+            const int mode = nmodes == kModes ? kModes - 1 : nmodes++;
+            if (nmodes == 1) gw[mode] = 1.f;
+            else {
+                gw[mode] = alphaT;
+                for (int i = 0; i < nmodes - 1; ++i) gw[i] *= alpha1;
+            }
+            mu[mode] = data;
+            gv[mode] = varInit;
+            for (int i = nmodes - 1; i > 0; --i) {
+                if (alphaT < gw[i - 1]) break;
+                std::swap(gw[i], gw[i - 1]); std::swap(gv[i], gv[i - 1]); std::swap(mu[i], mu[i - 1]);
+            }
+        }
+        used[p] = (uint8_t)nmodes;
+        uint8_t out = 0;
+        if (!background) {
+            out = 255;
+            float tWeight = 0.f;                     // detectShadowGMM
+            for (int mode = 0; mode < nmodes; ++mode) {
+                float numerator = 0.f, denominator = 0.f;
+                numerator += data * mu[mode];
+                denominator += mu[mode] * mu[mode];
+                if (denominator == 0) break;
+                if (numerator <= denominator && numerator >= tau * denominator) {
+                    const float a = numerator / denominator;
+                    float dist2a = 0.f;
+                    const float dDs = a * mu[mode] - data;
+                    dist2a += dDs * dDs;
+                    if (dist2a < Tb * gv[mode] * a * a) { out = 127; break; }
+                }
+                tWeight += gw[mode];
+                if (tWeight > TB) break;
+            }
+        }
+        mask.d[p] = out;
+    }
+}
+
+// ---- acc += saturate(round(flow * (float)(1/6))) ---------------------------------------------------------------------
+void accumulate_scaled_u8(ImageU8& acc, const ImageU8& flow, double scale) {
+    const float a = (float)scale;
+    for (size_t i = 0; i < acc.d.size(); ++i) {
+        int t = cv_round_f((float)flow.d[i] * a + 0.f);
+        t = t < 0 ? 0 : t > 255 ? 255 : t;
+        const int s = acc.d[i] + t;
+        acc.d[i] = (uint8_t)(s > 255 ? 255 : s);
+    }
+}
+
+// ---- medianBlur, 8 bit, odd ksize, replicated border: the exact median of the ksize x ksize window ----------------------
+void median_blur_u8(const ImageU8& src, int ksize, ImageU8& dst) {
+    dst = ImageU8(src.w, src.h, 1);
+    if (ksize <= 1) { dst.d = src.d; return; }
+    const int r = ksize / 2, w = src.w, h = src.h, half = (ksize * ksize) / 2;     // median = element number `half` (0-based)
+    std::vector<int> rows(ksize);
+    for (int y = 0; y < h; ++y) {
+        for (int k = 0; k < ksize; ++k) rows[k] = std::min(std::max(y + k - r, 0), h - 1);
+        int hist[256] = {0};
+        auto add_col = [&](int cx, int delta) {
+            const int x = std::min(std::max(cx, 0), w - 1);
+            for (int k = 0; k < ksize; ++k) hist[src.d[(size_t)rows[k] * w + x]] += delta;
+        };
+        for (int cx = -r; cx <= r; ++cx) add_col(cx, 1);
+        for (int x = 0; x < w; ++x) {
+            int s = 0, v = 0;
+            for (; v < 256; ++v) { s += hist[v]; if (s > half) break; }
+            dst.d[(size_t)y * w + x] = (uint8_t)v;
+            add_col(x - r, -1);
+            add_col(x + r + 1, 1);
+        }
+    }
+}
+
+// ---- GaussianBlur 23x23 sigma 1 on 8 bit: taps in 8.8 fixed point with error diffusion, exact integer sums ---------------
+// (getGaussianKernelFixedPoint_ED: round(k_i*256 + carried error), centre = 256 - rest.)  No saturation can occur: the taps
+// sum to 256, so the horizontal sum is <= 255*256 and fits 16 bits.
+const int kGauss23Sigma1Fx[23] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 14, 62, 102, 62, 14, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+
+void gaussian_blur23_u8(const ImageU8& src, ImageU8& dst) {
+    const int w = src.w, h = src.h, n = 23, r = 11;
+    std::vector<uint16_t> hbuf((size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint32_t s = 0;
+            for (int k = 0; k < n; ++k)
+                if (kGauss23Sigma1Fx[k]) s += (uint32_t)kGauss23Sigma1Fx[k] * src.d[(size_t)y * w + border_reflect101(x + k - r, w)];
+            hbuf[(size_t)y * w + x] = (uint16_t)s;
+        }
+    dst = ImageU8(w, h, 1);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint32_t s = 0;
+            for (int k = 0; k < n; ++k)
+                if (kGauss23Sigma1Fx[k]) s += (uint32_t)kGauss23Sigma1Fx[k] * hbuf[(size_t)border_reflect101(y + k - r, h) * w + x];
+            const uint32_t v = (s + (1u << 15)) >> 16;
+            dst.d[(size_t)y * w + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+}
+
+void foreground_mask(const ImageU8& grey, ImageU8& fgMask, std::vector<ImageU8>* stages) {
+    fgMask = ImageU8(grey.w, grey.h, 1);
+    ImageU8 last = grey, med, flow, blur;
+    Mog2 bs(grey.w, grey.h);
+    bs.apply(grey, flow);
+    accumulate_scaled_u8(fgMask, flow, 1.0 / (12 / 2.0));
+    if (stages) { stages->push_back(flow); stages->push_back(fgMask); }
+    for (int i = 0; i < 12; ++i) {
+        median_blur_u8(last, i * 8 + 1, med);
+        bs.apply(med, flow);
+        accumulate_scaled_u8(fgMask, flow, 1.0 / (12 / 2.0));
+        if (stages) { stages->push_back(med); stages->push_back(flow); stages->push_back(fgMask); }
+        gaussian_blur23_u8(fgMask, blur);
+        fgMask = blur;
+        if (stages) stages->push_back(fgMask);
+        last = med;
+    }
+}
+
+// ---- cv::log on float: 256-entry table of (ln(1 + i/256), 1/(1 + i/256)) + cubic ------------------------------------------
+static const float* log_tab() {
+    static float tab[512];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 255; ++i) {
+            const long double t = 1.0L + (long double)i / 256.0L;
+            tab[2 * i] = (float)(double)logl(t);            // the reference table holds these as doubles, used as floats
+            tab[2 * i + 1] = (float)(double)(1.0L / t);
+        }
+        // the last interval is expanded around 2 instead: (ln 2, 1/2), with x0 shifted by -1/512 (OCV/core/src/mathfuncs.cpp:2151-2408)
+        tab[510] = (float)0.69314718055994530941723212145818; tab[511] = 0.5f;
+        init = true;
+    }
+    return tab;
+}
+
+float cv_log32f(float x) {
+    const float* tab = log_tab();
+    const float A0 = 0.3333333333333333333333333f, A1 = -0.5f, A2 = 1.f;
+    const float ln2 = (float)0.69314718055994530941723212145818;
+    int32_t i0;
+    memcpy(&i0, &x, 4);
+    const int32_t bi = (i0 & ((1 << 15) - 1)) | (127 << 23);
+    float bf;
+    memcpy(&bf, &bi, 4);
+    const int idx = (i0 >> 14) & 510;
+    const float y0 = (float)(((i0 >> 23) & 0xff) - 127) * ln2 + tab[idx];
+    const float x0 = (bf - 1.f) * tab[idx + 1] + (idx == 510 ? -1.f / 512 : 0.f);
+    return ((A0 * x0 + A1) * x0 + A2) * x0 + y0;
+}
+
+void equalize_hist(const ImageU8& src, ImageU8& dst) {
+    dst = ImageU8(src.w, src.h, 1);
+    int hist[256] = {0};
+    for (uint8_t v : src.d) ++hist[v];
+    int i = 0;
+    while (!hist[i]) ++i;
+    const int total = (int)src.d.size();
+    if (hist[i] == total) { std::fill(dst.d.begin(), dst.d.end(), (uint8_t)i); return; }
+    const float scale = (256 - 1.f) / (total - hist[i]);
+    int lut[256] = {0};
+    int sum = 0;
+    for (lut[i++] = 0; i < 256; ++i) {
+        sum += hist[i];
+        int v = cv_round_f((float)sum * scale);
+        lut[i] = v < 0 ? 0 : v > 255 ? 255 : v;
+    }
+    for (size_t p = 0; p < src.d.size(); ++p) dst.d[p] = (uint8_t)lut[src.d[p]];
+}
+
+void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg) {
+    ImageU8 grey, fgMask;
+    bgr_to_gray_u8(bgr, grey);
+    foreground_mask(grey, fgMask, dbg ? &dbg->stages : nullptr);
+    ImageF greyF, maskF;
+    u8_to_f32(grey, greyF);
+    u8_to_f32(fgMask, maskF);
+    const float ln20 = cv_log32f(20.f);
+    ImageF lin(maskF.w, maskF.h, 1), logged(maskF.w, maskF.h, 1), fin(maskF.w, maskF.h, 1), masked(maskF.w, maskF.h, 1);
+    for (size_t i = 0; i < maskF.d.size(); ++i) {
+        lin.d[i] = maskF.d[i] * 19.f + 1.f;                  // convertTo(CV_32F, 19, 1)
+        logged.d[i] = cv_log32f(lin.d[i]);
+        fin.d[i] = logged.d[i] / ln20;
+        masked.d[i] = greyF.d[i] * fin.d[i];
+    }
+    ImageU8 m8;
+    f32_to_u8(masked, m8);
+    equalize_hist(m8, fg);
+    if (dbg) { dbg->grey = grey; dbg->ln20 = ln20; dbg->lin = lin; dbg->logged = logged; dbg->final_mask = fin; dbg->masked = m8; }
+}
+
+}  // namespace oracle

@@ -263,6 +263,7 @@ static void build_raster(FramePlan& plan, int w, int h) {
     const int T = plan.n_tris;
     plan.raster.assign(T, RasterTri{});
     plan.work.clear();
+    for (int t = 0; t < T; ++t) { plan.work.push_back(t); plan.work.push_back(-1); }      // outlines first
     for (int t = 0; t < T; ++t) {
         const int* v = &plan.tri_xy[(size_t)t * 6];
         const int vx[3] = {v[0], v[2], v[4]}, vy[3] = {v[1], v[3], v[5]};
@@ -302,7 +303,7 @@ static void build_raster(FramePlan& plan, int w, int h) {
             r.n0 = nseg[0]; r.n1 = nseg[1];
         }
         const int rows = r.ystop - r.ymin;
-        const int chunks = rows > 0 ? (rows + kPlanRasterRows - 1) / kPlanRasterRows : 1;   // chunk 0 also draws the outline
+        const int chunks = (rows + kPlanRasterRows - 1) / kPlanRasterRows;
         for (int k = 0; k < chunks; ++k) { plan.work.push_back(t); plan.work.push_back(k); }
     }
 }

@@ -28,7 +28,7 @@ struct FramePlan {
     std::vector<float> M1, M2;       // T*9 forward matrices (diagnostics)
     std::vector<float> inv1, inv2;   // T*9 inverse matrices, what create_map actually uses
     std::vector<RasterTri> raster;   // T fill-edge tables
-    std::vector<int> work;           // raster work list: (triangle, row chunk) pairs
+    std::vector<int> work;           // raster work list: (triangle, -1) = outline, (triangle, row chunk) = fill rows
     int n_tris = 0;
 };
 constexpr int kPlanRasterRows = 16;  // rows of one triangle per raster work item

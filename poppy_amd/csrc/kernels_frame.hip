@@ -121,8 +121,9 @@ __device__ void outline_segment(int32_t* map, int W, int H, int ax, int ay, int 
     }
 }
 
-// work item = (triangle, chunk of kRasterChunkRows rows).  256 threads: 4 waves take rows round-robin, lanes split
-// the span.  Chunk 0 also draws the outline (one segment per wave).  The fill edges come from the host plan
+// work item = (triangle, chunk of kRasterChunkRows rows): 4 waves take rows round-robin, lanes split the span; or
+// (triangle, -1): the triangle's outline, one segment per wave.  Outlines are items of their own (listed first) so
+// that their longer dependent chain runs beside the fills instead of in front of a chunk's rows.  The fill edges come from the host plan
 // (RasterTri, frame_plan.h): FillConvexPoly's two-chain walk (drawing.cpp:1164-1252) is decided there once per
 // triangle, a row here is one 64-bit multiply-add per chain.
 struct RasterTriDev {
@@ -139,12 +140,15 @@ __global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int value = t + 1;
 
-    if (chunk == 0 && wave < 3) {      // outline: (v2->v0), (v0->v1), (v1->v2)
-        int vx[3], vy[3];
+    if (chunk < 0) {                   // outline item: (v2->v0), (v0->v1), (v1->v2), one segment per wave
+        if (wave < 3) {
+            int vx[3], vy[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
-        const int a = wave == 0 ? 2 : wave - 1, b = wave == 0 ? 0 : wave;
-        outline_segment(map, W, H, vx[a], vy[a], vx[b], vy[b], value, lane);
+            for (int i = 0; i < 3; ++i) { vx[i] = tri_xy[t * 6 + 2 * i]; vy[i] = tri_xy[t * 6 + 2 * i + 1]; }
+            const int a = wave == 0 ? 2 : wave - 1, b = wave == 0 ? 0 : wave;
+            outline_segment(map, W, H, vx[a], vy[a], vx[b], vy[b], value, lane);
+        }
+        return;
     }
 
     const RasterTriDev& r = edges[t];

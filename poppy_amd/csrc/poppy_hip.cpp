@@ -201,7 +201,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // worst case every triangle spans the whole image height
-    const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 2);
+    const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 3);
     const size_t bytes = ((kBlobHeader + (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 + 15) / 16) * 16;
     for (FrameSlot& f : c->slots) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob

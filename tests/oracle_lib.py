@@ -285,3 +285,42 @@ def orb_describe(img, kps7, trig_mode=0):
     out = np.zeros((len(k), 32), np.uint8)
     lib().orc_orb_describe(_vp(g), w, h, _vp(k), len(k), _vp(out), trig_mode)
     return out
+
+
+def foreground(bgr):
+    """Extractor::foreground for one BGR image: dict with the final image and every intermediate."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    fg = np.zeros((h, w), np.uint8); grey = np.zeros((h, w), np.uint8); masked = np.zeros((h, w), np.uint8)
+    stages = np.zeros((50, h, w), np.uint8)
+    floats = np.zeros((3, h, w), np.float32)
+    ln20 = C.c_float(0)
+    lib().orc_foreground(_vp(bgr), w, h, _vp(fg), _vp(grey), _vp(stages), _vp(floats), _vp(masked), C.byref(ln20))
+    out = dict(foreground=fg, grey=grey, masked=masked, lin=floats[0], logged=floats[1], finalMask=floats[2],
+               log20=np.array([[ln20.value]], np.float32), flow0=stages[0], acc0=stages[1])
+    for i in range(12):
+        out[f"med{i + 1}"], out[f"flow{i + 1}"], out[f"acc{i + 1}"], out[f"blur{i + 1}"] = stages[2 + 4 * i: 6 + 4 * i]
+    return out
+
+
+def median_blur_u8(a, ksize):
+    a = np.ascontiguousarray(a, np.uint8); o = np.zeros_like(a)
+    lib().orc_median_blur_u8(_vp(a), a.shape[1], a.shape[0], ksize, _vp(o))
+    return o
+
+
+def gaussian_blur23_u8(a):
+    a = np.ascontiguousarray(a, np.uint8); o = np.zeros_like(a)
+    lib().orc_gaussian_blur23_u8(_vp(a), a.shape[1], a.shape[0], _vp(o))
+    return o
+
+
+def equalize_hist(a):
+    a = np.ascontiguousarray(a, np.uint8); o = np.zeros_like(a)
+    lib().orc_equalize_hist(_vp(a), a.shape[1], a.shape[0], _vp(o))
+    return o
+
+
+def log32f(x):
+    L = lib(); L.orc_log32f.restype = C.c_float; L.orc_log32f.argtypes = [C.c_float]
+    return L.orc_log32f(float(x))
