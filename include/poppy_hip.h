@@ -120,6 +120,22 @@ int poppy_hip_hamming_match(poppy_hip_ctx* ctx, const uint8_t* query32, int n_qu
 int poppy_match_points(const float* points1, const float* points2, int n_points, int width, int height,
                        double match_tolerance, float* out1, float* out2, int* n_out, double* initial_morph_distance);
 
+/* Extractor::foreground for ONE image (src/extractor.cpp:136-229; the reference runs it on both images of a pair,
+ * three times per pair: poppy.hpp:52,116 and matcher.cpp:17): grey -> 13 x MOG2 on progressively median-blurred copies
+ * (k = 1, 9, ..., 89), accumulated and Gaussian-smoothed -> log mask -> x grey -> equalizeHist.  Returns the 8-bit
+ * `goodFeatures` image (width*height bytes).  Bit-exact with the reference.  First part of the pre-ORB filter chain
+ * (SURVEY 8f-1); the rest (dft_detail2, Gabor bank) is not on the GPU yet, so poppy_hip_pair_begin still fails.
+ * debug (optional, host pointers, each may be NULL): grey w*h; stages 50 planes of w*h in the order flow0, acc0, then
+ * 12 x (med, flow, acc, blur); floats 3 planes of w*h: lin, logged, finalMask; masked w*h.                      */
+typedef struct poppy_foreground_debug {
+    uint8_t* grey;
+    uint8_t* stages;
+    float* floats;
+    uint8_t* masked;
+} poppy_foreground_debug;
+int poppy_hip_foreground(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height,
+                         uint8_t* good_features, const poppy_foreground_debug* debug);
+
 /* Pair set-up from the two ORB input images g1/g2 (what Extractor::keypoints feeds the detector,
  * src/extractor.cpp:50-78) and gabor2 (src/poppy.hpp:119-122): ORB x2 -> truncate to the shorter list
  * (extractor.cpp:96-99) -> poppy_match_points -> resident pair.  nfeatures = int(max_keypoints * detail).  */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_hip_orb_detect", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_points",
 ]
 
 
@@ -68,6 +68,7 @@ def lib():
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
+        L.poppy_hip_foreground.argtypes = [vp, vp, sz, i, i, vp, vp]
         L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
         L.poppy_hip_hamming_match.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.poppy_match_points.argtypes = [vp, vp, i, i, i, d, vp, vp, vp, vp]
@@ -181,6 +182,27 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_orb_detect(self.h, _p(g), w, w, h, nfeatures, _p(kp), cap, C.byref(n)), "orb_detect")
         return kp[:n.value].copy()
+
+    def foreground(self, bgr, debug=False):
+        """Extractor::foreground for one BGR image -> goodFeatures (u8); with debug=True a dict with every intermediate."""
+        a = np.ascontiguousarray(bgr, np.uint8)
+        h, w = a.shape[:2]
+        out = np.zeros((h, w), np.uint8)
+        if not debug:
+            self._chk(lib().poppy_hip_foreground(self.h, _p(a), w * 3, w, h, _p(out), None), "foreground")
+            return out
+        grey = np.zeros((h, w), np.uint8); masked = np.zeros((h, w), np.uint8)
+        stages = np.zeros((50, h, w), np.uint8); floats = np.zeros((3, h, w), np.float32)
+
+        class Dbg(C.Structure):
+            _fields_ = [("grey", C.c_void_p), ("stages", C.c_void_p), ("floats", C.c_void_p), ("masked", C.c_void_p)]
+        d = Dbg(grey.ctypes.data, stages.ctypes.data, floats.ctypes.data, masked.ctypes.data)
+        self._chk(lib().poppy_hip_foreground(self.h, _p(a), w * 3, w, h, _p(out), C.byref(d)), "foreground")
+        res = dict(foreground=out, grey=grey, masked=masked, lin=floats[0], logged=floats[1], finalMask=floats[2],
+                   flow0=stages[0], acc0=stages[1])
+        for k in range(12):
+            res[f"med{k + 1}"], res[f"flow{k + 1}"], res[f"acc{k + 1}"], res[f"blur{k + 1}"] = stages[2 + 4 * k: 6 + 4 * k]
+        return res
 
     def orb_describe(self, gray, kps7):
         g = np.ascontiguousarray(gray, np.uint8)

@@ -1,0 +1,127 @@
+// foreground.cpp — Extractor::foreground (src/extractor.cpp:136-229) for one image, as a sequence of HIP launches:
+//   grey -> MOG2 -> 12 x { median(8i+1) -> MOG2 -> accumulate -> Gaussian 23x23 } -> log mask -> equalizeHist.
+// Everything stays in HBM between the steps; the only host work is the schedule of learning rates.
+#include "foreground.h"
+#include "kernels_prefilter.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace poppy_hip {
+
+#define FG_CHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } \
+    } while (0)
+
+ForegroundFilter::~ForegroundFilter() {
+    release();
+    if (logtab) (void)hipFree(logtab);
+}
+
+void ForegroundFilter::release() {
+    void* bufs[] = {d_bgr, grey, img[0], img[1], acc[0], acc[1], flow, used, masked, out, lut, tmp16, gw, gv, gm, dbgf, hist};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    d_bgr = grey = img[0] = img[1] = acc[0] = acc[1] = flow = used = masked = out = lut = nullptr;
+    tmp16 = nullptr; gw = gv = gm = dbgf = nullptr; hist = nullptr;
+    W = H = 0;
+}
+
+int ForegroundFilter::ensure(int w, int h) {
+    if (!prepared) {
+        if (!prepare_median_u8()) { err = "hipFuncSetAttribute(k_median_u8) failed"; return -2; }
+        // cv::log's table (OCV/core/src/mathfuncs.cpp:2151-2408): (ln(1 + i/256), 1/(1 + i/256)) as doubles, used as floats;
+        // the last pair is (ln 2, 1/2)
+        std::vector<float> tab(512);
+        for (int i = 0; i < 255; ++i) {
+            const long double t = 1.0L + (long double)i / 256.0L;
+            tab[2 * i] = (float)(double)logl(t);
+            tab[2 * i + 1] = (float)(double)(1.0L / t);
+        }
+        tab[510] = (float)0.69314718055994530941723212145818; tab[511] = 0.5f;
+        FG_CHK(hipMalloc((void**)&logtab, 512 * sizeof(float)));
+        FG_CHK(hipMemcpy(logtab, tab.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+        prepared = true;
+    }
+    if (w == W && h == H) return 0;
+    float* keep = logtab;
+    release();
+    logtab = keep;
+    const size_t P = (size_t)w * h;
+    FG_CHK(hipMalloc((void**)&d_bgr, P * 3)); FG_CHK(hipMalloc((void**)&grey, P));
+    FG_CHK(hipMalloc((void**)&img[0], P)); FG_CHK(hipMalloc((void**)&img[1], P));
+    FG_CHK(hipMalloc((void**)&acc[0], P)); FG_CHK(hipMalloc((void**)&acc[1], P));
+    FG_CHK(hipMalloc((void**)&flow, P)); FG_CHK(hipMalloc((void**)&used, P));
+    FG_CHK(hipMalloc((void**)&masked, P)); FG_CHK(hipMalloc((void**)&out, P)); FG_CHK(hipMalloc((void**)&lut, 256));
+    FG_CHK(hipMalloc((void**)&tmp16, P * 2));
+    FG_CHK(hipMalloc((void**)&gw, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gv, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gm, P * 5 * 4));
+    FG_CHK(hipMalloc((void**)&hist, 256 * sizeof(unsigned)));
+    W = w; H = h;
+    return 0;
+}
+
+const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, int w, int h, hipStream_t s, const ForegroundDebugOut* dbg) {
+    if (ensure(w, h)) return nullptr;
+    const size_t P = (size_t)w * h;
+    const int n = (int)P;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e); };
+    auto stage_out = [&](int k, const uint8_t* d) {           // debug: copy one stage plane to the host (stream ordered)
+        if (dbg && dbg->stages) chk(hipMemcpyAsync(dbg->stages + (size_t)k * P, d, P, hipMemcpyDeviceToHost, s), "stage copy");
+    };
+    err.clear();
+    launch_bgr2gray(bgr, stride, grey, w, h, s);
+    chk(hipMemsetAsync(gw, 0, P * 20, s), "memset"); chk(hipMemsetAsync(gv, 0, P * 20, s), "memset");
+    chk(hipMemsetAsync(gm, 0, P * 20, s), "memset"); chk(hipMemsetAsync(used, 0, P, s), "memset");
+    chk(hipMemsetAsync(acc[0], 0, P, s), "memset");
+    const float acc_scale = (float)(1.0 / (12 / 2.0));       // flow * (1.0 / (iterations / 2.0)), iterations = 12
+    int nframes = 0;
+    auto mog2 = [&](const uint8_t* image, uint8_t* a) {
+        ++nframes;
+        const double lr = 1. / std::min(2 * nframes, 500);   // learningRate < 0 -> 1 / min(2 nframes, history)
+        launch_mog2(image, gw, gv, gm, used, (dbg && dbg->stages) ? flow : nullptr, a, n, (float)lr, (float)(-lr * 0.05f), acc_scale, s);
+    };
+    int cur = 0;                                              // acc[cur] is fgMask
+    mog2(grey, acc[cur]);
+    stage_out(0, flow); stage_out(1, acc[cur]);
+    const uint8_t* last = grey;
+    for (int i = 0; i < 12; ++i) {
+        uint8_t* med = img[i & 1];
+        const int ksize = i * 8 + 1;
+        if (ksize <= 1) chk(hipMemcpyAsync(med, last, P, hipMemcpyDeviceToDevice, s), "copy");
+        else launch_median_u8(last, med, w, h, ksize, s);
+        mog2(med, acc[cur]);
+        stage_out(2 + 4 * i, med); stage_out(3 + 4 * i, flow); stage_out(4 + 4 * i, acc[cur]);
+        launch_gauss23_u8(acc[cur], tmp16, acc[cur ^ 1], w, h, s);
+        cur ^= 1;
+        stage_out(5 + 4 * i, acc[cur]);
+        last = med;
+    }
+    float* dbg_floats = nullptr;
+    if (dbg && dbg->floats) {
+        if (!dbgf) chk(hipMalloc((void**)&dbgf, P * 12), "hipMalloc");
+        dbg_floats = dbgf;
+    }
+    launch_fg_tail(grey, acc[cur], logtab, masked, hist, lut, out, dbg_floats, n, s);
+    if (dbg) {
+        if (dbg->grey) chk(hipMemcpyAsync(dbg->grey, grey, P, hipMemcpyDeviceToHost, s), "copy");
+        if (dbg->masked) chk(hipMemcpyAsync(dbg->masked, masked, P, hipMemcpyDeviceToHost, s), "copy");
+        if (dbg->floats && dbgf) chk(hipMemcpyAsync(dbg->floats, dbgf, P * 12, hipMemcpyDeviceToHost, s), "copy");
+    }
+    chk(hipGetLastError(), "launch");
+    return err.empty() ? out : nullptr;
+}
+
+int ForegroundFilter::run(const uint8_t* bgr, size_t stride, int w, int h, hipStream_t s, uint8_t* dst, const ForegroundDebugOut* dbg) {
+    if (!bgr || !dst || w <= 0 || h <= 0 || stride < (size_t)w * 3) { err = "bad arguments"; return -1; }
+    if (ensure(w, h)) return -2;
+    FG_CHK(hipMemcpy2DAsync(d_bgr, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, s));
+    const uint8_t* r = run_device(d_bgr, (size_t)w * 3, w, h, s, dbg);
+    if (!r) return -2;
+    FG_CHK(hipMemcpyAsync(dst, r, (size_t)w * h, hipMemcpyDeviceToHost, s));
+    FG_CHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // namespace poppy_hip

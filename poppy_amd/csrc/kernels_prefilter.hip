@@ -1,0 +1,321 @@
+// kernels_prefilter.hip — pre-ORB filter chain, part 1: Extractor::foreground (src/extractor.cpp:136-229) on gfx950.
+//
+// Integer / per-pixel float work, HBM- or LDS-bound; no MFMA.  Arithmetic follows the reference's SSE3-baseline build
+// (this file is compiled with -ffp-contract=off; OCV = third/opencv-4.6.0/modules):
+//   k_bgr2gray        cvtColor(BGR2GRAY), 15-bit fixed point          OCV/imgproc/src/color_rgb.simd.hpp:646-730
+//   k_mog2            BackgroundSubtractorMOG2(500,16,true)::apply     OCV/video/src/bgfg_gaussmix2.cpp:479-523,539-755,847-884
+//                     + acc += flow * (1/6) (u8 convertTo, saturating add; matrix_expressions.cpp:270-275,1330-1336)
+//   k_median_u8       medianBlur, ksize 9..89, replicated border       OCV/imgproc/src/median_blur.simd.hpp (exact median)
+//   k_gauss23_h/_v    GaussianBlur 23x23 sigma 1, 8.8 fixed point      OCV/imgproc/src/smooth.simd.hpp:1136-1199,1780-1866
+//   k_fg_mask         u8 -> f32, *19 + 1, cv::log, / log 20, * grey, -> u8, histogram
+//                                                                      OCV/core/src/mathfuncs_core.simd.hpp:683-752
+//   k_equalize_lut / k_apply_lut   equalizeHist                        OCV/imgproc/src/histogram.cpp:3436-3493
+#include "kernels_prefilter.h"
+#include "pyramid_device.h"
+
+namespace poppy_hip {
+
+__global__ void __launch_bounds__(256) k_bgr2gray(const uint8_t* __restrict__ bgr, size_t stride, uint8_t* __restrict__ gray, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* p = bgr + (size_t)y * stride + (size_t)x * 3;
+    gray[(size_t)y * W + x] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+}
+void launch_bgr2gray(const uint8_t* bgr, size_t stride, uint8_t* gray, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL(k_bgr2gray, dim3((w + 255) / 256, h), dim3(256), 0, s, bgr, stride, gray, w, h);
+}
+
+// ---- MOG2 ---------------------------------------------------------------------------------------------------------
+// One thread per pixel; the model is structure-of-arrays [mode][pixel] so that every access is coalesced.  The five
+// modes live in registers for the duration of the update (sorting swaps become register moves).
+constexpr int kMog2Modes = 5;
+
+__global__ void __launch_bounds__(256) k_mog2(const uint8_t* __restrict__ img, float* __restrict__ gw, float* __restrict__ gv,
+                                              float* __restrict__ gm, uint8_t* __restrict__ used, uint8_t* __restrict__ flow_out,
+                                              uint8_t* __restrict__ acc, int n, float alphaT, float prune, float acc_scale) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float Tb = 16.f, TB = 0.9f, Tg = 9.f, varInit = 15.f, varMin = 4.f, varMax = 75.f, tau = 0.5f;
+    const float alpha1 = 1.f - alphaT;
+    float w[kMog2Modes], v[kMog2Modes], mu[kMog2Modes];
+    int nmodes = used[p];
+#pragma unroll
+    for (int k = 0; k < kMog2Modes; ++k) {
+        w[k] = gw[(size_t)k * n + p]; v[k] = gv[(size_t)k * n + p]; mu[k] = gm[(size_t)k * n + p];
+    }
+    const float data = (float)img[p];
+    bool background = false, fitsPDF = false;
+    float totalWeight = 0.f;
+#pragma unroll
+    for (int mode = 0; mode < kMog2Modes; ++mode) {
+        if (mode < nmodes) {                               // nmodes shrinks inside the loop when a mode is pruned
+            float wgt = alpha1 * w[mode] + prune;
+            int dst = mode;
+            if (!fitsPDF) {
+                const float var = v[mode];
+                const float dD = mu[mode] - data;
+                float dist2 = 0.f;
+                dist2 += dD * dD;
+                if (totalWeight < TB && dist2 < Tb * var) background = true;
+                if (dist2 < Tg * var) {
+                    fitsPDF = true;
+                    wgt += alphaT;
+                    const float k = __fdiv_rn(alphaT, wgt);
+                    mu[mode] -= k * dD;
+                    float varnew = var + k * (dist2 - var);
+                    varnew = fmaxf(varnew, varMin);
+                    varnew = fminf(varnew, varMax);
+                    v[mode] = varnew;
+#pragma unroll
+                    for (int i = kMog2Modes - 1; i > 0; --i) {   // bubble the matched mode up while its new weight is not smaller
+                        if (i <= dst && i == dst && !(wgt < w[i - 1])) {
+                            float t;
+                            t = w[i]; w[i] = w[i - 1]; w[i - 1] = t;
+                            t = v[i]; v[i] = v[i - 1]; v[i - 1] = t;
+                            t = mu[i]; mu[i] = mu[i - 1]; mu[i - 1] = t;
+                            --dst;
+                        }
+                    }
+                }
+            }
+            if (wgt < -prune) { wgt = 0.f; --nmodes; }
+            w[dst] = wgt;
+            totalWeight += wgt;
+        }
+    }
+    float invWeight = 0.f;
+    if (fabsf(totalWeight) > 1.1920928955078125e-7f) invWeight = __fdiv_rn(1.f, totalWeight);
+#pragma unroll
+    for (int mode = 0; mode < kMog2Modes; ++mode)
+        if (mode < nmodes) w[mode] *= invWeight;
+    if (!fitsPDF && alphaT > 0.f) {
+        const int mode = nmodes == kMog2Modes ? kMog2Modes - 1 : nmodes++;
+        if (nmodes == 1) {
+#pragma unroll
+            for (int k = 0; k < kMog2Modes; ++k) if (k == mode) w[k] = 1.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMog2Modes; ++k) {
+                if (k == mode) w[k] = alphaT;
+                else if (k < nmodes - 1) w[k] *= alpha1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kMog2Modes; ++k) if (k == mode) { mu[k] = data; v[k] = varInit; }
+        int pos = nmodes - 1;
+#pragma unroll
+        for (int i = kMog2Modes - 1; i > 0; --i) {
+            if (i == pos && !(alphaT < w[i - 1])) {
+                float t;
+                t = w[i]; w[i] = w[i - 1]; w[i - 1] = t;
+                t = v[i]; v[i] = v[i - 1]; v[i - 1] = t;
+                t = mu[i]; mu[i] = mu[i - 1]; mu[i - 1] = t;
+                --pos;
+            }
+        }
+    }
+    used[p] = (uint8_t)nmodes;
+#pragma unroll
+    for (int k = 0; k < kMog2Modes; ++k) {
+        gw[(size_t)k * n + p] = w[k]; gv[(size_t)k * n + p] = v[k]; gm[(size_t)k * n + p] = mu[k];
+    }
+    int out = 0;
+    if (!background) {
+        out = 255;
+        float tWeight = 0.f;                               // detectShadowGMM
+        bool done = false;
+#pragma unroll
+        for (int mode = 0; mode < kMog2Modes; ++mode) {
+            if (mode < nmodes && !done) {
+                float numerator = 0.f, denominator = 0.f;
+                numerator += data * mu[mode];
+                denominator += mu[mode] * mu[mode];
+                if (denominator == 0.f) done = true;
+                else {
+                    if (numerator <= denominator && numerator >= tau * denominator) {
+                        const float a = __fdiv_rn(numerator, denominator);
+                        float dist2a = 0.f;
+                        const float dDs = a * mu[mode] - data;
+                        dist2a += dDs * dDs;
+                        if (dist2a < Tb * v[mode] * a * a) { out = 127; done = true; }
+                    }
+                    if (!done) {
+                        tWeight += w[mode];
+                        if (tWeight > TB) done = true;
+                    }
+                }
+            }
+        }
+    }
+    if (flow_out) flow_out[p] = (uint8_t)out;
+    // fgMask += flow * (1/6): convertTo(u8, alpha) rounds to nearest even and saturates, then a saturating add
+    int t = cv_round_x86((float)out * acc_scale + 0.f);
+    t = t < 0 ? 0 : t > 255 ? 255 : t;
+    const int sum = acc[p] + t;
+    acc[p] = (uint8_t)(sum > 255 ? 255 : sum);
+}
+void launch_mog2(const uint8_t* img, float* gw, float* gv, float* gm, uint8_t* used, uint8_t* flow_or_null, uint8_t* acc,
+                 int n_px, float alphaT, float prune, float acc_scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_mog2, dim3((n_px + 255) / 256), dim3(256), 0, s, img, gw, gv, gm, used, flow_or_null, acc, n_px, alphaT, prune, acc_scale);
+}
+
+// ---- large-kernel median ---------------------------------------------------------------------------------------------
+// One lane = one image column, sliding DOWN a segment of rows.  Each lane keeps its own 256-bin histogram of the current
+// ksize x ksize window in LDS, laid out [bin][lane] so that the 64 lanes of a wave always hit 64 different banks-pairs
+// (an LDS access of a wave goes out as two halves of 32 lanes: no conflicts whatever the bins are), plus a 16-bin coarse
+// histogram for the search.  A step down = add one row of ksize values, remove one: 2*ksize global byte loads (adjacent
+// lanes read overlapping, consecutive addresses) and 4*ksize `ds_add` per lane, independent of the other lanes.  The
+// median is the first value whose cumulative count exceeds ksize^2 / 2: 16 coarse + 16 fine reads.
+constexpr int kMedLanes = 64;
+
+__global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H,
+                                                         int ksize, int rows_per_block) {
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* fine = lds_u32;                                 // [256][64]
+    uint32_t* coarse = lds_u32 + 256 * kMedLanes;             // [16][64]
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * kMedLanes + lane;
+    const int y_begin = blockIdx.y * rows_per_block, y_end = min(y_begin + rows_per_block, H);
+    const int r = ksize >> 1, half = (ksize * ksize) >> 1;
+    for (int b = 0; b < 256 + 16; ++b) lds_u32[b * kMedLanes + lane] = 0;
+    const bool live = x < W;                                  // lanes past the right edge idle along (no barriers in here)
+    const int xc = live ? x : W - 1;
+    auto row_ptr = [&](int yy) { return src + (size_t)min(max(yy, 0), H - 1) * W; };
+    auto add_row = [&](int yy, int delta) {
+        const uint8_t* row = row_ptr(yy);
+        for (int dx = -r; dx <= r; ++dx) {
+            const int v = row[min(max(xc + dx, 0), W - 1)];
+            atomicAdd(&fine[v * kMedLanes + lane], (uint32_t)delta);
+            atomicAdd(&coarse[(v >> 4) * kMedLanes + lane], (uint32_t)delta);
+        }
+    };
+    for (int yy = y_begin - r; yy <= y_begin + r; ++yy) add_row(yy, 1);
+    for (int y = y_begin; y < y_end; ++y) {
+        int s = 0, cb = 0, below = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {                        // first coarse bin whose cumulative count exceeds `half`
+            s += (int)coarse[c * kMedLanes + lane];
+            const bool hit = s > half;
+            cb += hit ? 0 : 1;
+            below = hit ? below : s;
+        }
+        int fb = 0;
+        s = below;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s += (int)fine[(cb * 16 + k) * kMedLanes + lane];
+            fb += (s > half) ? 0 : 1;
+        }
+        if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
+        if (y + 1 < y_end) { add_row(y - r, -1); add_row(y + r + 1, 1); }
+    }
+}
+void launch_median_u8(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
+    // segments of rows: each pays a ksize-row warm-up, so make them longer for bigger windows, but keep >= ~256 waves
+    const int col_blocks = (w + kMedLanes - 1) / kMedLanes;
+    int segs = std::max(1, 512 / col_blocks);
+    int rows = std::max((h + segs - 1) / segs, std::min(h, 2 * ksize));
+    segs = (h + rows - 1) / rows;
+    const size_t lds = (size_t)(256 + 16) * kMedLanes * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_median_u8, dim3(col_blocks, segs), dim3(kMedLanes), lds, s, src, dst, w, h, ksize, rows);
+}
+bool prepare_median_u8() {
+    return hipFuncSetAttribute((const void*)k_median_u8, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((256 + 16) * kMedLanes * sizeof(uint32_t))) == hipSuccess;
+}
+
+// ---- GaussianBlur 23x23, sigma 1, 8 bit: taps 1 14 62 102 62 14 1 (the other 16 taps are 0 in 8.8 fixed point) ------------
+__constant__ int c_g7[7] = {1, 14, 62, 102, 62, 14, 1};
+
+__global__ void __launch_bounds__(256) k_gauss23_h(const uint8_t* __restrict__ src, uint16_t* __restrict__ dst, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* row = src + (size_t)y * W;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (uint32_t)c_g7[k] * row[reflect101(x + k - 3, W)];
+    dst[(size_t)y * W + x] = (uint16_t)s;                     // <= 255 * 256: fits
+}
+__global__ void __launch_bounds__(256) k_gauss23_v(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (uint32_t)c_g7[k] * src[(size_t)reflect101(y + k - 3, H) * W + x];
+    const uint32_t v = (s + (1u << 15)) >> 16;
+    dst[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s) {
+    dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_gauss23_h, grid, dim3(256), 0, s, src, tmp, w, h);
+    hipLaunchKernelGGL(k_gauss23_v, grid, dim3(256), 0, s, tmp, dst, w, h);
+}
+
+// ---- log mask, multiply, 8 bit, histogram --------------------------------------------------------------------------------
+// cv::log for floats: 256-entry table of (ln(1 + i/256), 1/(1 + i/256)) — the last entry is (ln 2, 1/2) with the argument
+// shifted by -1/512 — and a cubic; the table is computed on the host in long double and handed over as floats.
+__device__ __forceinline__ float cv_log32f(float x, const float* __restrict__ tab) {
+    const float A0 = 0.3333333333333333333333333f, A1 = -0.5f, A2 = 1.f;
+    const float ln2 = (float)0.69314718055994530941723212145818;
+    const int i0 = __float_as_int(x);
+    const float bf = __int_as_float((i0 & ((1 << 15) - 1)) | (127 << 23));
+    const int idx = (i0 >> 14) & 510;
+    const float y0 = (float)(((i0 >> 23) & 0xff) - 127) * ln2 + tab[idx];
+    const float x0 = (bf - 1.f) * tab[idx + 1] + (idx == 510 ? -1.f / 512 : 0.f);
+    return ((A0 * x0 + A1) * x0 + A2) * x0 + y0;
+}
+
+__global__ void __launch_bounds__(256) k_fg_mask(const uint8_t* __restrict__ grey, const uint8_t* __restrict__ fg, const float* __restrict__ tab,
+                                                 uint8_t* __restrict__ masked, unsigned* __restrict__ hist, float* __restrict__ dbg, int n) {
+    __shared__ unsigned lh[256];
+    __shared__ float ltab[512];
+    lh[threadIdx.x] = 0;
+    ltab[threadIdx.x] = tab[threadIdx.x]; ltab[threadIdx.x + 256] = tab[threadIdx.x + 256];
+    __syncthreads();
+    const float ln20 = cv_log32f(20.f, ltab);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const float g = (float)grey[p] * kInv255 + 0.f;        // convertTo(CV_32F, 1/255)
+        const float m = (float)fg[p] * kInv255 + 0.f;
+        const float lin = m * 19.f + 1.f;                      // convertTo(CV_32F, 19, 1)
+        const float lg = cv_log32f(lin, ltab);
+        const float fin = __fdiv_rn(lg, ln20);
+        const float mk = g * fin;
+        const uint8_t o = sat_u8(cv_round_x86(mk * 255.f + 0.f));
+        masked[p] = o;
+        atomicAdd(&lh[o], 1u);
+        if (dbg) { dbg[p] = lin; dbg[(size_t)n + p] = lg; dbg[2 * (size_t)n + p] = fin; }
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// lut[i] = saturate(round(sum_{first < j <= i} hist[j] * 255 / (total - hist[first]))); a constant image maps to itself
+__global__ void k_equalize_lut(const unsigned* __restrict__ hist, int total, uint8_t* __restrict__ lut) {
+    if (threadIdx.x != 0) return;
+    int i = 0;
+    while (!hist[i]) ++i;
+    if ((int)hist[i] == total) { for (int k = 0; k < 256; ++k) lut[k] = (uint8_t)i; return; }
+    const float scale = __fdiv_rn(256 - 1.f, (float)(total - (int)hist[i]));
+    for (int k = 0; k <= i; ++k) lut[k] = 0;
+    int sum = 0;
+    for (++i; i < 256; ++i) {
+        sum += (int)hist[i];
+        lut[i] = sat_u8(cv_round_x86((float)sum * scale));
+    }
+}
+__global__ void __launch_bounds__(256) k_apply_lut(const uint8_t* __restrict__ src, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int n) {
+    __shared__ uint8_t l[256];
+    l[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) dst[p] = l[src[p]];
+}
+void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
+                    uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s) {
+    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);
+    const int blocks = std::min((n_px + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_fg_mask, dim3(blocks), dim3(256), 0, s, grey, fg, d_logtab, masked, hist, dbg_or_null, n_px);
+    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(64), 0, s, hist, n_px, lut);
+    hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, masked, lut, out, n_px);
+}
+
+}  // namespace poppy_hip

@@ -18,6 +18,7 @@
 //   out               u8x3   3P          the frame (chained mode feeds it to the next slot as c1)
 // No CPU fallback exists in this library: every entry point either runs the kernels or fails.
 #include "../../include/poppy_hip.h"
+#include "foreground.h"
 #include "frame_plan.h"
 #include "kernels.h"
 #include "orb_detect.h"
@@ -87,6 +88,7 @@ struct poppy_hip_ctx {
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
     OrbDetector orb;
+    ForegroundFilter foreground;
     double initial_morph_dist = 0;
     // diagnostics
     bool debug = false;
@@ -767,9 +769,20 @@ int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* c, const uint8_t* bgr1, size
     return poppy_hip_pair_load(c, bgr1, s1, bgr2, s2, gabor2, W, H, o1.data(), o2.data(), m);
 }
 
+int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, uint8_t* out, const poppy_foreground_debug* dbg) {
+    if (!c) return POPPY_E_ARG;
+    if (!bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    ForegroundDebugOut d;
+    if (dbg) { d.grey = dbg->grey; d.stages = dbg->stages; d.floats = dbg->floats; d.masked = dbg->masked; }
+    const int rc = c->foreground.run(bgr, stride, W, H, c->stream, out, dbg ? &d : nullptr);
+    if (rc) { c->err = "foreground: " + c->foreground.err; return rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
 int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t*, size_t, const uint8_t*, size_t, int, int) {
     if (!c) return POPPY_E_ARG;
-    return fail(c, POPPY_E_UNSUPPORTED, "the pre-ORB filter chain (MOG2 / median / Gabor / dft_detail2) is not part of this round; "
+    return fail(c, POPPY_E_UNSUPPORTED, "of the pre-ORB filter chain only Extractor::foreground is on the GPU (poppy_hip_foreground); dft_detail2 and the Gabor bank are not yet: "
                                         "use poppy_hip_pair_begin_prefiltered");
 }
 
