@@ -22,10 +22,10 @@ ForegroundFilter::~ForegroundFilter() {
 }
 
 void ForegroundFilter::release() {
-    void* bufs[] = {d_bgr, grey, img[0], img[1], acc[0], acc[1], flow, used, masked, out, lut, tmp16, gw, gv, gm, dbgf, hist};
+    void* bufs[] = {padded, d_bgr, grey, img[0], img[1], acc[0], acc[1], flow, used, masked, out, lut, tmp16, gw, gv, gm, dbgf, hist};
     for (void* b : bufs) if (b) (void)hipFree(b);
     d_bgr = grey = img[0] = img[1] = acc[0] = acc[1] = flow = used = masked = out = lut = nullptr;
-    tmp16 = nullptr; gw = gv = gm = dbgf = nullptr; hist = nullptr;
+    tmp16 = nullptr; padded = nullptr; gw = gv = gm = dbgf = nullptr; hist = nullptr;
     W = H = 0;
 }
 
@@ -56,6 +56,7 @@ int ForegroundFilter::ensure(int w, int h) {
     FG_CHK(hipMalloc((void**)&flow, P)); FG_CHK(hipMalloc((void**)&used, P));
     FG_CHK(hipMalloc((void**)&masked, P)); FG_CHK(hipMalloc((void**)&out, P)); FG_CHK(hipMalloc((void**)&lut, 256));
     FG_CHK(hipMalloc((void**)&tmp16, P * 2));
+    FG_CHK(hipMalloc((void**)&padded, median_padded_bytes(w, h)));
     FG_CHK(hipMalloc((void**)&gw, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gv, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gm, P * 5 * 4));
     FG_CHK(hipMalloc((void**)&hist, 256 * sizeof(unsigned)));
     W = w; H = h;
@@ -90,7 +91,7 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
         uint8_t* med = img[i & 1];
         const int ksize = i * 8 + 1;
         if (ksize <= 1) chk(hipMemcpyAsync(med, last, P, hipMemcpyDeviceToDevice, s), "copy");
-        else launch_median_u8(last, med, w, h, ksize, s);
+        else launch_median_u8(last, padded, med, w, h, ksize, s);
         mog2(med, acc[cur]);
         stage_out(2 + 4 * i, med); stage_out(3 + 4 * i, flow); stage_out(4 + 4 * i, acc[cur]);
         launch_gauss23_u8(acc[cur], tmp16, acc[cur ^ 1], w, h, s);

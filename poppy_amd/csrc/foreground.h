@@ -31,6 +31,7 @@ private:
     uint8_t *d_bgr = nullptr, *grey = nullptr, *img[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr}, *flow = nullptr;
     uint8_t *used = nullptr, *masked = nullptr, *out = nullptr, *lut = nullptr;
     uint16_t* tmp16 = nullptr;
+    uint8_t* padded = nullptr;           // median source with replicated side columns
     float *gw = nullptr, *gv = nullptr, *gm = nullptr, *logtab = nullptr, *dbgf = nullptr;
     unsigned* hist = nullptr;
     bool prepared = false;

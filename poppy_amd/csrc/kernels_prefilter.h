@@ -18,7 +18,9 @@ void launch_mog2(const uint8_t* img, float* gw, float* gv, float* gm, uint8_t* u
 
 // medianBlur(src, dst, ksize) for odd ksize >= 3 on a 1-channel 8-bit image (replicated border, exact median)
 bool prepare_median_u8();               // raises the kernel's LDS limit once; call outside stream capture
-void launch_median_u8(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, hipStream_t s);
+// padded_tmp: median_padded_bytes(w, h) bytes of scratch (the source with replicated side columns)
+size_t median_padded_bytes(int w, int h);
+void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s);
 
 // GaussianBlur(src, dst, 23x23, sigma 1) on 8 bit (the fixed-point path); tmp = w*h uint16
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);

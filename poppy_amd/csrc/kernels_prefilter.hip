@@ -161,68 +161,125 @@ void launch_mog2(const uint8_t* img, float* gw, float* gv, float* gm, uint8_t* u
 
 // ---- large-kernel median ---------------------------------------------------------------------------------------------
 // One lane = one image column, sliding DOWN a segment of rows.  Each lane keeps its own 256-bin histogram of the current
-// ksize x ksize window in LDS, laid out [bin][lane] so that the 64 lanes of a wave always hit 64 different banks-pairs
-// (an LDS access of a wave goes out as two halves of 32 lanes: no conflicts whatever the bins are), plus a 16-bin coarse
-// histogram for the search.  A step down = add one row of ksize values, remove one: 2*ksize global byte loads (adjacent
-// lanes read overlapping, consecutive addresses) and 4*ksize `ds_add` per lane, independent of the other lanes.  The
-// median is the first value whose cumulative count exceeds ksize^2 / 2: 16 coarse + 16 fine reads.
+// ksize x ksize window in LDS, laid out [bin pair][lane] so that the 64 lanes of a wave always hit different banks (an LDS
+// access of a wave goes out as two halves of 32 lanes: no conflicts whatever the bins are), plus a 16-bin coarse
+// histogram for the search.  Counts are at most 89^2 < 2^16, so two bins share a dword (34 KB per wave instead of 68:
+// four waves per CU); a count never goes negative, so adding / subtracting 1 << 16 never borrows across the halves.
+// A step down = add one row of ksize values, remove one: the two rows are read as unaligned dwords (adjacent lanes read
+// overlapping, consecutive addresses), 8 bytes of each per trip so that the loads are in flight together, and every byte
+// costs two `ds_add`/`ds_sub`.  The median is the first value whose cumulative count exceeds ksize^2 / 2: 16 coarse +
+// 16 fine reads.
 constexpr int kMedLanes = 64;
+constexpr int kMedWords = 128 + 8;                         // dwords per lane: 256 fine bins + 16 coarse bins, two per dword
 
-__global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H,
+__device__ __forceinline__ void med_update(uint32_t* __restrict__ hist, int lane, int v, bool add) {
+    uint32_t* f = &hist[(v >> 1) * kMedLanes + lane];
+    uint32_t* c = &hist[(128 + (v >> 5)) * kMedLanes + lane];
+    const uint32_t df = 1u << ((v & 1) << 4), dc = 1u << (((v >> 4) & 1) << 4);
+    if (add) { atomicAdd(f, df); atomicAdd(c, dc); }
+    else     { atomicSub(f, df); atomicSub(c, dc); }
+}
+
+// The source is first copied into a buffer with kMedPad replicated columns on either side (k_pad_cols), so that every
+// lane reads its window row as plain unaligned dwords without clamping; rows are clamped through the row pointer.
+constexpr int kMedPad = 48;                                 // >= 44 (ksize 89) + 3 spare bytes for the last dword
+constexpr int kMedMaxDw = 23;                               // dwords covering 89 bytes
+
+__global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
+    const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int Wp = W + 2 * kMedPad;
+    if (xp >= Wp) return;
+    dst[(size_t)y * Wp + xp] = src[(size_t)y * W + min(max(xp - kMedPad, 0), W - 1)];
+}
+
+__global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
                                                          int ksize, int rows_per_block) {
-    extern __shared__ uint32_t lds_u32[];
-    uint32_t* fine = lds_u32;                                 // [256][64]
-    uint32_t* coarse = lds_u32 + 256 * kMedLanes;             // [16][64]
+    __shared__ uint32_t hist[kMedWords * kMedLanes];
     const int lane = threadIdx.x;
     const int x = blockIdx.x * kMedLanes + lane;
     const int y_begin = blockIdx.y * rows_per_block, y_end = min(y_begin + rows_per_block, H);
     const int r = ksize >> 1, half = (ksize * ksize) >> 1;
-    for (int b = 0; b < 256 + 16; ++b) lds_u32[b * kMedLanes + lane] = 0;
+    const int Wp = W + 2 * kMedPad;
+    for (int b = 0; b < kMedWords; ++b) hist[b * kMedLanes + lane] = 0;
     const bool live = x < W;                                  // lanes past the right edge idle along (no barriers in here)
     const int xc = live ? x : W - 1;
-    auto row_ptr = [&](int yy) { return src + (size_t)min(max(yy, 0), H - 1) * W; };
-    auto add_row = [&](int yy, int delta) {
-        const uint8_t* row = row_ptr(yy);
-        for (int dx = -r; dx <= r; ++dx) {
-            const int v = row[min(max(xc + dx, 0), W - 1)];
-            atomicAdd(&fine[v * kMedLanes + lane], (uint32_t)delta);
-            atomicAdd(&coarse[(v >> 4) * kMedLanes + lane], (uint32_t)delta);
+    const int ndw = (ksize + 3) >> 2;                         // dwords per window row (the last one is partly used)
+    const int tail = ksize - 4 * (ndw - 1);                   // bytes used of the last dword
+    auto row_ptr = [&](int yy) { return srcp + (size_t)min(max(yy, 0), H - 1) * Wp + (kMedPad + xc - r); };
+    auto load_row = [&](const uint8_t* p, uint32_t* regs) {
+#pragma unroll
+        for (int i = 0; i < kMedMaxDw; ++i)
+            if (i < ndw) __builtin_memcpy(&regs[i], p + 4 * i, 4);
+    };
+    auto apply_row = [&](const uint32_t* regs, bool add) {
+#pragma unroll
+        for (int i = 0; i < kMedMaxDw; ++i) {
+            if (i < ndw) {
+                const int nb = (i == ndw - 1) ? tail : 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nb) med_update(hist, lane, (regs[i] >> (8 * k)) & 255, add);
+            }
         }
     };
-    for (int yy = y_begin - r; yy <= y_begin + r; ++yy) add_row(yy, 1);
+    uint32_t ra[kMedMaxDw], rs[kMedMaxDw];
+    // warm-up: rows y_begin - r .. y_begin + r, loaded one ahead of the row being applied
+    load_row(row_ptr(y_begin - r), ra);
+    for (int yy = y_begin - r; yy <= y_begin + r; ++yy) {
+        uint32_t cur[kMedMaxDw];
+#pragma unroll
+        for (int i = 0; i < kMedMaxDw; ++i) cur[i] = ra[i];
+        if (yy < y_begin + r) load_row(row_ptr(yy + 1), ra);
+        apply_row(cur, true);
+    }
+    if (y_begin + 1 < y_end) { load_row(row_ptr(y_begin + r + 1), ra); load_row(row_ptr(y_begin - r), rs); }
     for (int y = y_begin; y < y_end; ++y) {
         int s = 0, cb = 0, below = 0;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {                        // first coarse bin whose cumulative count exceeds `half`
-            s += (int)coarse[c * kMedLanes + lane];
-            const bool hit = s > half;
-            cb += hit ? 0 : 1;
-            below = hit ? below : s;
+        for (int c = 0; c < 8; ++c) {                         // first coarse bin whose cumulative count exceeds `half`
+            const uint32_t wv = hist[(128 + c) * kMedLanes + lane];
+#pragma unroll
+            for (int hv = 0; hv < 2; ++hv) {
+                s += (int)((wv >> (16 * hv)) & 0xffff);
+                const bool hit = s > half;
+                cb += hit ? 0 : 1;
+                below = hit ? below : s;
+            }
         }
         int fb = 0;
         s = below;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            s += (int)fine[(cb * 16 + k) * kMedLanes + lane];
-            fb += (s > half) ? 0 : 1;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t wv = hist[(cb * 8 + k) * kMedLanes + lane];
+#pragma unroll
+            for (int hv = 0; hv < 2; ++hv) {
+                s += (int)((wv >> (16 * hv)) & 0xffff);
+                fb += (s > half) ? 0 : 1;
+            }
         }
         if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
-        if (y + 1 < y_end) { add_row(y - r, -1); add_row(y + r + 1, 1); }
+        if (y + 1 < y_end) {
+            uint32_t ca[kMedMaxDw], cs[kMedMaxDw];
+#pragma unroll
+            for (int i = 0; i < kMedMaxDw; ++i) { ca[i] = ra[i]; cs[i] = rs[i]; }
+            if (y + 2 < y_end) { load_row(row_ptr(y + r + 2), ra); load_row(row_ptr(y + 1 - r), rs); }   // rows of the NEXT step
+            apply_row(ca, true);
+            apply_row(cs, false);
+        }
     }
 }
-void launch_median_u8(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
-    // segments of rows: each pays a ksize-row warm-up, so make them longer for bigger windows, but keep >= ~256 waves
+void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
+    const int wp = w + 2 * kMedPad;
+    hipLaunchKernelGGL(k_pad_cols, dim3((wp + 255) / 256, h), dim3(256), 0, s, src, padded_tmp, w, h);
+    // segments of rows: each pays a ksize-row warm-up, so make them longer for bigger windows, but keep ~1000 waves
     const int col_blocks = (w + kMedLanes - 1) / kMedLanes;
-    int segs = std::max(1, 512 / col_blocks);
-    int rows = std::max((h + segs - 1) / segs, std::min(h, 2 * ksize));
+    int segs = std::max(1, 1024 / col_blocks);
+    int rows = std::max((h + segs - 1) / segs, std::min(h, ksize));
     segs = (h + rows - 1) / rows;
-    const size_t lds = (size_t)(256 + 16) * kMedLanes * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_median_u8, dim3(col_blocks, segs), dim3(kMedLanes), lds, s, src, dst, w, h, ksize, rows);
+    hipLaunchKernelGGL(k_median_u8, dim3(col_blocks, segs), dim3(kMedLanes), 0, s, padded_tmp, dst, w, h, ksize, rows);
 }
-bool prepare_median_u8() {
-    return hipFuncSetAttribute((const void*)k_median_u8, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((256 + 16) * kMedLanes * sizeof(uint32_t))) == hipSuccess;
-}
+size_t median_padded_bytes(int w, int h) { return (size_t)(w + 2 * kMedPad) * h + 16; }
+bool prepare_median_u8() { return true; }
 
 // ---- GaussianBlur 23x23, sigma 1, 8 bit: taps 1 14 62 102 62 14 1 (the other 16 taps are 0 in 8.8 fixed point) ------------
 __constant__ int c_g7[7] = {1, 14, 62, 102, 62, 14, 1};
