@@ -271,10 +271,12 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
 void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
     const int wp = w + 2 * kMedPad;
     hipLaunchKernelGGL(k_pad_cols, dim3((wp + 255) / 256, h), dim3(256), 0, s, src, padded_tmp, w, h);
-    // segments of rows: each pays a ksize-row warm-up, so make them longer for bigger windows, but keep ~1000 waves
+    // Segments of rows.  A segment pays a ksize-row warm-up, so longer is cheaper in total work; but a wave is a long
+    // serial instruction stream and 35 KB of LDS limits a CU to 4 of them, so the time is that of ONE segment as long as
+    // there are no more than ~1000: aim for that many, never shorter than ksize / 2 rows.
     const int col_blocks = (w + kMedLanes - 1) / kMedLanes;
     int segs = std::max(1, 1024 / col_blocks);
-    int rows = std::max((h + segs - 1) / segs, std::min(h, ksize));
+    int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
     hipLaunchKernelGGL(k_median_u8, dim3(col_blocks, segs), dim3(kMedLanes), 0, s, padded_tmp, dst, w, h, ksize, rows);
 }
