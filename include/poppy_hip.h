@@ -143,11 +143,24 @@ int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* ctx,
                                      const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                                      const uint8_t* orb_input1, const uint8_t* orb_input2, const float* gabor2_f32x3,
                                      int width, int height, int nfeatures);
-/* Same from the raw BGR pair, including the reference's pre-ORB filter chain (MOG2 foreground, medians,
- * Gabor banks, dft_detail2; src/extractor.cpp:33-83,136-229).  That chain is outside this round's scope
- * (SURVEY.md 8f-1): the call returns POPPY_E_UNSUPPORTED instead of approximating it.                  */
+/* Same from the raw BGR pair (the set-up half of poppy::morph, src/poppy.hpp:46-157 with face detection and auto-align
+ * off): Extractor::foreground x2 -> dft_detail2 x2 -> nfeatures = int(max_keypoints * 255 / max(d1, d2)) -> unsharp(sigma 2),
+ * grey, 31x31 Gabor bank, radial gradient, equalizeHist -> ORB x2 -> matcher -> gabor_filter(image2 / 255) -> resident pair.
+ * Parity: every stage is bit-exact with the reference EXCEPT the two Gabor banks and the 2-D DFT, which OpenCV evaluates
+ * through FFTs (filter2D's DFT path, cv::dft): their float rounding depends on the butterfly order and is reproduced here
+ * to ~1e-6 only, so a few ORB-input pixels differ by one level and a few keypoints / frames can differ from the reference's
+ * (measured in DESIGN.md section 7).  poppy_hip_pair_begin_prefiltered stays bit-exact end to end.                     */
 int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                          int width, int height);
+/* nfeatures and the two dft_detail2 values of the last poppy_hip_pair_begin */
+int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail2);
+/* Pieces of the chain, host in / host out, for tests and for callers that cache intermediates:
+ * poppy_hip_orb_input: goodFeatures (w*h) -> g = the ORB input image; optional us (grey of the unsharp-masked image), gb (Gabor
+ * mean), detail (dft_detail2).  poppy_hip_gabor_field: gabor_filter(bgr / 255) with the default arguments -> f32x3.
+ * poppy_radial_gradient: draw_radial_gradiant2 (src/draw.cpp:40-59), host only.                                        */
+int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
+int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
+int poppy_radial_gradient(int width, int height, float* out);
 /* copies of the resident point sets after pair_begin / pair_load (n x 2 floats each); n via *n_points */
 int poppy_hip_pair_points(poppy_hip_ctx* ctx, float* points1, float* points2, int max_points, int* n_points);
 

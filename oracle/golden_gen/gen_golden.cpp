@@ -392,6 +392,7 @@ static void dump_astage() {
         cvtColor(us, us, COLOR_BGR2GRAY);
         Mat radial = draw_radial_gradiant2(us.cols, us.rows);
         gabor_filter(us, gg, 16, 31, 5, 2, 0.04, CV_PI / 4);
+        if (i == 0) { dump_mat("us1", us); dump_mat("gb1", gg); }
         multiply(gg, us, gg);
         multiply(gg, radial, gg);
         gg.convertTo(gg, CV_8U, 255.0);
@@ -400,6 +401,14 @@ static void dump_astage() {
         if (i == 0) dump_mat("radial", radial);
     }
     dump_mat("g1", g[0]); dump_mat("g2", g[1]);
+    {
+        Mat k17 = getGaussianKernel(17, 2, CV_32F);          // unsharp_mask(.., 2, ..) -> GaussianBlur(Size(0,0), 2) on float
+        dump_mat("gauss17", k17);
+        Mat gk0 = getGaborKernel(Size(31, 31), 5, 0 * 11.0, 2, 0.04, CV_PI / 4, CV_32F);
+        Mat gk5 = getGaborKernel(Size(31, 31), 5, 5 * 11.0, 2, 0.04, CV_PI / 4, CV_32F);
+        Mat gs3 = getGaborKernel(Size(13, 13), 5, 3 * 11.0, 10, 0.04, CV_PI / 4, CV_32F);
+        dump_mat("gaborK31_0", gk0); dump_mat("gaborK31_5", gk5); dump_mat("gaborK13_3", gs3);
+    }
     auto kps = ex.keypoints();
     {
         Ptr<ORB> orb = ORB::create(nfeatures);

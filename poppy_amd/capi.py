@@ -28,7 +28,7 @@ SYMBOLS = [
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_pair_points",
 ]
 
 
@@ -69,6 +69,11 @@ def lib():
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
         L.poppy_hip_foreground.argtypes = [vp, vp, sz, i, i, vp, vp]
+        L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
+        L.poppy_hip_pair_begin_info.argtypes = [vp, vp, vp]
+        L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
+        L.poppy_hip_gabor_field.argtypes = [vp, vp, sz, i, i, vp]
+        L.poppy_radial_gradient.argtypes = [i, i, vp]
         L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
         L.poppy_hip_hamming_match.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.poppy_match_points.argtypes = [vp, vp, i, i, i, d, vp, vp, vp, vp]
@@ -102,6 +107,15 @@ def plan_frame(w, h, p1, p2, shape):
         raise PoppyError(f"poppy_plan_frame: {rc}")
     t = nt.value
     return dict(idx3=idx3[:t], tri_xy=tri[:t], M1=M1[:t], M2=M2[:t], inv1=i1[:t], inv2=i2[:t], morphed=mp)
+
+
+def radial_gradient(w, h):
+    """draw_radial_gradiant2 (host only)."""
+    out = np.zeros((h, w), np.float32)
+    rc = lib().poppy_radial_gradient(w, h, _p(out))
+    if rc:
+        raise PoppyError(f"poppy_radial_gradient: {rc}")
+    return out
 
 
 def match_points(p1, p2, w, h, tolerance=1.0):
@@ -203,6 +217,29 @@ class Context:
         for k in range(12):
             res[f"med{k + 1}"], res[f"flow{k + 1}"], res[f"acc{k + 1}"], res[f"blur{k + 1}"] = stages[2 + 4 * k: 6 + 4 * k]
         return res
+
+    def pair_begin(self, bgr1, bgr2):
+        """Raw BGR pair -> resident pair (pre-ORB chain, ORB, matcher, gabor2 on the GPU). Returns (nfeatures, (d1, d2))."""
+        a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
+        h, w = a.shape[:2]
+        self._chk(lib().poppy_hip_pair_begin(self.h, _p(a), w * 3, _p(b), w * 3, w, h), "pair_begin")
+        nf = C.c_int(0); d = (C.c_double * 2)()
+        lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), d)
+        return nf.value, (d[0], d[1])
+
+    def orb_input(self, good_features):
+        gf = np.ascontiguousarray(good_features, np.uint8)
+        h, w = gf.shape
+        g = np.zeros((h, w), np.uint8); us = np.zeros((h, w), np.float32); gb = np.zeros((h, w), np.float32); d = C.c_double(0)
+        self._chk(lib().poppy_hip_orb_input(self.h, _p(gf), w, h, _p(g), _p(us), _p(gb), C.byref(d)), "orb_input")
+        return dict(g=g, us=us, gb=gb, detail=d.value)
+
+    def gabor_field(self, bgr):
+        a = np.ascontiguousarray(bgr, np.uint8)
+        h, w = a.shape[:2]
+        out = np.zeros((h, w, 3), np.float32)
+        self._chk(lib().poppy_hip_gabor_field(self.h, _p(a), w * 3, w, h, _p(out)), "gabor_field")
+        return out
 
     def orb_describe(self, gray, kps7):
         g = np.ascontiguousarray(gray, np.uint8)

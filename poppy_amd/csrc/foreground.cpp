@@ -18,6 +18,7 @@ namespace poppy_hip {
 
 ForegroundFilter::~ForegroundFilter() {
     release();
+    release2();
     if (logtab) (void)hipFree(logtab);
 }
 

@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace poppy_hip {
 
@@ -15,6 +16,9 @@ struct ForegroundDebugOut {          // host pointers, each may be null
     uint8_t* masked = nullptr;       // w*h
 };
 
+// draw_radial_gradiant2 (src/draw.cpp:40-59), host
+void radial_gradient(int width, int height, std::vector<float>& out);
+
 class ForegroundFilter {
 public:
     ~ForegroundFilter();
@@ -22,11 +26,28 @@ public:
     int run(const uint8_t* bgr, size_t stride, int w, int h, hipStream_t s, uint8_t* out, const ForegroundDebugOut* dbg);
     // same, from / to device memory (bgr device pointer with `stride`), result left in device memory and returned
     const uint8_t* run_device(const uint8_t* d_bgr, size_t stride, int w, int h, hipStream_t s, const ForegroundDebugOut* dbg);
+    // --- part 2 (foreground2.cpp): everything between goodFeatures and the ORB input, gabor2, dft_detail2 ---------------
+    int detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out);
+    const uint8_t* orb_input(const uint8_t* d_gf, int w, int h, int which, hipStream_t s, float* h_us = nullptr, float* h_gb = nullptr);
+    const float* gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s);
+    uint8_t* bgr_staging() { return d_bgr; }         // w*h*3 bytes once ensure() ran
+    int prepare(int w, int h) { return ensure(w, h); }
     std::string err;
 
 private:
     int ensure(int w, int h);
+    int ensure2(int w, int h);
     void release();
+    void release2();
+    int W2 = 0, H2 = 0, dftN = 0, dftM = 0;
+    float *f_a = nullptr, *f_b = nullptr, *f_c = nullptr, *f_d = nullptr, *radial = nullptr, *bank31 = nullptr, *bank13 = nullptr, *taps17 = nullptr;
+    float *mag = nullptr, *c3_in = nullptr, *c3_out = nullptr;
+    void* spec = nullptr;
+    unsigned* minmax = nullptr;
+    unsigned long long* powsum = nullptr;
+    uint8_t *g_tmp = nullptr, *g_out[2] = {nullptr, nullptr};
+    void* fft_plan = nullptr;
+    bool plan_ok = false;
     int W = 0, H = 0;
     uint8_t *d_bgr = nullptr, *grey = nullptr, *img[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr}, *flow = nullptr;
     uint8_t *used = nullptr, *masked = nullptr, *out = nullptr, *lut = nullptr;

@@ -1,0 +1,176 @@
+// foreground2.cpp — host side of the rest of the pre-ORB chain (ForegroundFilter::orb_inputs / gabor_field / detail):
+// Extractor::keypoints up to the detector call (src/extractor.cpp:33-78), gabor_filter(corrected2 / 255) (src/poppy.hpp:119-122,
+// src/util.cpp:40-60) and dft_detail2 (src/experiments.hpp:267-318).  Kernel tables that the reference computes with libm
+// in double (Gaussian taps, Gabor kernels, the radial gradient) are computed here the same way and uploaded.
+#include "foreground.h"
+#include "kernels_prefilter.h"
+#include <hipfft/hipfft.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace poppy_hip {
+
+#define F2_CHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } \
+    } while (0)
+
+// cv::getGaussianKernel(n, sigma, CV_32F) for n > 7 (OCV/imgproc/src/smooth.dispatch.cpp:81-221): exp(-x^2 / 2 sigma^2)
+// normalised by the sum, evaluated in double, stored as float (checked against the reference's taps, tests/golden a_*: gauss17)
+static void gaussian_taps(int n, double sigma, std::vector<float>& out) {
+    std::vector<double> v(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2 * sigma * sigma)); sum += v[i]; }
+    out.resize(n);
+    for (int i = 0; i < n; ++i) out[i] = (float)(v[i] / sum);
+}
+
+// cv::getGaborKernel(Size(ks, ks), sigma, theta, lambd, gamma, psi, CV_32F)  (OCV/imgproc/src/gabor.cpp:50-95)
+static void gabor_kernel(int ks, double sigma, double theta, double lambd, double gamma, double psi, float* out) {
+    const double sigma_x = sigma, sigma_y = sigma / gamma;
+    const double c = std::cos(theta), s = std::sin(theta);
+    const int xmax = ks / 2, ymax = ks / 2, xmin = -xmax, ymin = -ymax;
+    const double scale = 1, ex = -0.5 / (sigma_x * sigma_x), ey = -0.5 / (sigma_y * sigma_y), cscale = M_PI * 2 / lambd;
+    for (int y = ymin; y <= ymax; ++y)
+        for (int x = xmin; x <= xmax; ++x) {
+            const double xr = x * c + y * s, yr = -x * s + y * c;
+            const double v = scale * std::exp(ex * xr * xr + ey * yr * yr) * std::cos(cscale * xr + psi);
+            out[(ymax - y) * ks + (xmax - x)] = (float)v;
+        }
+}
+// gabor_filter's bank: theta_i = i * float(180 / numAngles) used as radians (src/util.cpp:40-47)
+static void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank) {
+    bank.resize((size_t)16 * ks * ks);
+    const float step = (float)(180 / 16);
+    for (int i = 0; i < 16; ++i) gabor_kernel(ks, sigma, (double)(i * step), lambd, gamma, psi, &bank[(size_t)i * ks * ks]);
+}
+
+// draw_radial_gradiant2 (src/draw.cpp:40-59): pow(sin(sin(d pi/2) pi/2), 32) -> u8 -> min-max normalise -> invert -> / 255
+void radial_gradient(int width, int height, std::vector<float>& out) {
+    // cv::Point center(width / 2.0, height / 2.0): the doubles convert to the int members by truncation
+    const int ccx = (int)(width / 2.0), ccy = (int)(height / 2.0);
+    const double maxDist = std::hypot(width / 2.0, height / 2.0);
+    std::vector<uint8_t> g8((size_t)width * height);
+    int mn = 255, mx = 0;
+    for (int row = 0; row < height; ++row)
+        for (int col = 0; col < width; ++col) {
+            const double dist = std::hypot((double)(ccx - col), (double)(ccy - row)) / maxDist;
+            const float f = (float)std::pow(std::sin(std::sin(dist * (M_PI / 2)) * (M_PI / 2)), 32);
+            const float t = f * 255.f + 0.f;
+            int v = (int)std::nearbyintf(t);
+            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            g8[(size_t)row * width + col] = (uint8_t)v;
+            mn = std::min(mn, v); mx = std::max(mx, v);
+        }
+    // cv::normalize(grad, grad, 0, 255, NORM_MINMAX) on 8 bit: convertTo(u8, scale, shift) in float
+    const double scale = (255.0 - 0.0) * (mx - mn > 2.220446049250313e-16 ? 1. / (mx - mn) : 0), shift = 0.0 - mn * scale;
+    const float fs = (float)scale, fb = (float)shift;
+    out.resize(g8.size());
+    for (size_t i = 0; i < g8.size(); ++i) {
+        int v = (int)std::nearbyintf((float)g8[i] * fs + fb);
+        v = v < 0 ? 0 : v > 255 ? 255 : v;
+        const uint8_t inv = (uint8_t)~(uint8_t)v;                              // bitwise_not
+        out[i] = (float)inv * (float)(1.0 / 255.0) + 0.f;
+    }
+}
+
+static int optimal_dft_size(int n) {           // cv::getOptimalDFTSize: smallest 2^a 3^b 5^c >= n
+    for (int m = n;; ++m) {
+        int t = m;
+        while (t % 2 == 0) t /= 2;
+        while (t % 3 == 0) t /= 3;
+        while (t % 5 == 0) t /= 5;
+        if (t == 1) return m;
+    }
+}
+
+int ForegroundFilter::ensure2(int w, int h) {
+    if (w == W2 && h == H2) return 0;
+    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    f_a = f_b = f_c = f_d = radial = bank31 = bank13 = taps17 = mag = c3_in = c3_out = nullptr; spec = nullptr;
+    minmax = nullptr; powsum = nullptr; g_tmp = g_out[0] = g_out[1] = nullptr;
+    if (plan_ok) { (void)hipfftDestroy((hipfftHandle)fft_plan); plan_ok = false; }
+    const size_t P = (size_t)w * h;
+    F2_CHK(hipMalloc((void**)&f_a, P * 4)); F2_CHK(hipMalloc((void**)&f_b, P * 4)); F2_CHK(hipMalloc((void**)&f_c, P * 4)); F2_CHK(hipMalloc((void**)&f_d, P * 4));
+    F2_CHK(hipMalloc((void**)&radial, P * 4)); F2_CHK(hipMalloc((void**)&g_tmp, P)); F2_CHK(hipMalloc((void**)&g_out[0], P)); F2_CHK(hipMalloc((void**)&g_out[1], P));
+    F2_CHK(hipMalloc((void**)&c3_in, P * 12)); F2_CHK(hipMalloc((void**)&c3_out, P * 12));
+    std::vector<float> t17, b31, b13, rad;
+    gaussian_taps(17, 2.0, t17);
+    gabor_bank(31, 5, 2, 0.04, M_PI / 4, b31);                // Extractor::keypoints (src/extractor.cpp:63-64)
+    gabor_bank(13, 5, 10, 0.04, M_PI / 4, b13);               // gabor_filter defaults (src/util.hpp:95)
+    radial_gradient(w, h, rad);
+    F2_CHK(hipMalloc((void**)&taps17, 17 * 4)); F2_CHK(hipMalloc((void**)&bank31, b31.size() * 4)); F2_CHK(hipMalloc((void**)&bank13, b13.size() * 4));
+    F2_CHK(hipMemcpy(taps17, t17.data(), 17 * 4, hipMemcpyHostToDevice));
+    F2_CHK(hipMemcpy(bank31, b31.data(), b31.size() * 4, hipMemcpyHostToDevice));
+    F2_CHK(hipMemcpy(bank13, b13.data(), b13.size() * 4, hipMemcpyHostToDevice));
+    F2_CHK(hipMemcpy(radial, rad.data(), P * 4, hipMemcpyHostToDevice));
+    dftN = optimal_dft_size(w); dftM = optimal_dft_size(h);
+    F2_CHK(hipMalloc((void**)&spec, (size_t)dftN * dftM * 8)); F2_CHK(hipMalloc((void**)&mag, (size_t)dftN * dftM * 4));
+    F2_CHK(hipMalloc((void**)&minmax, 8)); F2_CHK(hipMalloc((void**)&powsum, 8));
+    hipfftHandle plan;
+    if (hipfftPlan2d(&plan, dftM, dftN, HIPFFT_C2C) != HIPFFT_SUCCESS) { err = "hipfftPlan2d failed"; return -2; }
+    fft_plan = (void*)plan; plan_ok = true;
+    W2 = w; H2 = h;
+    return 0;
+}
+
+void ForegroundFilter::release2() {
+    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (plan_ok) (void)hipfftDestroy((hipfftHandle)fft_plan);
+    plan_ok = false; W2 = H2 = 0;
+}
+
+// dft_detail2(goodFeatures): RMS of the first `cols` bytes of every row of the normalised, centred log spectrum
+int ForegroundFilter::detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out) {
+    if (ensure(w, h) || ensure2(w, h)) return -2;
+    const int N = dftN, M = dftM, Nc = N & -2, Mc = M & -2;
+    launch_pad_complex(d_gf, (float2*)spec, w, h, N, M, s);
+    if (hipfftSetStream((hipfftHandle)fft_plan, s) != HIPFFT_SUCCESS ||
+        hipfftExecC2C((hipfftHandle)fft_plan, (hipfftComplex*)spec, (hipfftComplex*)spec, HIPFFT_FORWARD) != HIPFFT_SUCCESS) { err = "hipfftExecC2C failed"; return -2; }
+    const unsigned init[2] = {0xffffffffu, 0u};
+    F2_CHK(hipMemcpyAsync(minmax, init, 8, hipMemcpyHostToDevice, s));
+    launch_spectrum_log((const float2*)spec, mag, logtab, minmax, N, M, Nc, Mc, s);
+    unsigned mm[2];
+    F2_CHK(hipMemcpyAsync(mm, minmax, 8, hipMemcpyDeviceToHost, s));
+    F2_CHK(hipStreamSynchronize(s));
+    auto ord2f = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; };
+    const double smin = ord2f(mm[0]), smax = ord2f(mm[1]);
+    // cv::normalize(.., 0, 1, NORM_MINMAX): convertTo(CV_32F, scale, shift)
+    const double scale = (1.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0), shift = 0.0 - smin * scale;
+    F2_CHK(hipMemsetAsync(powsum, 0, 8, s));
+    launch_spectrum_bytes(mag, (float)scale, (float)shift, Nc, Mc, powsum, s);
+    unsigned long long ps = 0;
+    F2_CHK(hipMemcpyAsync(&ps, powsum, 8, hipMemcpyDeviceToHost, s));
+    F2_CHK(hipStreamSynchronize(s));
+    *out = std::sqrt((double)ps / (double)(Nc * Mc));
+    return 0;
+}
+
+// the ORB input image of Extractor::keypoints for one goodFeatures image (device in, device out); which = 0 / 1 selects the output buffer
+const uint8_t* ForegroundFilter::orb_input(const uint8_t* d_gf, int w, int h, int which, hipStream_t s, float* h_us, float* h_gb) {
+    if (ensure(w, h) || ensure2(w, h)) return nullptr;
+    const int n = w * h;
+    launch_unsharp1_gray(d_gf, f_a, f_b, f_c, f_d, taps17, w, h, s);       // f_d = us (grey of the unsharp-masked triple)
+    launch_gabor_bank31(f_d, bank31, f_a, w, h, s);                          // f_a = gabor mean
+    if (h_us) (void)hipMemcpyAsync(h_us, f_d, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (h_gb) (void)hipMemcpyAsync(h_gb, f_a, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    launch_orb_input(f_a, f_d, radial, g_tmp, hist, lut, g_out[which & 1], n, s);
+    if (hipGetLastError() != hipSuccess) { err = "orb_input launch failed"; return nullptr; }
+    return g_out[which & 1];
+}
+
+// gabor_filter(corrected2 / 255) with the default arguments: 3-channel float field (device in u8 BGR packed, device out f32x3)
+const float* ForegroundFilter::gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s) {
+    if (ensure(w, h) || ensure2(w, h)) return nullptr;
+    launch_u8_to_f32(d_bgr_packed, c3_in, w * h * 3, s);
+    launch_gabor_bank13_c3(c3_in, bank13, c3_out, w, h, s);
+    if (hipGetLastError() != hipSuccess) { err = "gabor_field launch failed"; return nullptr; }
+    return c3_out;
+}
+
+}  // namespace poppy_hip

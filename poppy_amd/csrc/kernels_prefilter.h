@@ -30,4 +30,23 @@ void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, i
 void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
                     uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s);
 
+// equalizeHist given the 256-bin histogram of src (lut: 256 bytes of scratch)
+void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t* lut, uint8_t* out, int n_px, hipStream_t s);
+
+// ---- part 2 (kernels_prefilter2.hip) ----------------------------------------------------------------------------------
+// grey(unsharp_mask(triple(gf / 255), 2, 6, 0.1)) on one channel; f32, tmp, diff, out: w*h floats; d_taps17: getGaussianKernel(17, 2)
+void launch_unsharp1_gray(const uint8_t* gf, float* f32, float* tmp, float* diff, float* out, const float* d_taps17, int w, int h, hipStream_t s);
+// gabor_filter(src, dst, 16 angles, ksize, ...): bank = [16][ksize*ksize] floats; 31x31 on one channel, 13x13 on three
+void launch_gabor_bank31(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s);
+void launch_gabor_bank13_c3(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s);
+void launch_u8_to_f32(const uint8_t* src, float* dst, int n, hipStream_t s);
+// out = equalizeHist(u8(gb * us * radial * 255))
+void launch_orb_input(const float* gb, const float* us, const float* radial, uint8_t* tmp_u8, unsigned* hist, uint8_t* lut, uint8_t* out,
+                      int n_px, hipStream_t s);
+// dft_detail2 around the 2-D DFT: zero-padded complex input; log-magnitude + min/max (as order-preserving uints) over the
+// even-cropped nc x mc window; sum of squared bytes of the first nc bytes of every row of the swapped, normalised image
+void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s);
+void launch_spectrum_log(const float2* spec, float* mag, const float* d_logtab, unsigned* minmax, int n, int m, int nc, int mc, hipStream_t s);
+void launch_spectrum_bytes(const float* mag, float scale, float shift, int nc, int mc, unsigned long long* powsum, hipStream_t s);
+
 }  // namespace poppy_hip

@@ -368,6 +368,11 @@ __global__ void __launch_bounds__(256) k_apply_lut(const uint8_t* __restrict__ s
     __syncthreads();
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) dst[p] = l[src[p]];
 }
+void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t* lut, uint8_t* out, int n_px, hipStream_t s) {
+    const int blocks = std::min((n_px + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(64), 0, s, hist, n_px, lut);
+    hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, src, lut, out, n_px);
+}
 void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
                     uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s) {
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);

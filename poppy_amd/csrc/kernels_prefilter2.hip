@@ -1,0 +1,210 @@
+// kernels_prefilter2.hip — pre-ORB filter chain, part 2 (src/extractor.cpp:33-83, src/poppy.hpp:119-122) on gfx950:
+// the float stages between `goodFeatures` and the ORB input, the `gabor2` mask field, and dft_detail2.
+//
+// Exact stages (same expression trees as the reference's SSE3-baseline build, -ffp-contract=off):
+//   u8 -> f32, unsharp_mask(sigma 2: 17-tap separable Gaussian, 3x3 median of the difference, threshold, amount),
+//   BGR2GRAY on float, multiplies, f32 -> u8, equalizeHist, magnitude / log / min-max normalisation of the spectrum.
+// Stages that can only match to a tolerance: the two Gabor banks.  OpenCV evaluates filter2D with a 31x31 (13x13) float
+// kernel through its DFT-based cross-correlation (OCV/imgproc/src/filter.dispatch.cpp:1291, templmatch.cpp), whose
+// rounding follows the FFT's butterfly order; here it is a direct float convolution.  The 2-D DFT of dft_detail2 comes
+// from hipFFT (foreground2.cpp) for the same reason.  DESIGN.md section 7 states the measured differences.
+#include "kernels_prefilter.h"
+#include "pyramid_device.h"
+
+namespace poppy_hip {
+
+// ---- unsharp_mask(src, radius 2, amount 6, threshold 0.1) on ONE channel ----------------------------------------------
+// The reference runs it on the 3-channel replication of a grey image (triple_channel): all three channels carry the
+// same numbers through the same operations, so one channel is computed; the norm of the difference is the double
+// sqrt(d*d + d*d + d*d) as for the Vec3f.  src/util.cpp:113-148, filter.simd.hpp:1625-1700,1884-1990.
+__global__ void __launch_bounds__(256) k_u8_to_f32(const uint8_t* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i] * kInv255 + 0.f;
+}
+__global__ void __launch_bounds__(256) k_sep_row(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ taps, int ksize, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const float* row = src + (size_t)y * W;
+    const int r = ksize >> 1;
+    float acc = row[reflect101(x - r, W)] * taps[0];
+    for (int k = 1; k < ksize; ++k) acc = row[reflect101(x - r + k, W)] * taps[k] + acc;
+    dst[(size_t)y * W + x] = acc;
+}
+__global__ void __launch_bounds__(256) k_sep_col_diff(const float* __restrict__ src, const float* __restrict__ tmp, float* __restrict__ diff,
+                                                      const float* __restrict__ taps, int ksize, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int r = ksize >> 1;
+    float acc = taps[r] * tmp[(size_t)y * W + x] + 0.f;
+    for (int k = 1; k <= r; ++k)
+        acc = taps[r + k] * (tmp[(size_t)reflect101(y + k, H) * W + x] + tmp[(size_t)reflect101(y - k, H) * W + x]) + acc;
+    diff[(size_t)y * W + x] = src[(size_t)y * W + x] - acc;
+}
+__device__ __forceinline__ float med9(const float* __restrict__ d, int W, int H, int x, int y) {
+    const int x0 = x > 0 ? x - 1 : x, x2 = x < W - 1 ? x + 1 : x;
+    const float* r0 = d + (size_t)(y > 0 ? y - 1 : 0) * W;
+    const float* r1 = d + (size_t)y * W;
+    const float* r2 = d + (size_t)(y < H - 1 ? y + 1 : H - 1) * W;
+    const float a0 = r0[x0], a1 = r0[x], a2 = r0[x2], b0 = r1[x0], b1 = r1[x], b2 = r1[x2], c0 = r2[x0], c1 = r2[x], c2 = r2[x2];
+    const float lo = fmaxf(fmaxf(fminf(fminf(a0, b0), c0), fminf(fminf(a1, b1), c1)), fminf(fminf(a2, b2), c2));
+    const float mi = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a0, b0, c0), __builtin_amdgcn_fmed3f(a1, b1, c1), __builtin_amdgcn_fmed3f(a2, b2, c2));
+    const float hi = fminf(fminf(fmaxf(fmaxf(a0, b0), c0), fmaxf(fmaxf(a1, b1), c1)), fmaxf(fmaxf(a2, b2), c2));
+    return __builtin_amdgcn_fmed3f(lo, mi, hi);
+}
+// out = grey of the unsharp-masked triple: v' = v + amount * d where |(d,d,d)| >= threshold, then v'*0.114 + v'*0.587 + v'*0.299
+__global__ void __launch_bounds__(256) k_unsharp1_gray(const float* __restrict__ src, const float* __restrict__ diff, float* __restrict__ out,
+                                                       int W, int H, float amount, float threshold) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float d;
+    if (W == 1 || H == 1) {            // 1-D special case of medianBlur (median_blur.simd.hpp:694-711)
+        const int len = W + H - 1, i = (H == 1) ? x : y;
+        float p0 = diff[i > 0 ? i - 1 : i], p1 = diff[i], p2 = diff[i < len - 1 ? i + 1 : i];
+        d = __builtin_amdgcn_fmed3f(p0, p1, p2);
+    } else d = med9(diff, W, H, x, y);
+    const size_t p = (size_t)y * W + x;
+    float v = src[p];
+    const double n2 = (double)d * (double)d + (double)d * (double)d + (double)d * (double)d;
+    if (sqrt(n2) >= (double)threshold) v = v + amount * d;
+    out[p] = v * 0.299f + (v * 0.587f + v * 0.114f);           // v_fma(r, cr, v_fma(g, cg, b*cb)), color_rgb.simd.hpp:630,638
+}
+void launch_unsharp1_gray(const uint8_t* gf, float* f32, float* tmp, float* diff, float* out, const float* d_taps17, int w, int h, hipStream_t s) {
+    const int n = w * h;
+    dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, gf, f32, n);
+    hipLaunchKernelGGL(k_sep_row, grid, dim3(256), 0, s, f32, tmp, d_taps17, 17, w, h);
+    hipLaunchKernelGGL(k_sep_col_diff, grid, dim3(256), 0, s, f32, tmp, diff, d_taps17, 17, w, h);
+    hipLaunchKernelGGL(k_unsharp1_gray, grid, dim3(256), 0, s, f32, diff, out, w, h, 6.f, 0.1f);
+}
+
+// ---- Gabor bank: mean over 16 orientations of clamp(filter2D(src, kernel_i), 0, 1) ------------------------------------
+// Direct correlation with reflect-101 borders.  Tile in LDS; every source value is read once per tap position and feeds
+// the 16 orientation accumulators; the taps are uniform across the wave (scalar loads).  `bank` = [16][K*K] floats.
+template <int K, int CN>
+__global__ void __launch_bounds__(256) k_gabor_bank(const float* __restrict__ src, const float* __restrict__ bank, float* __restrict__ dst, int W, int H) {
+    constexpr int R = K / 2, TX = 32, TY = 8, SX = TX + 2 * R, SY = TY + 2 * R;
+    __shared__ float tile[SY * SX];
+    const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, ch = blockIdx.z;
+    for (int i = threadIdx.x; i < SY * SX; i += 256) {
+        const int r = i / SX, c = i - r * SX;
+        tile[i] = src[((size_t)reflect101(ty0 - R + r, H) * W + reflect101(tx0 - R + c, W)) * CN + ch];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int dy = 0; dy < K; ++dy)
+        for (int dx = 0; dx < K; ++dx) {
+            const float v = tile[(ly + dy) * SX + lx + dx];
+            const float* wv = bank + dy * K + dx;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = wv[o * K * K] * v + acc[o];
+        }
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W || y >= H) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) sum += fminf(fmaxf(acc[o], 0.f), 1.f);       // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
+    dst[((size_t)y * W + x) * CN + ch] = sum * 0.0625f;                         // dst /= 16
+}
+void launch_gabor_bank31(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL((k_gabor_bank<31, 1>), dim3((w + 31) / 32, (h + 7) / 8, 1), dim3(256), 0, s, src, d_bank, dst, w, h);
+}
+void launch_gabor_bank13_c3(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL((k_gabor_bank<13, 3>), dim3((w + 31) / 32, (h + 7) / 8, 3), dim3(256), 0, s, src, d_bank, dst, w, h);
+}
+
+// u8 BGR -> f32 BGR * (1/255)  (corrected2.convertTo(CV_32F, 1.0/255))
+void launch_u8_to_f32(const uint8_t* src, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+
+// ---- g = gabor * us * radial -> u8 -> equalizeHist ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_orb_input(const float* __restrict__ gb, const float* __restrict__ us, const float* __restrict__ radial,
+                                                   uint8_t* __restrict__ out, unsigned* __restrict__ hist, int n) {
+    __shared__ unsigned lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        float g = gb[p] * us[p];
+        g = g * radial[p];
+        const uint8_t o = sat_u8(cv_round_x86(g * 255.f + 0.f));
+        out[p] = o;
+        atomicAdd(&lh[o], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+void launch_orb_input(const float* gb, const float* us, const float* radial, uint8_t* tmp_u8, unsigned* hist, uint8_t* lut, uint8_t* out,
+                      int n_px, hipStream_t s) {
+    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);
+    const int blocks = std::min((n_px + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_orb_input, dim3(blocks), dim3(256), 0, s, gb, us, radial, tmp_u8, hist, n_px);
+    launch_equalize_from_hist(tmp_u8, hist, lut, out, n_px, s);
+}
+
+// ---- dft_detail2: spectrum post-processing (src/experiments.hpp:267-318) ----------------------------------------------------
+// spec = interleaved complex DFT of the zero-padded image, M x N.  mag = log(sqrt(re^2 + im^2) + 1) and its min / max.
+__device__ __forceinline__ float cv_log32f_dev(float x, const float* __restrict__ tab) {
+    const float A0 = 0.3333333333333333333333333f, A1 = -0.5f, A2 = 1.f;
+    const float ln2 = (float)0.69314718055994530941723212145818;
+    const int i0 = __float_as_int(x);
+    const float bf = __int_as_float((i0 & ((1 << 15) - 1)) | (127 << 23));
+    const int idx = (i0 >> 14) & 510;
+    const float y0 = (float)(((i0 >> 23) & 0xff) - 127) * ln2 + tab[idx];
+    const float x0 = (bf - 1.f) * tab[idx + 1] + (idx == 510 ? -1.f / 512 : 0.f);
+    return ((A0 * x0 + A1) * x0 + A2) * x0 + y0;
+}
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+__global__ void __launch_bounds__(256) k_pad_complex(const uint8_t* __restrict__ src, float2* __restrict__ dst, int W, int H, int N, int M) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= N) return;
+    dst[(size_t)y * N + x] = make_float2((x < W && y < H) ? (float)src[(size_t)y * W + x] : 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256) k_spectrum_log(const float2* __restrict__ spec, float* __restrict__ mag, const float* __restrict__ tab,
+                                                      unsigned* __restrict__ minmax, int N, int M, int Nc, int Mc) {
+    __shared__ float ltab[512];
+    __shared__ unsigned smin, smax;
+    ltab[threadIdx.x] = tab[threadIdx.x]; ltab[threadIdx.x + 256] = tab[threadIdx.x + 256];
+    if (threadIdx.x == 0) { smin = 0xffffffffu; smax = 0; }
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < Nc && y < Mc) {                                   // the crop to even sizes happens before min / max
+        const float2 c = spec[(size_t)y * N + x];
+        float m = __fsqrt_rn(c.x * c.x + c.y * c.y);          // hal::magnitude32f
+        m = m + 1.f;
+        m = cv_log32f_dev(m, ltab);
+        mag[(size_t)y * Nc + x] = m;
+        atomicMin(&smin, f2ord(m)); atomicMax(&smax, f2ord(m));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicMin(&minmax[0], smin); atomicMax(&minmax[1], smax); }
+}
+// sum over rows r and bytes b < Nc of (byte b of row r of the quadrant-swapped, min-max normalised image)^2
+__global__ void __launch_bounds__(256) k_spectrum_bytes(const float* __restrict__ mag, float scale, float shift, int Nc, int Mc,
+                                                        unsigned long long* __restrict__ powsum) {
+    const int cx = Nc / 2, cy = Mc / 2;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;      // float column c < Nc / 4 (+ a partial one)
+    unsigned long long s = 0;
+    if (4 * c < Nc) {
+        const float v = mag[(size_t)((r + cy) % Mc) * Nc + (c + cx) % Nc] * scale + shift;
+        const unsigned u = __float_as_uint(v);
+        const int nb = min(4, Nc - 4 * c);
+        for (int k = 0; k < nb; ++k) { const unsigned b = (u >> (8 * k)) & 255; s += b * b; }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(powsum, s);
+}
+void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s) {
+    hipLaunchKernelGGL(k_pad_complex, dim3((n + 255) / 256, m), dim3(256), 0, s, src, dst, w, h, n, m);
+}
+void launch_spectrum_log(const float2* spec, float* mag, const float* d_logtab, unsigned* minmax, int n, int m, int nc, int mc, hipStream_t s) {
+    hipLaunchKernelGGL(k_spectrum_log, dim3((nc + 255) / 256, mc), dim3(256), 0, s, spec, mag, d_logtab, minmax, n, m, nc, mc);
+}
+void launch_spectrum_bytes(const float* mag, float scale, float shift, int nc, int mc, unsigned long long* powsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_spectrum_bytes, dim3(((nc + 3) / 4 + 255) / 256, mc), dim3(256), 0, s, mag, scale, shift, nc, mc, powsum);
+}
+
+}  // namespace poppy_hip

@@ -90,6 +90,8 @@ struct poppy_hip_ctx {
     OrbDetector orb;
     ForegroundFilter foreground;
     double initial_morph_dist = 0;
+    int last_nfeatures = 0;
+    double last_detail[2] = {0, 0};
     // diagnostics
     bool debug = false;
     int timing = 0;                      // 0 off, 1 every kernel group (direct launches), 2 the warp kernel only
@@ -780,10 +782,96 @@ int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, in
     return POPPY_OK;
 }
 
-int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t*, size_t, const uint8_t*, size_t, int, int) {
+// Pair set-up from the raw images: the pre-ORB filter chain on the GPU, then the same steps as pair_begin_prefiltered.
+int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H) {
     if (!c) return POPPY_E_ARG;
-    return fail(c, POPPY_E_UNSUPPORTED, "of the pre-ORB filter chain only Extractor::foreground is on the GPU (poppy_hip_foreground); dft_detail2 and the Gabor bank are not yet: "
-                                        "use poppy_hip_pair_begin_prefiltered");
+    if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = alloc_pair(c, W, H); if (rc) return rc;
+    c->pair_ready = false;
+    rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
+    rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
+    ForegroundFilter& fg = c->foreground;
+    const size_t P = (size_t)W * H;
+    std::vector<uint8_t> g[2] = {std::vector<uint8_t>(P), std::vector<uint8_t>(P)};
+    double d[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {                  // Extractor::foreground -> dft_detail2 -> the ORB input of Extractor::keypoints
+        const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, c->stream, nullptr);
+        if (!gf) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
+        if (fg.detail(gf, W, H, c->stream, &d[i])) { c->err = "dft_detail2: " + fg.err; return POPPY_E_DEVICE; }
+        const uint8_t* gi = fg.orb_input(gf, W, H, i, c->stream);
+        if (!gi) { c->err = "orb_input: " + fg.err; return POPPY_E_DEVICE; }
+        HIPCHK(c, hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, c->stream));
+    }
+    const float* gab = fg.gabor_field(c->c2, W, H, c->stream);          // gabor_filter(corrected2 / 255), src/poppy.hpp:119-122
+    if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
+    HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
+    c->last_detail[0] = d[0]; c->last_detail[1] = d[1];
+    const int nfeatures = (int)(c->cfg.max_keypoints * detail);
+    c->last_nfeatures = nfeatures;
+    std::vector<OrbKeyPoint> k1, k2;
+    if (c->orb.detect(g[0].data(), W, W, H, nfeatures, c->stream, k1) < 0 || c->orb.detect(g[1].data(), W, W, H, nfeatures, c->stream, k2) < 0) {
+        c->err = "orb_detect: " + c->orb.err;
+        return POPPY_E_DEVICE;
+    }
+    const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
+    std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
+    for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
+    int m = 0;
+    rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
+    if (rc) return fail(c, rc, "poppy_match_points failed");
+    rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
+    rc = finish_pair_load(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
+// intermediates of the last poppy_hip_pair_begin, for the tolerance tests: nfeatures, the two dft_detail2 values
+int poppy_hip_pair_begin_info(poppy_hip_ctx* c, int* nfeatures, double* detail2) {
+    if (!c) return POPPY_E_ARG;
+    if (nfeatures) *nfeatures = c->last_nfeatures;
+    if (detail2) { detail2[0] = c->last_detail[0]; detail2[1] = c->last_detail[1]; }
+    return POPPY_OK;
+}
+
+// Extractor::keypoints' image chain for one goodFeatures image (host in / out): us = grey(unsharp), gb = Gabor mean, g = ORB input
+int poppy_hip_orb_input(poppy_hip_ctx* c, const uint8_t* good_features, int W, int H, uint8_t* g, float* us, float* gb, double* detail) {
+    if (!c || !good_features || W <= 0 || H <= 0) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    ForegroundFilter& fg = c->foreground;
+    if (fg.prepare(W, H)) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
+    uint8_t* d_gf = fg.bgr_staging();                                   // any w*h device bytes will do as the staging area
+    HIPCHK(c, hipMemcpyAsync(d_gf, good_features, (size_t)W * H, hipMemcpyHostToDevice, c->stream));
+    if (detail && fg.detail(d_gf, W, H, c->stream, detail)) { c->err = "dft_detail2: " + fg.err; return POPPY_E_DEVICE; }
+    const uint8_t* gi = fg.orb_input(d_gf, W, H, 0, c->stream, us, gb);
+    if (!gi) { c->err = "orb_input: " + fg.err; return POPPY_E_DEVICE; }
+    if (g) HIPCHK(c, hipMemcpyAsync(g, gi, (size_t)W * H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
+// gabor_filter(bgr / 255) with the default arguments (host in / out, f32x3)
+int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, float* out) {
+    if (!c || !bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    ForegroundFilter& fg = c->foreground;
+    if (fg.prepare(W, H)) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
+    HIPCHK(c, hipMemcpy2DAsync(fg.bgr_staging(), (size_t)W * 3, bgr, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    const float* gab = fg.gabor_field(fg.bgr_staging(), W, H, c->stream);
+    if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
+    HIPCHK(c, hipMemcpyAsync(out, gab, (size_t)W * H * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
+int poppy_radial_gradient(int W, int H, float* out) {
+    if (W <= 0 || H <= 0 || !out) return POPPY_E_ARG;
+    std::vector<float> r;
+    radial_gradient(W, H, r);
+    memcpy(out, r.data(), r.size() * 4);
+    return POPPY_OK;
 }
 
 int poppy_hip_pair_points(poppy_hip_ctx* c, float* p1, float* p2, int max_points, int* n_points) {

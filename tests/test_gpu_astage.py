@@ -58,12 +58,6 @@ def test_pair_begin_prefiltered_reproduces_reference_frames(ctx):
     c.close()
 
 
-def test_pair_begin_raw_is_unsupported_not_approximated(ctx):
-    a = synth.textured_bgr(64, 48, 1)
-    rc = capi.lib().poppy_hip_pair_begin(ctx.h, capi._p(a), 64 * 3, capi._p(a), 64 * 3, 64, 48)
-    assert rc == -6
-
-
 @pytest.mark.parametrize("case,nf", [("o_256x256", 300), ("o_256x256", 516), ("o_640x480", 500), ("o_1920x1080", 516)])
 def test_orb_describe_and_hamming_vs_opencv(ctx, case, nf):
     """ORB::compute + BFMatcher(NORM_HAMMING).match (no call site in Poppy; pinned against OpenCV's outputs)."""
