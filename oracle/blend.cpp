@@ -288,9 +288,18 @@ void median3_f32(const ImageF& src, ImageF& dst) {
 }
 
 void unsharp_mask(const ImageF& src, float radius, float amount, float threshold, ImageF& dst, ImageF* blurOut, ImageF* medOut) {
-    (void)radius;   // the hot path only ever uses radius 1 -> 9 taps (smooth.dispatch.cpp:289)
+    // GaussianBlur(Size(0,0), radius) on float: ksize = cvRound(radius*4*2 + 1) | 1 (smooth.dispatch.cpp:289): 9 taps for the
+    // per-frame call (radius 1), 17 for the pre-ORB call (radius 2); taps = exp(-x^2 / 2 sigma^2) / sum in double, stored as float
     ImageF blurred, diff(src.w, src.h, src.c), med;
-    gaussian_blur_f32(src, kGauss9Sigma1, 9, blurred);
+    if (radius == 1.f) gaussian_blur_f32(src, kGauss9Sigma1, 9, blurred);
+    else {
+        const int n = cv_round_f(radius * 4 * 2 + 1) | 1;
+        std::vector<double> v(n); double sum = 0;
+        for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2.0 * radius * radius)); sum += v[i]; }
+        std::vector<float> taps(n);
+        for (int i = 0; i < n; ++i) taps[i] = (float)(v[i] / sum);
+        gaussian_blur_f32(src, taps.data(), n, blurred);
+    }
     for (size_t i = 0; i < src.d.size(); ++i) diff.d[i] = src.d[i] - blurred.d[i];
     median3_f32(diff, med);
     dst = src;

@@ -134,4 +134,8 @@ struct ForegroundDebug {
 };
 void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg = nullptr);
 
+void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank);
+void gabor_filter_direct(const ImageF& src, int ks, const std::vector<float>& bank, ImageF& dst);   // tolerance comparator
+void orb_unsharp_gray(const ImageU8& gf, ImageF& us);
+
 }  // namespace oracle

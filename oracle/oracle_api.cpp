@@ -149,4 +149,13 @@ void orc_gaussian_blur23_u8(const uint8_t* s, int w, int h, uint8_t* d) { ImageU
 void orc_equalize_hist(const uint8_t* s, int w, int h, uint8_t* d) { ImageU8 o; equalize_hist(wrap_u8(s, w, h, 1), o); put_img(d, o); }
 float orc_log32f(float x) { return cv_log32f(x); }
 
+void orc_orb_unsharp_gray(const uint8_t* gf, int w, int h, float* us) { ImageF o; orb_unsharp_gray(wrap_u8(gf, w, h, 1), o); put_img(us, o); }
+void orc_gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, float* out) {
+    std::vector<float> b; gabor_bank(ks, sigma, lambd, gamma, psi, b); memcpy(out, b.data(), b.size() * 4);
+}
+void orc_gabor_filter_direct(const float* src, int w, int h, int c, int ks, const float* bank, float* dst) {
+    std::vector<float> b(bank, bank + (size_t)16 * ks * ks); ImageF o;
+    gabor_filter_direct(wrap_f(src, w, h, c), ks, b, o); put_img(dst, o);
+}
+
 }  // extern "C"

@@ -272,4 +272,58 @@ void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg) {
     if (dbg) { dbg->grey = grey; dbg->ln20 = ln20; dbg->lin = lin; dbg->logged = logged; dbg->final_mask = fin; dbg->masked = m8; }
 }
 
+// ---- Extractor::keypoints up to the detector (src/extractor.cpp:50-76), gabor_filter (src/util.cpp:40-60) -----------------------
+// getGaborKernel (OCV/imgproc/src/gabor.cpp:50-95), theta_i = i * float(180 / 16) used as radians
+void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank) {
+    bank.resize((size_t)16 * ks * ks);
+    const float step = (float)(180 / 16);
+    for (int a = 0; a < 16; ++a) {
+        const double theta = (double)(a * step), sx = sigma, sy = sigma / gamma, c = std::cos(theta), s = std::sin(theta);
+        const int m = ks / 2;
+        const double ex = -0.5 / (sx * sx), ey = -0.5 / (sy * sy), cscale = M_PI * 2 / lambd;
+        for (int y = -m; y <= m; ++y)
+            for (int x = -m; x <= m; ++x) {
+                const double xr = x * c + y * s, yr = -x * s + y * c;
+                bank[(size_t)a * ks * ks + (m - y) * ks + (m - x)] = (float)(1 * std::exp(ex * xr * xr + ey * yr * yr) * std::cos(cscale * xr + psi));
+            }
+    }
+}
+
+// mean over the bank of clamp(correlate(src, kernel), 0, 1).  The reference evaluates the correlation through OpenCV's DFT-based
+// filter2D; this is the direct sum in double, rounded once: the comparator for tolerance checks, not a bit-exact restatement.
+void gabor_filter_direct(const ImageF& src, int ks, const std::vector<float>& bank, ImageF& dst) {
+    dst = ImageF(src.w, src.h, src.c);
+    const int m = ks / 2, w = src.w, h = src.h, cn = src.c;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int ch = 0; ch < cn; ++ch) {
+                float sum = 0.f;
+                for (int a = 0; a < 16; ++a) {
+                    double acc = 0;
+                    const float* k = &bank[(size_t)a * ks * ks];
+                    for (int dy = 0; dy < ks; ++dy) {
+                        const float* row = src.row(border_reflect101(y + dy - m, h));
+                        for (int dx = 0; dx < ks; ++dx) acc += (double)k[dy * ks + dx] * row[(size_t)border_reflect101(x + dx - m, w) * cn + ch];
+                    }
+                    float p = (float)acc;
+                    p = p > 1.f ? 1.f : p; p = p < 0.f ? 0.f : p;
+                    sum += p;
+                }
+                dst.d[((size_t)y * w + x) * cn + ch] = sum * 0.0625f;
+            }
+}
+
+// us = grey(unsharp_mask(triple(gf / 255), 2, 6, 0.1)): exact
+void orb_unsharp_gray(const ImageU8& gf, ImageF& us) {
+    ImageF f1, trip(gf.w, gf.h, 3), um;
+    u8_to_f32(gf, f1);
+    for (size_t i = 0; i < f1.d.size(); ++i) trip.d[3 * i] = trip.d[3 * i + 1] = trip.d[3 * i + 2] = f1.d[i];
+    unsharp_mask(trip, 2.f, 6.f, 0.1f, um);
+    us = ImageF(gf.w, gf.h, 1);
+    for (size_t i = 0; i < us.d.size(); ++i) {
+        const float b = um.d[3 * i], g = um.d[3 * i + 1], r = um.d[3 * i + 2];
+        us.d[i] = r * 0.299f + (g * 0.587f + b * 0.114f);          // color_rgb.simd.hpp:630,638
+    }
+}
+
 }  // namespace oracle

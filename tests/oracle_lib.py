@@ -324,3 +324,23 @@ def equalize_hist(a):
 def log32f(x):
     L = lib(); L.orc_log32f.restype = C.c_float; L.orc_log32f.argtypes = [C.c_float]
     return L.orc_log32f(float(x))
+
+
+def orb_unsharp_gray(gf):
+    gf = np.ascontiguousarray(gf, np.uint8); o = np.zeros(gf.shape, np.float32)
+    lib().orc_orb_unsharp_gray(_vp(gf), gf.shape[1], gf.shape[0], _vp(o))
+    return o
+
+
+def gabor_bank(ks, sigma, lambd, gamma=0.04, psi=np.pi / 4):
+    o = np.zeros((16, ks, ks), np.float32)
+    L = lib(); L.orc_gabor_bank.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    L.orc_gabor_bank(ks, sigma, lambd, gamma, psi, _vp(o))
+    return o
+
+
+def gabor_filter_direct(src, ks, bank):
+    a = _f(src); c = 1 if a.ndim == 2 else a.shape[2]
+    o = np.zeros_like(a); b = _f(bank)
+    lib().orc_gabor_filter_direct(_vp(a), a.shape[1], a.shape[0], c, ks, _vp(b), _vp(o))
+    return o

@@ -67,3 +67,15 @@ def test_pair_begin_from_raw_images(case):
         d = np.abs(frames[j].astype(int) - ref_f.astype(int))
         assert (d > 0).mean() <= 0.15 and d.mean() <= 2.0           # measured 1.8-3.4 % of pixels, mean 0.24-0.32 levels
     c.close()
+
+
+@pytest.mark.parametrize("w,h,seed", [(97, 61, 2), (64, 130, 3)])
+def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
+    import oracle_lib as O
+    from poppy_amd import synth
+    gf = synth.textured_gray(w, h, seed)
+    r = ctx.orb_input(gf)
+    us = O.orb_unsharp_gray(gf)
+    assert np.array_equal(r["us"].view(np.uint32), us.view(np.uint32))           # exact stage
+    gb = O.gabor_filter_direct(us, 31, O.gabor_bank(31, 5, 2))
+    assert np.abs(r["gb"] - gb).max() <= 1e-5                                      # float vs double direct sums
