@@ -171,6 +171,34 @@ def main():
         ctx.sync()
         phase_fps = args.steps * FRAMES / (time.perf_counter() - t1)
 
+    # N = 1 only: BASELINE.json configs[4] in miniature — several independent pairs on this GPU at once, each a chained
+    # 60-frame morph driven by its own host thread and context (pairs never depend on each other)
+    batched_fps, batched_pairs = None, 3
+    if world == 1 and mode == "chain" and not args.no_setup:
+        import threading
+        extra = []
+        for _ in range(batched_pairs - 1):
+            cx = capi.Context(local, number_of_frames=FRAMES)
+            cx.pair_load_device(ta.data_ptr(), tb.data_ptr(), tg.data_ptr(), W, H, p1r, p2r)
+            extra.append(cx)
+        allc = [ctx] + extra
+
+        def run_pair(cx, n):
+            for _ in range(n):
+                cx.reset(); cx.render_many(shapes, chain=True)
+            cx.sync()
+        for cx in allc:
+            run_pair(cx, 1)
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=run_pair, args=(cx, args.steps)) for cx in allc]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        batched_fps = batched_pairs * args.steps * FRAMES / (time.perf_counter() - t1)
+        for cx in extra:
+            cx.close()
+
     # PCIe-inclusive rate (frames copied back to pinned host memory), rank 0, short run, not `value`
     pcie_fps = None
     if rank == 0:
@@ -239,6 +267,7 @@ def main():
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
             "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
             "phase_mode_fps": round(phase_fps, 1) if phase_fps else None,
+            "batched_pairs_fps": {"pairs": batched_pairs, "value": round(batched_fps, 1)} if batched_fps else None,
             "pair_setup_ms": round(setup_ms, 2) if setup_ms else None,
             "fps_including_setup": round(FRAMES / (setup_ms * 1e-3 + FRAMES / fps), 1) if setup_ms and world == 1 else None,
         }
