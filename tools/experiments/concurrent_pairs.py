@@ -1,5 +1,5 @@
 import sys, time, threading, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 import bench
 from poppy_amd import capi
 K = int(sys.argv[1])

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 from poppy_amd import capi, synth
 ctx = capi.Context(0)
 for (w,h) in [(1920,1080),(3840,2160)]:

@@ -1,5 +1,5 @@
 import sys, time, os, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 import bench
 from poppy_amd import capi
 a,b,g,p1,p2 = bench.synth_inputs()

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 from poppy_amd import capi, synth
 for (w,h) in [(1920,1080)]:
     a,b = synth.gen_pair(w,h)

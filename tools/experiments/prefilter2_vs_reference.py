@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 from poppy_amd import capi
 import golden_util as G
 ctx = capi.Context(0)

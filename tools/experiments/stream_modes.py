@@ -1,5 +1,5 @@
 import sys, time, os, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
 import bench
 from poppy_amd import capi
 mode = sys.argv[1]; timing = int(sys.argv[2])
