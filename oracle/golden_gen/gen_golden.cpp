@@ -547,6 +547,40 @@ static void dump_fstage() {
     fprintf(stderr, "fstage ok (staged == Extractor::foreground)\n");
 }
 
+// dft_detail2 (src/experiments.hpp:305-318) on a grey image: the value and a few raw spectrum samples
+static void dump_detail() {
+    Mat g = read_mat("gray");
+    Mat spec;
+    double d = dft_detail2(g, spec);
+    dump_f64("detail", { d });
+    Mat head = spec(Rect(0, 0, std::min(spec.cols, 64), std::min(spec.rows, 8))).clone();
+    dump_mat("spectrum_head", head);
+    if (getenv("DUMP_FULL_SPECTRUM")) dump_mat("spectrum_full", spec);
+    {   // the raw transform, as dft_spectrum computes it (src/experiments.hpp:267-279)
+        Mat padded;
+        int m = getOptimalDFTSize(g.rows), n = getOptimalDFTSize(g.cols);
+        copyMakeBorder(g, padded, 0, m - g.rows, 0, n - g.cols, BORDER_CONSTANT, Scalar::all(0));
+        Mat planes[] = {Mat_<float>(padded), Mat::zeros(padded.size(), CV_32F)};
+        Mat complexI;
+        merge(planes, 2, complexI);
+        dft(complexI, complexI);
+        dump_mat("dft", complexI);
+        Mat row0;
+        dft(Mat_<Vec2f>(complexI.size(), Vec2f(0, 0)), row0);    // (keeps the planner warm; not used)
+        Mat in0;
+        merge(planes, 2, in0);
+        Mat r0 = in0.row(0).clone(), r0out;
+        dft(r0, r0out, DFT_ROWS);
+        dump_mat("dft_row0", r0out);
+    }
+}
+
+static void dump_logcheck() {      // cv::log / cv::magnitude on given floats (debugging aid for the oracle)
+    Mat x = read_mat("x"), y;
+    log(x, y);
+    dump_mat("logx", y);
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s <bstage|orb|match|astage|prims> <case_dir>\n", argv[0]); return 1; }
     string mode = argv[1], dir = argv[2];
@@ -559,6 +593,8 @@ int main(int argc, char** argv) {
     else if (mode == "astage") dump_astage();
     else if (mode == "prims") dump_prims();
     else if (mode == "fstage") dump_fstage();
+    else if (mode == "detail") dump_detail();
+    else if (mode == "logcheck") dump_logcheck();
     else { fprintf(stderr, "unknown mode\n"); return 1; }
     return 0;
 }

@@ -63,6 +63,22 @@ FSTAGE = {
 }
 
 
+DETAIL = {
+    # name: (w, h, seed): dft_detail2 of a grey image; sizes chosen to hit every radix path of cv::dft
+    "d_256x256": (256, 256, 51),       # powers of two: radix 4 only
+    "d_512x384": (512, 384, 52),       # 512 = 4^4 * 2 (radix 2 pass), 384 = 128 * 3
+    "d_640x480": (640, 480, 53),       # 640 = 128 * 5, 480 = 32 * 5 * 3
+    "d_317x211": (317, 211, 54),       # padded to 320 x 216 = (64 * 5) x (8 * 3^3)
+    "d_100x75": (100, 75, 55),         # 100 = 4 * 5^2, 75 = 3 * 5^2 (no power of two: the odd permutation branch)
+    "d_1920x1080": (1920, 1080, 56),
+}
+
+
+def detail_inputs(name):
+    w, h, seed = DETAIL[name]
+    return {"gray": synth.textured_gray(w, h, seed)}
+
+
 def fstage_inputs(name):
     w, h, seed = FSTAGE[name]
     return {"img1": synth.textured_bgr(w, h, seed)}
@@ -130,6 +146,7 @@ def all_cases():
     out += [("astage", n, astage_inputs) for n in ASTAGE]
     out += [("prims", "p_prims", lambda _n: prims_inputs())]
     out += [("fstage", n, fstage_inputs) for n in FSTAGE]
+    out += [("detail", n, detail_inputs) for n in DETAIL]
     return out
 
 

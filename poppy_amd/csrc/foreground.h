@@ -46,8 +46,10 @@ private:
     unsigned* minmax = nullptr;
     unsigned long long* powsum = nullptr;
     uint8_t *g_tmp = nullptr, *g_out[2] = {nullptr, nullptr};
-    void* fft_plan = nullptr;
-    bool plan_ok = false;
+    void *spec_tmp = nullptr, *spec_out = nullptr;
+    int* d_itab[2] = {nullptr, nullptr};
+    float* d_wave[2] = {nullptr, nullptr};
+    int dft_n[2] = {0, 0}, dft_nf[2] = {0, 0}, dft_factors[2][16] = {};
     int W = 0, H = 0;
     uint8_t *d_bgr = nullptr, *grey = nullptr, *img[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr}, *flow = nullptr;
     uint8_t *used = nullptr, *masked = nullptr, *out = nullptr, *lut = nullptr;

@@ -4,7 +4,7 @@
 // in double (Gaussian taps, Gabor kernels, the radial gradient) are computed here the same way and uploaded.
 #include "foreground.h"
 #include "kernels_prefilter.h"
-#include <hipfft/hipfft.h>
+#include "dft_exact.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -77,23 +77,14 @@ void radial_gradient(int width, int height, std::vector<float>& out) {
     }
 }
 
-static int optimal_dft_size(int n) {           // cv::getOptimalDFTSize: smallest 2^a 3^b 5^c >= n
-    for (int m = n;; ++m) {
-        int t = m;
-        while (t % 2 == 0) t /= 2;
-        while (t % 3 == 0) t /= 3;
-        while (t % 5 == 0) t /= 5;
-        if (t == 1) return m;
-    }
-}
-
 int ForegroundFilter::ensure2(int w, int h) {
     if (w == W2 && h == H2) return 0;
     void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     f_a = f_b = f_c = f_d = radial = bank31 = bank13 = taps17 = mag = c3_in = c3_out = nullptr; spec = nullptr;
     minmax = nullptr; powsum = nullptr; g_tmp = g_out[0] = g_out[1] = nullptr;
-    if (plan_ok) { (void)hipfftDestroy((hipfftHandle)fft_plan); plan_ok = false; }
+    for (void* b : {(void*)spec_tmp, (void*)spec_out, (void*)d_itab[0], (void*)d_itab[1], (void*)d_wave[0], (void*)d_wave[1]}) if (b) (void)hipFree(b);
+    spec_tmp = spec_out = nullptr; d_itab[0] = d_itab[1] = nullptr; d_wave[0] = d_wave[1] = nullptr;
     const size_t P = (size_t)w * h;
     F2_CHK(hipMalloc((void**)&f_a, P * 4)); F2_CHK(hipMalloc((void**)&f_b, P * 4)); F2_CHK(hipMalloc((void**)&f_c, P * 4)); F2_CHK(hipMalloc((void**)&f_d, P * 4));
     F2_CHK(hipMalloc((void**)&radial, P * 4)); F2_CHK(hipMalloc((void**)&g_tmp, P)); F2_CHK(hipMalloc((void**)&g_out[0], P)); F2_CHK(hipMalloc((void**)&g_out[1], P));
@@ -108,12 +99,20 @@ int ForegroundFilter::ensure2(int w, int h) {
     F2_CHK(hipMemcpy(bank31, b31.data(), b31.size() * 4, hipMemcpyHostToDevice));
     F2_CHK(hipMemcpy(bank13, b13.data(), b13.size() * 4, hipMemcpyHostToDevice));
     F2_CHK(hipMemcpy(radial, rad.data(), P * 4, hipMemcpyHostToDevice));
-    dftN = optimal_dft_size(w); dftM = optimal_dft_size(h);
+    dftN = dft_optimal_size(w); dftM = dft_optimal_size(h);
     F2_CHK(hipMalloc((void**)&spec, (size_t)dftN * dftM * 8)); F2_CHK(hipMalloc((void**)&mag, (size_t)dftN * dftM * 4));
     F2_CHK(hipMalloc((void**)&minmax, 8)); F2_CHK(hipMalloc((void**)&powsum, 8));
-    hipfftHandle plan;
-    if (hipfftPlan2d(&plan, dftM, dftN, HIPFFT_C2C) != HIPFFT_SUCCESS) { err = "hipfftPlan2d failed"; return -2; }
-    fft_plan = (void*)plan; plan_ok = true;
+    F2_CHK(hipMalloc((void**)&spec_tmp, (size_t)dftN * dftM * 8)); F2_CHK(hipMalloc((void**)&spec_out, (size_t)dftN * dftM * 8));
+    for (int d = 0; d < 2; ++d) {                             // 0: rows (length N), 1: columns (length M)
+        DftPlanHost ph;
+        dft_make_plan(d ? dftM : dftN, ph);
+        if (ph.nf > 16) { err = "DFT size with too many factors"; return -2; }
+        F2_CHK(hipMalloc((void**)&d_itab[d], ph.itab.size() * 4)); F2_CHK(hipMalloc((void**)&d_wave[d], ph.wave.size() * 4));
+        F2_CHK(hipMemcpy(d_itab[d], ph.itab.data(), ph.itab.size() * 4, hipMemcpyHostToDevice));
+        F2_CHK(hipMemcpy(d_wave[d], ph.wave.data(), ph.wave.size() * 4, hipMemcpyHostToDevice));
+        dft_n[d] = ph.n; dft_nf[d] = ph.nf;
+        for (int k = 0; k < 16; ++k) dft_factors[d][k] = k < ph.nf ? ph.factors[k] : 0;
+    }
     W2 = w; H2 = h;
     return 0;
 }
@@ -121,8 +120,8 @@ int ForegroundFilter::ensure2(int w, int h) {
 void ForegroundFilter::release2() {
     void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (plan_ok) (void)hipfftDestroy((hipfftHandle)fft_plan);
-    plan_ok = false; W2 = H2 = 0;
+    for (void* b : {(void*)spec_tmp, (void*)spec_out, (void*)d_itab[0], (void*)d_itab[1], (void*)d_wave[0], (void*)d_wave[1]}) if (b) (void)hipFree(b);
+    W2 = H2 = 0;
 }
 
 // dft_detail2(goodFeatures): RMS of the first `cols` bytes of every row of the normalised, centred log spectrum
@@ -130,18 +129,24 @@ int ForegroundFilter::detail(const uint8_t* d_gf, int w, int h, hipStream_t s, d
     if (ensure(w, h) || ensure2(w, h)) return -2;
     const int N = dftN, M = dftM, Nc = N & -2, Mc = M & -2;
     launch_pad_complex(d_gf, (float2*)spec, w, h, N, M, s);
-    if (hipfftSetStream((hipfftHandle)fft_plan, s) != HIPFFT_SUCCESS ||
-        hipfftExecC2C((hipfftHandle)fft_plan, (hipfftComplex*)spec, (hipfftComplex*)spec, HIPFFT_FORWARD) != HIPFFT_SUCCESS) { err = "hipfftExecC2C failed"; return -2; }
+    DftPlanDev pr, pc;
+    pr.n = dft_n[0]; pr.nf = dft_nf[0]; pr.itab = d_itab[0]; pr.wave = (const float2*)d_wave[0];
+    pc.n = dft_n[1]; pc.nf = dft_nf[1]; pc.itab = d_itab[1]; pc.wave = (const float2*)d_wave[1];
+    for (int k = 0; k < 16; ++k) { pr.factors[k] = dft_factors[0][k]; pc.factors[k] = dft_factors[1][k]; }
+    launch_dft2d_exact((const float2*)spec, (float2*)spec_tmp, (float2*)spec_out, N, M, pr, pc, s);
     const unsigned init[2] = {0xffffffffu, 0u};
     F2_CHK(hipMemcpyAsync(minmax, init, 8, hipMemcpyHostToDevice, s));
-    launch_spectrum_log((const float2*)spec, mag, logtab, minmax, N, M, Nc, Mc, s);
+    launch_spectrum_log((const float2*)spec_out, mag, logtab, minmax, N, M, Nc, Mc, s);
     unsigned mm[2];
     F2_CHK(hipMemcpyAsync(mm, minmax, 8, hipMemcpyDeviceToHost, s));
     F2_CHK(hipStreamSynchronize(s));
     auto ord2f = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; };
     const double smin = ord2f(mm[0]), smax = ord2f(mm[1]);
-    // cv::normalize(.., 0, 1, NORM_MINMAX): convertTo(CV_32F, scale, shift)
-    const double scale = (1.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0), shift = 0.0 - smin * scale;
+    // cv::normalize(.., 0, 1, NORM_MINMAX) into CV_32F (OCV/core/src/norm.cpp:1384-1397): the scale is rounded to float
+    // first and the shift is built from that rounded scale, then convertTo(CV_32F, scale, shift)
+    double scale = (1.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0);
+    scale = (float)scale;
+    const double shift = (float)0.0 - (float)(smin * scale);
     F2_CHK(hipMemsetAsync(powsum, 0, 8, s));
     launch_spectrum_bytes(mag, (float)scale, (float)shift, Nc, Mc, powsum, s);
     unsigned long long ps = 0;

@@ -45,6 +45,9 @@ void launch_orb_input(const float* gb, const float* us, const float* radial, uin
                       int n_px, hipStream_t s);
 // dft_detail2 around the 2-D DFT: zero-padded complex input; log-magnitude + min/max (as order-preserving uints) over the
 // even-cropped nc x mc window; sum of squared bytes of the first nc bytes of every row of the swapped, normalised image
+// cv::dft's complex float transform (exact operation order, dft_exact.h builds the tables); 2-D forward: rows then columns
+struct DftPlanDev { int n, nf; int factors[16]; const int* itab; const float2* wave; };
+void launch_dft2d_exact(const float2* src, float2* tmp, float2* dst, int n, int m, const DftPlanDev& rows, const DftPlanDev& cols, hipStream_t s);
 void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s);
 void launch_spectrum_log(const float2* spec, float* mag, const float* d_logtab, unsigned* minmax, int n, int m, int nc, int mc, hipStream_t s);
 void launch_spectrum_bytes(const float* mag, float scale, float shift, int nc, int mc, unsigned long long* powsum, hipStream_t s);

@@ -173,7 +173,9 @@ __global__ void __launch_bounds__(256) k_spectrum_log(const float2* __restrict__
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x < Nc && y < Mc) {                                   // the crop to even sizes happens before min / max
         const float2 c = spec[(size_t)y * N + x];
-        float m = __fsqrt_rn(c.x * c.x + c.y * c.y);          // hal::magnitude32f
+        // hal::magnitude32f = correctly rounded sqrt of the float sum; through double (53 >= 2*24 + 2 bits, so the second rounding
+        // cannot change the result) because the float intrinsic is not correctly rounded on this target
+        float m = (float)sqrt((double)(c.x * c.x + c.y * c.y));
         m = m + 1.f;
         m = cv_log32f_dev(m, ltab);
         mag[(size_t)y * Nc + x] = m;
@@ -197,6 +199,135 @@ __global__ void __launch_bounds__(256) k_spectrum_bytes(const float* __restrict_
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(powsum, s);
 }
+// ---- cv::dft's complex float transform, one thread per 1-D transform ------------------------------------------------------
+// OCV/core/src/dxt.cpp:835-1190 with the SSE3 specialisations that run for float (radix 4: :645-727, radix 2 / 3 identical
+// in value to the scalar forms).  The operation ORDER is the reference's: the permuted copy, radix-4 passes over the power
+// of two, one radix-2 pass if the power is odd, then the odd factors (5s before 3s: DFTFactorize reverses them).  Each
+// product and each sum rounds on its own (-ffp-contract=off).  A thread walks its transform sequentially in global
+// memory: rows of the image in the first launch (elements contiguous), columns in the second (adjacent threads touch
+// adjacent addresses).  This is the exactness path of dft_detail2, where the result is read back as raw float bytes.
+
+
+#define DFT_AT(p, i) (p)[(size_t)(i) * stride]
+__device__ void dft_c2c_forward(const float2* __restrict__ src, float2* __restrict__ dst, int stride, const DftPlanDev& c) {
+    const float2* __restrict__ wave = c.wave;
+    const int N = c.n;
+    for (int i = 0; i < N; ++i) DFT_AT(dst, i) = DFT_AT(src, c.itab[i]);        // 0. shuffle data
+    int n = 1, dw0 = N;
+    if ((c.factors[0] & 1) == 0) {
+        const int f0 = c.factors[0];
+        for (; n * 4 <= f0;) {                                                   // radix-4 passes (DFT_VecR4<float>)
+            const int nx = n;
+            n *= 4; dw0 /= 4;
+            for (int i = 0; i < N; i += n) {
+                for (int j = 0, dw = 0; j < nx; ++j, dw += dw0) {
+                    float2 x0 = DFT_AT(dst, i + j), x1 = DFT_AT(dst, i + j + nx), x2 = DFT_AT(dst, i + j + 2 * nx), x3 = DFT_AT(dst, i + j + 3 * nx);
+                    if (j > 0) {
+                        const float2 w1 = wave[dw], w2 = wave[dw * 2], w3 = wave[dw * 3];
+                        const float2 a = x1, b = x2, d = x3;
+                        x1 = make_float2(a.x * w2.x - a.y * w2.y, a.x * w2.y + a.y * w2.x);
+                        x3 = make_float2(d.x * w3.x - d.y * w3.y, d.x * w3.y + d.y * w3.x);
+                        x2 = make_float2(b.x * w1.x - b.y * w1.y, b.x * w1.y + b.y * w1.x);
+                    }
+                    const float2 s01 = make_float2(x0.x + x1.x, x0.y + x1.y), s23 = make_float2(x2.x + x3.x, x2.y + x3.y);
+                    const float2 d01 = make_float2(x0.x - x1.x, x0.y - x1.y), d23 = make_float2(x2.x - x3.x, x2.y - x3.y);
+                    DFT_AT(dst, i + j) = make_float2(s01.x + s23.x, s01.y + s23.y);
+                    DFT_AT(dst, i + j + nx) = make_float2(d01.x + d23.y, d01.y - d23.x);
+                    DFT_AT(dst, i + j + 2 * nx) = make_float2(s01.x - s23.x, s01.y - s23.y);
+                    DFT_AT(dst, i + j + 3 * nx) = make_float2(d01.x - d23.y, d01.y + d23.x);
+                }
+            }
+        }
+        for (; n < f0;) {                                                        // the remaining radix-2 pass
+            n *= 2; dw0 /= 2;
+            const int nx = n / 2;
+            for (int i = 0; i < N; i += n)
+                for (int j = 0, dw = 0; j < nx; ++j, dw += dw0) {
+                    const float2 v0 = DFT_AT(dst, i + j), vn = DFT_AT(dst, i + j + nx);
+                    float2 x1 = vn;
+                    if (j > 0) { const float2 w = wave[dw]; x1 = make_float2(vn.x * w.x - vn.y * w.y, vn.y * w.x + vn.x * w.y); }
+                    DFT_AT(dst, i + j) = make_float2(v0.x + x1.x, v0.y + x1.y);
+                    DFT_AT(dst, i + j + nx) = make_float2(v0.x - x1.x, v0.y - x1.y);
+                }
+        }
+    }
+    for (int f_idx = (c.factors[0] & 1) ? 0 : 1; f_idx < c.nf; ++f_idx) {        // 2. odd factors
+        const int factor = c.factors[f_idx];
+        const int nx = n;
+        n *= factor; dw0 /= factor;
+        if (factor == 3) {
+            const float sin_120 = (float)0.86602540378443864676372317075294;
+            for (int i = 0; i < N; i += n)
+                for (int j = 0, dw = 0; j < nx; ++j, dw += dw0) {
+                    const float2 v0 = DFT_AT(dst, i + j), a = DFT_AT(dst, i + j + nx), b = DFT_AT(dst, i + j + 2 * nx);
+                    float r0, i0, r1, i1, r2, i2;
+                    if (j == 0) {
+                        r1 = a.x + b.x; i1 = a.y + b.y;
+                        r2 = sin_120 * (a.y - b.y); i2 = sin_120 * (b.x - a.x);
+                    } else {
+                        const float2 w1 = wave[dw], w2 = wave[dw * 2];
+                        const float ar = a.x * w1.x - a.y * w1.y, ai = a.x * w1.y + a.y * w1.x;
+                        const float br = b.x * w2.x - b.y * w2.y, bi = b.x * w2.y + b.y * w2.x;
+                        r1 = ar + br; i1 = ai + bi;
+                        r2 = sin_120 * (ai - bi); i2 = sin_120 * (br - ar);
+                    }
+                    r0 = v0.x; i0 = v0.y;
+                    DFT_AT(dst, i + j) = make_float2(r0 + r1, i0 + i1);
+                    r0 -= 0.5f * r1; i0 -= 0.5f * i1;
+                    DFT_AT(dst, i + j + nx) = make_float2(r0 + r2, i0 + i2);
+                    DFT_AT(dst, i + j + 2 * nx) = make_float2(r0 - r2, i0 - i2);
+                }
+        } else if (factor == 5) {
+            const float fft5_2 = (float)0.559016994374947424102293417182819, fft5_3 = (float)-0.951056516295153572116439333379382;
+            const float fft5_4 = (float)-1.538841768587626701285145288018455, fft5_5 = (float)0.363271264002680442947733378740309;
+            for (int i = 0; i < N; i += n)
+                for (int j = 0, dw = 0; j < nx; ++j, dw += dw0) {
+                    const float2 a0 = DFT_AT(dst, i + j), a1 = DFT_AT(dst, i + j + nx), a2 = DFT_AT(dst, i + j + 2 * nx),
+                                 a3 = DFT_AT(dst, i + j + 3 * nx), a4 = DFT_AT(dst, i + j + 4 * nx);
+                    const float2 w1 = wave[dw], w2 = wave[dw * 2], w3 = wave[dw * 3], w4 = wave[dw * 4];
+                    float r0, i0, r1, i1, r2, i2, r3, i3, r4, i4, r5, i5;
+                    r3 = a1.x * w1.x - a1.y * w1.y; i3 = a1.x * w1.y + a1.y * w1.x;
+                    r2 = a4.x * w4.x - a4.y * w4.y; i2 = a4.x * w4.y + a4.y * w4.x;
+                    r1 = r3 + r2; i1 = i3 + i2;
+                    r3 -= r2; i3 -= i2;
+                    r4 = a3.x * w3.x - a3.y * w3.y; i4 = a3.x * w3.y + a3.y * w3.x;
+                    r0 = a2.x * w2.x - a2.y * w2.y; i0 = a2.x * w2.y + a2.y * w2.x;
+                    r2 = r4 + r0; i2 = i4 + i0;
+                    r4 -= r0; i4 -= i0;
+                    r0 = a0.x; i0 = a0.y;
+                    r5 = r1 + r2; i5 = i1 + i2;
+                    DFT_AT(dst, i + j) = make_float2(r0 + r5, i0 + i5);
+                    r0 -= 0.25f * r5; i0 -= 0.25f * i5;
+                    r1 = fft5_2 * (r1 - r2); i1 = fft5_2 * (i1 - i2);
+                    r2 = -fft5_3 * (i3 + i4); i2 = fft5_3 * (r3 + r4);
+                    i3 *= -fft5_5; r3 *= fft5_5;
+                    i4 *= -fft5_4; r4 *= fft5_4;
+                    r5 = r2 + i3; i5 = i2 + r3;
+                    r2 -= i4; i2 -= r4;
+                    r3 = r0 + r1; i3 = i0 + i1;
+                    r0 -= r1; i0 -= i1;
+                    DFT_AT(dst, i + j + nx) = make_float2(r3 + r2, i3 + i2);
+                    DFT_AT(dst, i + j + 4 * nx) = make_float2(r3 - r2, i3 - i2);
+                    DFT_AT(dst, i + j + 2 * nx) = make_float2(r0 + r5, i0 + i5);
+                    DFT_AT(dst, i + j + 3 * nx) = make_float2(r0 - r5, i0 - i5);
+                }
+        }
+    }
+}
+#undef DFT_AT
+
+__global__ void __launch_bounds__(64) k_dft_lines(const float2* __restrict__ src, float2* __restrict__ dst, int count, int line_pitch,
+                                                  int stride, DftPlanDev plan) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= count) return;
+    dft_c2c_forward(src + (size_t)t * line_pitch, dst + (size_t)t * line_pitch, stride, plan);
+}
+// 2-D forward transform of an m x n complex image: rows (src -> tmp), then columns (tmp -> dst)
+void launch_dft2d_exact(const float2* src, float2* tmp, float2* dst, int n, int m, const DftPlanDev& rows, const DftPlanDev& cols, hipStream_t s) {
+    hipLaunchKernelGGL(k_dft_lines, dim3((m + 63) / 64), dim3(64), 0, s, src, tmp, m, n, 1, rows);
+    hipLaunchKernelGGL(k_dft_lines, dim3((n + 63) / 64), dim3(64), 0, s, tmp, dst, n, 1, n, cols);
+}
+
 void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s) {
     hipLaunchKernelGGL(k_pad_complex, dim3((n + 255) / 256, m), dim3(256), 0, s, src, dst, w, h, n, m);
 }

@@ -1,9 +1,10 @@
 """GPU parity of the rest of the pre-ORB chain (src/extractor.cpp:33-83, src/poppy.hpp:119-122) through the C ABI.
 
-Exact stages are compared bit for bit (unsharp sigma 2 + grey; everything up to goodFeatures is covered by
-test_gpu_prefilter.py).  The two Gabor banks and dft_detail2 go through FFTs in the reference (filter2D's DFT path,
-cv::dft): their float rounding follows the butterfly order, so those are held to a stated tolerance, and so is what
-depends on them (ORB input pixels, nfeatures, keypoints, frames).  Tolerances are written next to each assertion;
+Exact stages are compared bit for bit: unsharp sigma 2 + grey, and dft_detail2 — the RMS of raw float bytes of the
+spectrum, which only cv::dft's exact factorisation and butterfly order reproduces (everything up to goodFeatures is
+covered by test_gpu_prefilter.py).  The two Gabor banks go through filter2D's DFT-based correlation in the reference;
+here they are direct convolutions, held to a stated tolerance, and so is what depends on them (a few ORB input
+pixels, hence a few keypoints and frame regions).  Tolerances are written next to each assertion;
 the measured values are in DESIGN.md section 7."""
 import numpy as np
 import pytest
@@ -32,8 +33,7 @@ def test_orb_input_chain_from_reference_good_features(ctx, case):
     assert np.abs(r["gb"] - gb).max() <= 1e-5                       # Gabor bank: direct convolution vs DFT-based filter2D (measured 1.6e-6)
     dg = np.abs(r["g"].astype(int) - G.full(case, "g1").astype(int))
     assert (dg > 0).mean() <= 1e-3                                  # ORB input: a handful of pixels flip a level (measured 1.5e-5 of them)
-    det = G.full(case, "detail")
-    assert abs(r["detail"] - det[0]) / det[0] <= 5e-3              # RMS of raw float bytes: +-1e-3 between ANY two FFTs (numpy f32 / f64 spread 1.4e-3)
+    assert r["detail"] == G.full(case, "detail")[0]                 # dft_detail2: exact (cv::dft's operation order is reproduced)
 
 
 def test_gabor_field_vs_reference(ctx):
@@ -51,7 +51,7 @@ def test_pair_begin_from_raw_images(case):
     c = capi.Context(0, number_of_frames=int(inp["cfg"][0]))
     nf, det = c.pair_begin(inp["img1"], inp["img2"])
     ref = G.full(case, "detail")
-    assert abs(nf - int(ref[3])) <= 3                               # nfeatures = int(300 * 255 / max(d1, d2)); measured: equal
+    assert nf == int(ref[3]) and det == (ref[0], ref[1])            # dft_detail2 -> nfeatures: exact
     p1, p2 = c.pair_points()
     r1, r2 = G.full(case, "prepared1"), G.full(case, "prepared2")
     got = set(map(tuple, np.round(np.hstack([p1, p2]), 3)))
@@ -79,3 +79,12 @@ def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
     assert np.array_equal(r["us"].view(np.uint32), us.view(np.uint32))           # exact stage
     gb = O.gabor_filter_direct(us, 31, O.gabor_bank(31, 5, 2))
     assert np.abs(r["gb"] - gb).max() <= 1e-5                                      # float vs double direct sums
+
+
+@pytest.mark.parametrize("case", sorted(G.make_inputs.DETAIL))
+def test_dft_detail2_exact(ctx, case):
+    """dft_detail2 is the RMS of raw float bytes of the spectrum: only cv::dft's exact operation order reproduces it."""
+    gray = G.make_inputs.detail_inputs(case)["gray"]
+    got = ctx.orb_input(gray)["detail"]
+    want = float(G.full(case, "detail")[0])
+    assert got == want, f"{case}: {got!r} != {want!r} (rel {abs(got - want) / want:.2e})"
