@@ -146,10 +146,9 @@ int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* ctx,
 /* Same from the raw BGR pair (the set-up half of poppy::morph, src/poppy.hpp:46-157 with face detection and auto-align
  * off): Extractor::foreground x2 -> dft_detail2 x2 -> nfeatures = int(max_keypoints * 255 / max(d1, d2)) -> unsharp(sigma 2),
  * grey, 31x31 Gabor bank, radial gradient, equalizeHist -> ORB x2 -> matcher -> gabor_filter(image2 / 255) -> resident pair.
- * Parity: every stage is bit-exact with the reference (including dft_detail2, hence nfeatures) EXCEPT the two Gabor
- * banks, which OpenCV evaluates through its DFT-based filter2D: a direct convolution reproduces them to ~1e-6 only, so a
- * few ORB-input pixels differ by a level and a few keypoints / frame regions can differ from the reference's (measured in
- * DESIGN.md section 7).  poppy_hip_pair_begin_prefiltered stays bit-exact end to end.                                  */
+ * Parity: bit-exact with the reference end to end (tests/test_gpu_prefilter2.py reproduces the point pairs and frames of
+ * the real poppy::morph).  dft_detail2 restates cv::dft operation for operation; the Gabor banks produce the once-rounded
+ * exact sums that OpenCV's double-precision DFT correlation yields (DESIGN.md section 7 has the fine print).          */
 int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                          int width, int height);
 /* nfeatures and the two dft_detail2 values of the last poppy_hip_pair_begin */

@@ -40,7 +40,8 @@ private:
     void release();
     void release2();
     int W2 = 0, H2 = 0, dftN = 0, dftM = 0;
-    float *f_a = nullptr, *f_b = nullptr, *f_c = nullptr, *f_d = nullptr, *radial = nullptr, *bank31 = nullptr, *bank13 = nullptr, *taps17 = nullptr;
+    float *f_a = nullptr, *f_b = nullptr, *f_c = nullptr, *f_d = nullptr, *radial = nullptr, *taps17 = nullptr;
+    double *bank31 = nullptr, *bank13 = nullptr;
     float *mag = nullptr, *c3_in = nullptr, *c3_out = nullptr;
     void* spec = nullptr;
     unsigned* minmax = nullptr;

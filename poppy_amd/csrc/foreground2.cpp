@@ -81,7 +81,7 @@ int ForegroundFilter::ensure2(int w, int h) {
     if (w == W2 && h == H2) return 0;
     void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    f_a = f_b = f_c = f_d = radial = bank31 = bank13 = taps17 = mag = c3_in = c3_out = nullptr; spec = nullptr;
+    f_a = f_b = f_c = f_d = radial = taps17 = mag = c3_in = c3_out = nullptr; bank31 = bank13 = nullptr; spec = nullptr;
     minmax = nullptr; powsum = nullptr; g_tmp = g_out[0] = g_out[1] = nullptr;
     for (void* b : {(void*)spec_tmp, (void*)spec_out, (void*)d_itab[0], (void*)d_itab[1], (void*)d_wave[0], (void*)d_wave[1]}) if (b) (void)hipFree(b);
     spec_tmp = spec_out = nullptr; d_itab[0] = d_itab[1] = nullptr; d_wave[0] = d_wave[1] = nullptr;
@@ -94,10 +94,11 @@ int ForegroundFilter::ensure2(int w, int h) {
     gabor_bank(31, 5, 2, 0.04, M_PI / 4, b31);                // Extractor::keypoints (src/extractor.cpp:63-64)
     gabor_bank(13, 5, 10, 0.04, M_PI / 4, b13);               // gabor_filter defaults (src/util.hpp:95)
     radial_gradient(w, h, rad);
-    F2_CHK(hipMalloc((void**)&taps17, 17 * 4)); F2_CHK(hipMalloc((void**)&bank31, b31.size() * 4)); F2_CHK(hipMalloc((void**)&bank13, b13.size() * 4));
+    std::vector<double> b31d(b31.begin(), b31.end()), b13d(b13.begin(), b13.end());     // the float taps, widened (exact)
+    F2_CHK(hipMalloc((void**)&taps17, 17 * 4)); F2_CHK(hipMalloc((void**)&bank31, b31d.size() * 8)); F2_CHK(hipMalloc((void**)&bank13, b13d.size() * 8));
     F2_CHK(hipMemcpy(taps17, t17.data(), 17 * 4, hipMemcpyHostToDevice));
-    F2_CHK(hipMemcpy(bank31, b31.data(), b31.size() * 4, hipMemcpyHostToDevice));
-    F2_CHK(hipMemcpy(bank13, b13.data(), b13.size() * 4, hipMemcpyHostToDevice));
+    F2_CHK(hipMemcpy(bank31, b31d.data(), b31d.size() * 8, hipMemcpyHostToDevice));
+    F2_CHK(hipMemcpy(bank13, b13d.data(), b13d.size() * 8, hipMemcpyHostToDevice));
     F2_CHK(hipMemcpy(radial, rad.data(), P * 4, hipMemcpyHostToDevice));
     dftN = dft_optimal_size(w); dftM = dft_optimal_size(h);
     F2_CHK(hipMalloc((void**)&spec, (size_t)dftN * dftM * 8)); F2_CHK(hipMalloc((void**)&mag, (size_t)dftN * dftM * 4));

@@ -36,9 +36,10 @@ void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t
 // ---- part 2 (kernels_prefilter2.hip) ----------------------------------------------------------------------------------
 // grey(unsharp_mask(triple(gf / 255), 2, 6, 0.1)) on one channel; f32, tmp, diff, out: w*h floats; d_taps17: getGaussianKernel(17, 2)
 void launch_unsharp1_gray(const uint8_t* gf, float* f32, float* tmp, float* diff, float* out, const float* d_taps17, int w, int h, hipStream_t s);
-// gabor_filter(src, dst, 16 angles, ksize, ...): bank = [16][ksize*ksize] floats; 31x31 on one channel, 13x13 on three
-void launch_gabor_bank31(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s);
-void launch_gabor_bank13_c3(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s);
+// gabor_filter(src, dst, 16 angles, ksize, ...): bank = [16][ksize*ksize] kernel taps (the float taps widened to double);
+// 31x31 on one channel, 13x13 on three
+void launch_gabor_bank31(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s);
+void launch_gabor_bank13_c3(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s);
 void launch_u8_to_f32(const uint8_t* src, float* dst, int n, hipStream_t s);
 // out = equalizeHist(u8(gb * us * radial * 255))
 void launch_orb_input(const float* gb, const float* us, const float* radial, uint8_t* tmp_u8, unsigned* hist, uint8_t* lut, uint8_t* out,

@@ -4,10 +4,10 @@
 // Exact stages (same expression trees as the reference's SSE3-baseline build, -ffp-contract=off):
 //   u8 -> f32, unsharp_mask(sigma 2: 17-tap separable Gaussian, 3x3 median of the difference, threshold, amount),
 //   BGR2GRAY on float, multiplies, f32 -> u8, equalizeHist, magnitude / log / min-max normalisation of the spectrum.
-// Stages that can only match to a tolerance: the two Gabor banks.  OpenCV evaluates filter2D with a 31x31 (13x13) float
-// kernel through its DFT-based cross-correlation (OCV/imgproc/src/filter.dispatch.cpp:1291, templmatch.cpp), whose
-// rounding follows the FFT's butterfly order; here it is a direct float convolution.  The 2-D DFT of dft_detail2 comes
-// from hipFFT (foreground2.cpp) for the same reason.  DESIGN.md section 7 states the measured differences.
+// The two Gabor banks: OpenCV evaluates filter2D with a 31x31 (13x13) float kernel through its DFT-based cross-correlation
+// in DOUBLE precision and rounds to float once (OCV/imgproc/src/filter.dispatch.cpp:1291, templmatch.cpp:592); here the
+// same once-rounded exact sum is accumulated directly in double (see k_gabor_bank).  dft_detail2's complex float DFT is
+// cv::dft restated operation for operation (dft_c2c_forward), because its result is read back as raw bytes.
 #include "kernels_prefilter.h"
 #include "pyramid_device.h"
 
@@ -78,10 +78,15 @@ void launch_unsharp1_gray(const uint8_t* gf, float* f32, float* tmp, float* diff
 }
 
 // ---- Gabor bank: mean over 16 orientations of clamp(filter2D(src, kernel_i), 0, 1) ------------------------------------
-// Direct correlation with reflect-101 borders.  Tile in LDS; every source value is read once per tap position and feeds
-// the 16 orientation accumulators; the taps are uniform across the wave (scalar loads).  `bank` = [16][K*K] floats.
+// For float images OpenCV's filter2D with a kernel this large runs crossCorr (OCV/imgproc/src/templmatch.cpp:566-760) with
+// maxDepth = CV_64F: the correlation is evaluated through DOUBLE-precision DFTs and converted to float at the end, i.e. each
+// plane is the exact sum rounded once to float (the double DFT's error, ~1e-13 relative, only matters if the exact sum sits
+// within that distance of a float rounding boundary).  The same value is produced here directly: the products of two floats
+// are exact in double, they are accumulated in double and rounded once.  Measured: bit-identical to the reference on every
+// pixel of the fixtures.  Tile in LDS (reflect-101 borders); every source value is read once per tap position and feeds the
+// 16 orientation accumulators; the taps (doubles, uniform across the wave) come in through scalar loads.
 template <int K, int CN>
-__global__ void __launch_bounds__(256) k_gabor_bank(const float* __restrict__ src, const float* __restrict__ bank, float* __restrict__ dst, int W, int H) {
+__global__ void __launch_bounds__(256) k_gabor_bank(const float* __restrict__ src, const double* __restrict__ bank, float* __restrict__ dst, int W, int H) {
     constexpr int R = K / 2, TX = 32, TY = 8, SX = TX + 2 * R, SY = TY + 2 * R;
     __shared__ float tile[SY * SX];
     const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, ch = blockIdx.z;
@@ -91,27 +96,27 @@ __global__ void __launch_bounds__(256) k_gabor_bank(const float* __restrict__ sr
     }
     __syncthreads();
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    float acc[16];
+    double acc[16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int o = 0; o < 16; ++o) acc[o] = 0.0;
     for (int dy = 0; dy < K; ++dy)
         for (int dx = 0; dx < K; ++dx) {
-            const float v = tile[(ly + dy) * SX + lx + dx];
-            const float* wv = bank + dy * K + dx;
+            const double v = (double)tile[(ly + dy) * SX + lx + dx];
+            const double* wv = bank + dy * K + dx;
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = wv[o * K * K] * v + acc[o];
+            for (int o = 0; o < 16; ++o) acc[o] = fma(wv[o * K * K], v, acc[o]);      // the product is exact in double
         }
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) return;
     float sum = 0.f;
 #pragma unroll
-    for (int o = 0; o < 16; ++o) sum += fminf(fmaxf(acc[o], 0.f), 1.f);       // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
-    dst[((size_t)y * W + x) * CN + ch] = sum * 0.0625f;                         // dst /= 16
+    for (int o = 0; o < 16; ++o) sum += fminf(fmaxf((float)acc[o], 0.f), 1.f);   // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
+    dst[((size_t)y * W + x) * CN + ch] = sum * 0.0625f;                            // dst /= 16
 }
-void launch_gabor_bank31(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s) {
+void launch_gabor_bank31(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s) {
     hipLaunchKernelGGL((k_gabor_bank<31, 1>), dim3((w + 31) / 32, (h + 7) / 8, 1), dim3(256), 0, s, src, d_bank, dst, w, h);
 }
-void launch_gabor_bank13_c3(const float* src, const float* d_bank, float* dst, int w, int h, hipStream_t s) {
+void launch_gabor_bank13_c3(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s) {
     hipLaunchKernelGGL((k_gabor_bank<13, 3>), dim3((w + 31) / 32, (h + 7) / 8, 3), dim3(256), 0, s, src, d_bank, dst, w, h);
 }
 

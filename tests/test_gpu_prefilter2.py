@@ -1,11 +1,12 @@
-"""GPU parity of the rest of the pre-ORB chain (src/extractor.cpp:33-83, src/poppy.hpp:119-122) through the C ABI.
+"""GPU parity of the rest of the pre-ORB chain (src/extractor.cpp:33-83, src/poppy.hpp:119-122) through the C ABI,
+against the real reference's outputs (tests/golden/a_*, d_*).
 
-Exact stages are compared bit for bit: unsharp sigma 2 + grey, and dft_detail2 — the RMS of raw float bytes of the
-spectrum, which only cv::dft's exact factorisation and butterfly order reproduces (everything up to goodFeatures is
-covered by test_gpu_prefilter.py).  The two Gabor banks go through filter2D's DFT-based correlation in the reference;
-here they are direct convolutions, held to a stated tolerance, and so is what depends on them (a few ORB input
-pixels, hence a few keypoints and frame regions).  Tolerances are written next to each assertion;
-the measured values are in DESIGN.md section 7."""
+Everything is compared bit for bit: unsharp sigma 2 + grey; dft_detail2 (the RMS of raw float bytes of the spectrum,
+which only cv::dft's exact factorisation and butterfly order reproduces); the ORB input images; gabor2; the prepared
+point pairs and the chained frames of the real poppy::morph.  One intermediate is allowed a tolerance: the Gabor mean
+BEFORE it is multiplied and quantised.  The reference computes each Gabor plane through double-precision DFTs and
+rounds it to float once; the kernel accumulates the same sum directly in double and rounds once.  Where the exact
+value is ~0 the DFT's own noise (1e-13) shows up as a different tiny float; those values vanish in the next stage."""
 import numpy as np
 import pytest
 
@@ -30,9 +31,8 @@ def test_orb_input_chain_from_reference_good_features(ctx, case):
     r = ctx.orb_input(gf1)
     G.check(case, "us1", r["us"])                                   # unsharp_mask(sigma 2) + BGR2GRAY: exact
     gb = G.full(case, "gb1")
-    assert np.abs(r["gb"] - gb).max() <= 1e-5                       # Gabor bank: direct convolution vs DFT-based filter2D (measured 1.6e-6)
-    dg = np.abs(r["g"].astype(int) - G.full(case, "g1").astype(int))
-    assert (dg > 0).mean() <= 1e-3                                  # ORB input: a handful of pixels flip a level (measured 1.5e-5 of them)
+    assert np.abs(r["gb"] - gb).max() <= 1e-12                      # Gabor mean: once-rounded exact sums vs double-DFT noise (measured 1.3e-13)
+    G.check(case, "g1", r["g"])                                     # the ORB input image: exact
     assert r["detail"] == G.full(case, "detail")[0]                 # dft_detail2: exact (cv::dft's operation order is reproduced)
 
 
@@ -40,32 +40,26 @@ def test_gabor_field_vs_reference(ctx):
     case = "a_256x256_chain"
     inp = G.astage_inputs(case)
     gab = ctx.gabor_field(inp["img2"])
-    assert np.abs(gab - G.full(case, "gabor2")).max() <= 1e-5       # measured 1.8e-6
+    G.check(case, "gabor2", gab)                                    # exact
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_pair_begin_from_raw_images(case):
-    """Whole set-up on the GPU from the raw pair; compared with the real poppy::morph (tolerance, see module docstring)."""
+def test_pair_begin_from_raw_images_reproduces_poppy_morph(case):
+    """Whole pipeline on the GPU from the raw pair: nfeatures, prepared point pairs and every chained frame of the real
+    poppy::morph, bit for bit."""
     from poppy_amd import capi
     inp = G.astage_inputs(case)
     c = capi.Context(0, number_of_frames=int(inp["cfg"][0]))
     nf, det = c.pair_begin(inp["img1"], inp["img2"])
     ref = G.full(case, "detail")
-    assert nf == int(ref[3]) and det == (ref[0], ref[1])            # dft_detail2 -> nfeatures: exact
+    assert nf == int(ref[3]) and det == (ref[0], ref[1])
     p1, p2 = c.pair_points()
-    r1, r2 = G.full(case, "prepared1"), G.full(case, "prepared2")
-    got = set(map(tuple, np.round(np.hstack([p1, p2]), 3)))
-    want = set(map(tuple, np.round(np.hstack([r1, r2]), 3)))
-    assert len(got & want) >= 0.9 * len(want)                       # measured 383 of 388 identical pairs
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
     frames = c.morph_frames(-1.0)
     assert len(frames) == int(inp["cfg"][0])
-    G.check(case, "frame0", frames[0])                              # shape ratio 0: image 1 through the blend, no mesh dependence
-    for j in (1, 2):
-        ref_f = G.full(case, f"frame{j}")
-        if ref_f is None:
-            continue
-        d = np.abs(frames[j].astype(int) - ref_f.astype(int))
-        assert (d > 0).mean() <= 0.15 and d.mean() <= 2.0           # measured 1.8-3.4 % of pixels, mean 0.24-0.32 levels
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
     c.close()
 
 
@@ -78,7 +72,7 @@ def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
     us = O.orb_unsharp_gray(gf)
     assert np.array_equal(r["us"].view(np.uint32), us.view(np.uint32))           # exact stage
     gb = O.gabor_filter_direct(us, 31, O.gabor_bank(31, 5, 2))
-    assert np.abs(r["gb"] - gb).max() <= 1e-5                                      # float vs double direct sums
+    assert np.array_equal(r["gb"].view(np.uint32), gb.view(np.uint32))             # both: exact products, double sums, one rounding
 
 
 @pytest.mark.parametrize("case", sorted(G.make_inputs.DETAIL))
