@@ -325,10 +325,16 @@ class Context:
         n = lib().poppy_hip_timing_summary(self.h, names, ms, cnt, 32)
         return [(names[i].decode(), ms[i], cnt[i]) for i in range(n)]
 
-    def render_many(self, shapes, masks=None, chain=False):
+    def render_many(self, shapes, masks=None, chain=False, write=None):
+        """write: optional callable(frame_view) invoked for every frame with a view of the pinned host copy (valid during the call)."""
         sh = np.ascontiguousarray(shapes, np.float64)
         mk = sh if masks is None else np.ascontiguousarray(masks, np.float64)
-        self._chk(lib().poppy_hip_render_many(self.h, _p(sh), _p(mk), len(sh), int(chain), None, None), "render_many")
+        fn = None
+        if write is not None:
+            def cb(user, ptr, w, h, stride):
+                write(np.ctypeslib.as_array(ptr, shape=(h, stride))[:, :w * 3].reshape(h, w, 3))
+            fn = WRITE_CB(cb)
+        self._chk(lib().poppy_hip_render_many(self.h, _p(sh), _p(mk), len(sh), int(chain), C.cast(fn, C.c_void_p) if fn else None, None), "render_many")
 
     def frame_device_ptr(self):
         return lib().poppy_hip_frame_device(self.h)

@@ -99,6 +99,9 @@ struct poppy_hip_ctx {
     std::vector<Mark> marks; size_t marks_used = 0;
     // staging for host-image entry points
     uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
+    static const int kStageRing = 3;          // pinned frames in flight towards the writer
+    hipStream_t dl_stream = nullptr;
+    hipEvent_t dl_done[kStageRing] = {};
 };
 
 #define HIPCHK(ctx, call)                                                                             \
@@ -183,6 +186,8 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     }
     if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
@@ -360,7 +365,17 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
     int rc = POPPY_OK;
-    const size_t row = (size_t)W * 3;
+    const size_t row = (size_t)W * 3, frame_bytes = row * H;
+    const int R = std::min(poppy_hip_ctx::kStageRing, (int)c->slots.size());
+    int written = 0;
+    if (write) {
+        rc = stage_host(c, frame_bytes * R);
+        if (rc == POPPY_OK && !c->dl_stream) {
+            if (hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipStreamCreate failed");
+            for (int k = 0; k < poppy_hip_ctx::kStageRing && rc == POPPY_OK; ++k)
+                if (hipEventCreateWithFlags(&c->dl_done[k], hipEventDisableTiming) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipEventCreate failed");
+        }
+    }
     for (int j = 0; j < n && rc == POPPY_OK; ++j) {
         while (!ready[j].load(std::memory_order_acquire)) std::this_thread::yield();
         if (rcs[j]) { rc = fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)"); break; }
@@ -368,12 +383,29 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         if (chain) c->pts1 = src1[j];
         rc = submit_frame(c, mask[j], chain);
         if (rc == POPPY_OK && write) {
-            hipError_t e = hipMemcpyAsync(c->h_stage, c->slots[c->last_slot].out, row * H, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            // Frame hand-off: the download of frame j runs on its own stream into a ring of pinned buffers while the GPU
+            // renders frame j+1; the writer gets frame j-(R-1).  R <= number of slots, so by the time a slot is rendered
+            // into again its previous frame has been handed over (the host waited for that download).
+            const int r = j % R;
+            FrameSlot& f = c->slots[c->last_slot];
+            hipError_t e = hipStreamWaitEvent(c->dl_stream, f.done, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * frame_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
+            if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
             if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; break; }
-            write(user, c->h_stage, W, H, row);
+            if (j >= R - 1) {
+                const int jr = j - (R - 1), rr = jr % R;
+                if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; break; }
+                write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
+                ++written;
+            }
         }
     }
+    if (write && rc == POPPY_OK)
+        for (int jr = written; jr < n; ++jr) {            // drain the ring
+            const int rr = jr % R;
+            if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; break; }
+            write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
+        }
     next.store(n);                         // on an error: let the workers drain
     for (auto& t : pool) t.join();
     return rc;
