@@ -160,6 +160,11 @@ int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail
 int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
 int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
 int poppy_radial_gradient(int width, int height, float* out);
+
+/* blur_margin (src/util.cpp:574-602), the CLI's padding step before poppy::morph (src/poppy.cpp:233-240,293-308): the image
+ * centred in a union_width x union_height canvas, the four margin strips Gaussian-blurred (127x127, sigma 6).  Bit-exact.   */
+int poppy_hip_blur_margin(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height,
+                          int union_width, int union_height, uint8_t* dst, size_t dst_stride);
 /* copies of the resident point sets after pair_begin / pair_load (n x 2 floats each); n via *n_points */
 int poppy_hip_pair_points(poppy_hip_ctx* ctx, float* points1, float* points2, int max_points, int* n_points);
 

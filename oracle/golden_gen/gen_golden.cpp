@@ -575,6 +575,15 @@ static void dump_detail() {
     }
 }
 
+// blur_margin (src/util.cpp:574-602): the CLI's padding of an image into the union canvas
+static void dump_margin() {
+    Mat a = read_mat("img");
+    vector<double> cfg = read_f64("cfg");          // union width, height
+    Mat out;
+    blur_margin(a, Size((int)cfg[0], (int)cfg[1]), out);
+    dump_mat("padded", out);
+}
+
 static void dump_logcheck() {      // cv::log / cv::magnitude on given floats (debugging aid for the oracle)
     Mat x = read_mat("x"), y;
     log(x, y);
@@ -595,6 +604,7 @@ int main(int argc, char** argv) {
     else if (mode == "fstage") dump_fstage();
     else if (mode == "detail") dump_detail();
     else if (mode == "logcheck") dump_logcheck();
+    else if (mode == "margin") dump_margin();
     else { fprintf(stderr, "unknown mode\n"); return 1; }
     return 0;
 }

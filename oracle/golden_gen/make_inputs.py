@@ -79,6 +79,19 @@ def detail_inputs(name):
     return {"gray": synth.textured_gray(w, h, seed)}
 
 
+MARGIN = {
+    # name: (w, h, union_w, union_h, seed): blur_margin (src/util.cpp:574-602)
+    "g_same_200x150": (200, 150, 200, 150, 61),        # equal sizes: one-pixel strips still get blurred
+    "g_wide_200x150_in_260x150": (200, 150, 260, 150, 62),
+    "g_both_181x97_in_240x160": (181, 97, 240, 160, 63),
+}
+
+
+def margin_inputs(name):
+    w, h, uw, uh, seed = MARGIN[name]
+    return {"img": synth.textured_bgr(w, h, seed), "cfg": np.array([uw, uh], dtype=np.float64)}
+
+
 def fstage_inputs(name):
     w, h, seed = FSTAGE[name]
     return {"img1": synth.textured_bgr(w, h, seed)}
@@ -147,6 +160,7 @@ def all_cases():
     out += [("prims", "p_prims", lambda _n: prims_inputs())]
     out += [("fstage", n, fstage_inputs) for n in FSTAGE]
     out += [("detail", n, detail_inputs) for n in DETAIL]
+    out += [("margin", n, margin_inputs) for n in MARGIN]
     return out
 
 

@@ -35,7 +35,7 @@ def load_raw(path):
 def keep_full(name, arr):
     if arr.nbytes <= FULL_LIMIT:
         return True
-    big_ok = name.startswith("frame") or name.endswith("frame") or name in ("g1", "g2", "gabor2", "us1", "gb1", "radial") or "trImg" in name
+    big_ok = name.startswith("frame") or name.endswith("frame") or name in ("g1", "g2", "gabor2", "us1", "gb1", "radial", "padded") or "trImg" in name
     return big_ok and arr.nbytes <= FRAME_LIMIT
 
 

@@ -138,4 +138,7 @@ void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, st
 void gabor_filter_direct(const ImageF& src, int ks, const std::vector<float>& bank, ImageF& dst);   // tolerance comparator
 void orb_unsharp_gray(const ImageU8& gf, ImageF& us);
 
+void gaussian_blur_fx_u8(const ImageU8& src, int ksize, double sigma, ImageU8& dst);   // GaussianBlur on 8 bit, fixed-point path
+void blur_margin(const ImageU8& src, int union_w, int union_h, ImageU8& dst);            // src/util.cpp:574-602
+
 }  // namespace oracle

@@ -158,4 +158,6 @@ void orc_gabor_filter_direct(const float* src, int w, int h, int c, int ks, cons
     gabor_filter_direct(wrap_f(src, w, h, c), ks, b, o); put_img(dst, o);
 }
 
+void orc_blur_margin(const uint8_t* src, int w, int h, int uw, int uh, uint8_t* dst) { ImageU8 o; blur_margin(wrap_u8(src, w, h, 3), uw, uh, o); put_img(dst, o); }
+
 }  // extern "C"

@@ -326,4 +326,68 @@ void orb_unsharp_gray(const ImageU8& gf, ImageF& us) {
     }
 }
 
+// ---- blur_margin (src/util.cpp:574-602): pad into the union canvas, blur the four margin strips ------------------------------
+// 8-bit GaussianBlur, any odd ksize: taps in 8.8 fixed point with error diffusion (smooth.dispatch.cpp:224-258), exact integer
+// sums, (sum + 2^15) >> 16 at the end (smooth.simd.hpp:1136-1199,1780-1866); a dimension of size 1 is not filtered (:626-631).
+static void gaussian_taps_fx(int n, double sigma, std::vector<int>& taps) {
+    std::vector<double> v(n); double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2 * sigma * sigma)); sum += v[i]; }
+    taps.assign(n, 0);
+    double err = 0; int tot = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        const double adj = v[i] / sum * 256 + err;
+        const int v0 = cv_round(adj);
+        err = adj - v0;
+        taps[i] = taps[n - 1 - i] = v0; tot += v0;
+    }
+    taps[n / 2] = 256 - 2 * tot;
+}
+
+void gaussian_blur_fx_u8(const ImageU8& src, int ksize, double sigma, ImageU8& dst) {
+    const int w = src.w, h = src.h, cn = src.c;
+    std::vector<int> kx, ky, one(1, 256);
+    gaussian_taps_fx(ksize, sigma, kx);
+    ky = kx;
+    if (w == 1) kx = one;
+    if (h == 1) ky = one;
+    const int nx = (int)kx.size(), ny = (int)ky.size();
+    std::vector<uint32_t> hbuf((size_t)w * h * cn);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < cn; ++c) {
+                uint32_t s = 0;
+                for (int k = 0; k < nx; ++k)
+                    if (kx[k]) s += (uint32_t)kx[k] * src.d[((size_t)y * w + border_reflect101(x + k - nx / 2, w)) * cn + c];
+                hbuf[((size_t)y * w + x) * cn + c] = s;
+            }
+    dst = ImageU8(w, h, cn);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < cn; ++c) {
+                uint32_t s = 0;
+                for (int k = 0; k < ny; ++k)
+                    if (ky[k]) s += (uint32_t)ky[k] * hbuf[((size_t)border_reflect101(y + k - ny / 2, h) * w + x) * cn + c];
+                const uint32_t v = (s + (1u << 15)) >> 16;
+                dst.d[((size_t)y * w + x) * cn + c] = (uint8_t)(v > 255 ? 255 : v);
+            }
+}
+
+void blur_margin(const ImageU8& src, int uw, int uh, ImageU8& dst) {
+    ImageU8 U(uw, uh, 3);
+    const double margin = (src.w + src.h) / 100.0;
+    double dx = std::fabs((double)(src.w - uw)) / 2.0, dy = std::fabs((double)(src.h - uh)) / 2.0;
+    const int rx = (int)dx, ry = (int)dy;
+    for (int y = 0; y < src.h; ++y) memcpy(&U.d[((size_t)(ry + y) * uw + rx) * 3], src.row(y), (size_t)src.w * 3);
+    dx = (dx == 0 ? 1.3 : dx + margin);
+    dy = (dy == 0 ? 1.3 : dy + margin);
+    const int rects[4][4] = {{0, 0, (int)dx, uh}, {(int)(uw - dx), 0, (int)dx, uh}, {0, 0, uw, (int)dy}, {0, (int)(uh - dy), uw, (int)dy}};
+    dst = U;
+    for (const auto& r : rects) {                       // all four strips are cut from the unblurred canvas; written in this order
+        ImageU8 strip(r[2], r[3], 3), blurred;
+        for (int y = 0; y < r[3]; ++y) memcpy(strip.row(y), &U.d[((size_t)(r[1] + y) * uw + r[0]) * 3], (size_t)r[2] * 3);
+        gaussian_blur_fx_u8(strip, 127, 6, blurred);
+        for (int y = 0; y < r[3]; ++y) memcpy(&dst.d[((size_t)(r[1] + y) * uw + r[0]) * 3], blurred.row(y), (size_t)r[2] * 3);
+    }
+}
+
 }  // namespace oracle

@@ -28,7 +28,7 @@ SYMBOLS = [
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
         L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
         L.poppy_hip_gabor_field.argtypes = [vp, vp, sz, i, i, vp]
         L.poppy_radial_gradient.argtypes = [i, i, vp]
+        L.poppy_hip_blur_margin.argtypes = [vp, vp, sz, i, i, i, i, vp, sz]
         L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
         L.poppy_hip_hamming_match.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.poppy_match_points.argtypes = [vp, vp, i, i, i, d, vp, vp, vp, vp]
@@ -233,6 +234,13 @@ class Context:
         g = np.zeros((h, w), np.uint8); us = np.zeros((h, w), np.float32); gb = np.zeros((h, w), np.float32); d = C.c_double(0)
         self._chk(lib().poppy_hip_orb_input(self.h, _p(gf), w, h, _p(g), _p(us), _p(gb), C.byref(d)), "orb_input")
         return dict(g=g, us=us, gb=gb, detail=d.value)
+
+    def blur_margin(self, bgr, union_w, union_h):
+        a = np.ascontiguousarray(bgr, np.uint8)
+        h, w = a.shape[:2]
+        out = np.zeros((union_h, union_w, 3), np.uint8)
+        self._chk(lib().poppy_hip_blur_margin(self.h, _p(a), w * 3, w, h, union_w, union_h, _p(out), union_w * 3), "blur_margin")
+        return out
 
     def gabor_field(self, bgr):
         a = np.ascontiguousarray(bgr, np.uint8)

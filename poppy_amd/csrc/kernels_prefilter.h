@@ -30,6 +30,10 @@ void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, i
 void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
                     uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s);
 
+// GaussianBlur (8-bit fixed-point path, n taps in 8.8) of the strip (rx, ry, rw, rh) of a 3-channel canvas of width cw, read from
+// `canvas`, written to the same place in `out`; tmp: rw*rh*3 uint32
+void launch_strip_blur(const uint8_t* canvas, uint8_t* out, int cw, uint32_t* tmp, const int* d_taps, int n, int rx, int ry, int rw, int rh, hipStream_t s);
+
 // equalizeHist given the 256-bin histogram of src (lut: 256 bytes of scratch)
 void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t* lut, uint8_t* out, int n_px, hipStream_t s);
 

@@ -310,6 +310,41 @@ void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, i
     hipLaunchKernelGGL(k_gauss23_v, grid, dim3(256), 0, s, tmp, dst, w, h);
 }
 
+// ---- blur_margin's GaussianBlur(127x127, sigma 6) of one strip of a 3-channel 8-bit canvas (src/util.cpp:574-602) -------------
+// The strip (rx, ry, rw, rh) is filtered as an image of its own: reflect-101 inside the strip; a strip dimension of 1 is not
+// filtered (the taps collapse to {256}).  taps: n fixed-point (8.8) values.  Pass 1 reads the unblurred canvas, pass 2 writes
+// the output canvas.
+__global__ void __launch_bounds__(256) k_strip_h(const uint8_t* __restrict__ canvas, int cw, uint32_t* __restrict__ tmp, const int* __restrict__ taps, int n,
+                                                 int rx, int ry, int rw, int rh) {
+    const int e = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;      // e = x * 3 + channel inside the strip
+    if (e >= rw * 3) return;
+    const int x = e / 3, c = e - x * 3;
+    uint32_t s = 0;
+    if (rw == 1) s = 256u * canvas[((size_t)(ry + y) * cw + rx) * 3 + c];
+    else
+        for (int k = 0; k < n; ++k)
+            if (taps[k]) s += (uint32_t)taps[k] * canvas[((size_t)(ry + y) * cw + rx + reflect101(x + k - n / 2, rw)) * 3 + c];
+    tmp[(size_t)y * rw * 3 + e] = s;
+}
+__global__ void __launch_bounds__(256) k_strip_v(const uint32_t* __restrict__ tmp, uint8_t* __restrict__ out, int cw, const int* __restrict__ taps, int n,
+                                                 int rx, int ry, int rw, int rh) {
+    const int e = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (e >= rw * 3) return;
+    uint32_t s = 0;
+    if (rh == 1) s = 256u * tmp[e];
+    else
+        for (int k = 0; k < n; ++k)
+            if (taps[k]) s += (uint32_t)taps[k] * tmp[(size_t)reflect101(y + k - n / 2, rh) * rw * 3 + e];
+    const uint32_t v = (s + (1u << 15)) >> 16;
+    out[((size_t)(ry + y) * cw + rx) * 3 + e] = (uint8_t)(v > 255 ? 255 : v);
+}
+void launch_strip_blur(const uint8_t* canvas, uint8_t* out, int cw, uint32_t* tmp, const int* d_taps, int n, int rx, int ry, int rw, int rh, hipStream_t s) {
+    if (rw <= 0 || rh <= 0) return;
+    dim3 grid((rw * 3 + 255) / 256, rh);
+    hipLaunchKernelGGL(k_strip_h, grid, dim3(256), 0, s, canvas, cw, tmp, d_taps, n, rx, ry, rw, rh);
+    hipLaunchKernelGGL(k_strip_v, grid, dim3(256), 0, s, tmp, out, cw, d_taps, n, rx, ry, rw, rh);
+}
+
 // ---- log mask, multiply, 8 bit, histogram --------------------------------------------------------------------------------
 // cv::log for floats: 256-entry table of (ln(1 + i/256), 1/(1 + i/256)) — the last entry is (ln 2, 1/2) with the argument
 // shifted by -1/512 — and a cubic; the table is computed on the host in long double and handed over as floats.

@@ -21,6 +21,7 @@
 #include "foreground.h"
 #include "frame_plan.h"
 #include "kernels.h"
+#include "kernels_prefilter.h"
 #include "orb_detect.h"
 #include "point_match.h"
 #include <hip/hip_runtime.h>
@@ -895,6 +896,46 @@ int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, i
     if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
     HIPCHK(c, hipMemcpyAsync(out, gab, (size_t)W * H * 12, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
+// blur_margin (src/util.cpp:574-602): what the reference's CLI does to every image before poppy::morph when the phase is not 0 / 1
+// (src/poppy.cpp:233-240,293-308): centre it in the union canvas and blur the four margin strips (127x127, sigma 6, fixed point).
+int poppy_hip_blur_margin(poppy_hip_ctx* c, const uint8_t* src, size_t stride, int W, int H, int UW, int UH, uint8_t* dst, size_t dst_stride) {
+    if (!c) return POPPY_E_ARG;
+    if (!src || !dst || W <= 0 || H <= 0 || UW < W || UH < H || stride < (size_t)W * 3 || dst_stride < (size_t)UW * 3) return fail(c, POPPY_E_ARG, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t UB = (size_t)UW * UH * 3;
+    uint8_t *canvas = nullptr, *out = nullptr; uint32_t* tmp = nullptr; int* d_taps = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)canvas, (void*)out, (void*)tmp, (void*)d_taps}) if (p) (void)hipFree(p); };
+    // taps: exp(-x^2 / 2 sigma^2) / sum in double, to 8 fractional bits with error diffusion, centre = 256 - rest (smooth.dispatch.cpp:224-258)
+    const int n = 127; const double sigma = 6;
+    std::vector<double> v(n); double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2 * sigma * sigma)); sum += v[i]; }
+    std::vector<int> taps(n, 0);
+    { double err = 0; int tot = 0;
+      for (int i = 0; i < n / 2; ++i) { const double adj = v[i] / sum * 256 + err; const int v0 = (int)std::nearbyint(adj); err = adj - v0; taps[i] = taps[n - 1 - i] = v0; tot += v0; }
+      taps[n / 2] = 256 - 2 * tot; }
+    hipError_t e = hipMalloc((void**)&canvas, UB);
+    if (e == hipSuccess) e = hipMalloc((void**)&out, UB);
+    if (e == hipSuccess) e = hipMalloc((void**)&tmp, UB * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_taps, n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_taps, taps.data(), n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(canvas, 0, UB, c->stream);
+    const double margin = (W + H) / 100.0;
+    double dx = std::fabs((double)(W - UW)) / 2.0, dy = std::fabs((double)(H - UH)) / 2.0;
+    const int rx = (int)dx, ry = (int)dy;
+    if (e == hipSuccess) e = hipMemcpy2DAsync(canvas + ((size_t)ry * UW + rx) * 3, (size_t)UW * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, canvas, UB, hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) { cleanup(); c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
+    dx = (dx == 0 ? 1.3 : dx + margin);
+    dy = (dy == 0 ? 1.3 : dy + margin);
+    const int rects[4][4] = {{0, 0, (int)dx, UH}, {(int)(UW - dx), 0, (int)dx, UH}, {0, 0, UW, (int)dy}, {0, (int)(UH - dy), UW, (int)dy}};
+    for (const auto& r : rects) launch_strip_blur(canvas, out, UW, tmp, d_taps, n, r[0], r[1], r[2], r[3], c->stream);   // left, right, top, bottom: later strips win
+    e = hipMemcpy2DAsync(dst, dst_stride, out, (size_t)UW * 3, (size_t)UW * 3, UH, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) { c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
     return POPPY_OK;
 }
 

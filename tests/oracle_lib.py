@@ -344,3 +344,9 @@ def gabor_filter_direct(src, ks, bank):
     o = np.zeros_like(a); b = _f(bank)
     lib().orc_gabor_filter_direct(_vp(a), a.shape[1], a.shape[0], c, ks, _vp(b), _vp(o))
     return o
+
+
+def blur_margin(img, uw, uh):
+    a = np.ascontiguousarray(img, np.uint8); o = np.zeros((uh, uw, 3), np.uint8)
+    lib().orc_blur_margin(_vp(a), a.shape[1], a.shape[0], uw, uh, _vp(o))
+    return o

@@ -82,3 +82,9 @@ def test_dft_detail2_exact(ctx, case):
     got = ctx.orb_input(gray)["detail"]
     want = float(G.full(case, "detail")[0])
     assert got == want, f"{case}: {got!r} != {want!r} (rel {abs(got - want) / want:.2e})"
+
+
+@pytest.mark.parametrize("case", sorted(G.make_inputs.MARGIN))
+def test_blur_margin_exact(ctx, case):
+    inp = G.make_inputs.margin_inputs(case)
+    G.check(case, "padded", ctx.blur_margin(inp["img"], int(inp["cfg"][0]), int(inp["cfg"][1])))

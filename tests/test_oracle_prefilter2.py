@@ -38,3 +38,9 @@ def test_gabor_bank_direct_within_tolerance_of_reference():
     ref = G.full(case, "gb1")[64:128, 64:128]
     assert us.shape == got.shape
     assert np.abs(got - ref).max() <= 1e-5            # OpenCV's DFT-based filter2D vs a direct sum in double
+
+
+@pytest.mark.parametrize("case", sorted(G.make_inputs.MARGIN))
+def test_blur_margin_oracle_exact(case):
+    inp = G.make_inputs.margin_inputs(case)
+    G.check(case, "padded", O.blur_margin(inp["img"], int(inp["cfg"][0]), int(inp["cfg"][1])))
