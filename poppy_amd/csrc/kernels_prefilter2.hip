@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(256) k_spectrum_log(const float2* __restrict__
     if (threadIdx.x == 0) { smin = 0xffffffffu; smax = 0; }
     __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    unsigned lo = 0xffffffffu, hi = 0;
     if (x < Nc && y < Mc) {                                   // the crop to even sizes happens before min / max
         const float2 c = spec[(size_t)y * N + x];
         // hal::magnitude32f = correctly rounded sqrt of the float sum; through double (53 >= 2*24 + 2 bits, so the second rounding
@@ -184,8 +185,10 @@ __global__ void __launch_bounds__(256) k_spectrum_log(const float2* __restrict__
         m = m + 1.f;
         m = cv_log32f_dev(m, ltab);
         mag[(size_t)y * Nc + x] = m;
-        atomicMin(&smin, f2ord(m)); atomicMax(&smax, f2ord(m));
+        lo = hi = f2ord(m);
     }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (unsigned)__shfl_down(lo, o)); hi = max(hi, (unsigned)__shfl_down(hi, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&smin, lo); atomicMax(&smax, hi); }
     __syncthreads();
     if (threadIdx.x == 0) { atomicMin(&minmax[0], smin); atomicMax(&minmax[1], smax); }
 }
@@ -327,8 +330,124 @@ __global__ void __launch_bounds__(64) k_dft_lines(const float2* __restrict__ src
     if (t >= count) return;
     dft_c2c_forward(src + (size_t)t * line_pitch, dst + (size_t)t * line_pitch, stride, plan);
 }
+// The same transform with one WORKGROUP per line: the line sits in LDS and the butterflies of a pass — which are independent
+// of each other — are spread over the threads, with a barrier between passes.  Every butterfly is the same expression as
+// in dft_c2c_forward, so the result is bit-identical; only the order in which independent butterflies run differs.
+constexpr int kDftMaxN = 4096;
+
+__device__ __forceinline__ float2 cmul_f(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+
+__global__ void __launch_bounds__(256) k_dft_line_wg(const float2* __restrict__ src, float2* __restrict__ dst, int line_pitch, int stride, DftPlanDev c) {
+    extern __shared__ float2 v[];
+    const float2* __restrict__ wave = c.wave;
+    const int N = c.n, tid = threadIdx.x;
+    const float2* s = src + (size_t)blockIdx.x * line_pitch;
+    float2* d = dst + (size_t)blockIdx.x * line_pitch;
+    for (int i = tid; i < N; i += 256) v[i] = s[(size_t)c.itab[i] * stride];
+    __syncthreads();
+    int n = 1, dw0 = N;
+    if ((c.factors[0] & 1) == 0) {
+        const int f0 = c.factors[0];
+        for (; n * 4 <= f0;) {
+            const int nx = n;
+            n *= 4; dw0 /= 4;
+            for (int b = tid; b < N / 4; b += 256) {
+                const int blk = b / nx, j = b - blk * nx, p = blk * n + j, dw = j * dw0;
+                float2 x0 = v[p], x1 = v[p + nx], x2 = v[p + 2 * nx], x3 = v[p + 3 * nx];
+                if (j > 0) { x1 = cmul_f(x1, wave[dw * 2]); x3 = cmul_f(x3, wave[dw * 3]); x2 = cmul_f(x2, wave[dw]); }
+                const float2 s01 = make_float2(x0.x + x1.x, x0.y + x1.y), s23 = make_float2(x2.x + x3.x, x2.y + x3.y);
+                const float2 d01 = make_float2(x0.x - x1.x, x0.y - x1.y), d23 = make_float2(x2.x - x3.x, x2.y - x3.y);
+                v[p] = make_float2(s01.x + s23.x, s01.y + s23.y);
+                v[p + nx] = make_float2(d01.x + d23.y, d01.y - d23.x);
+                v[p + 2 * nx] = make_float2(s01.x - s23.x, s01.y - s23.y);
+                v[p + 3 * nx] = make_float2(d01.x - d23.y, d01.y + d23.x);
+            }
+            __syncthreads();
+        }
+        for (; n < f0;) {
+            n *= 2; dw0 /= 2;
+            const int nx = n / 2;
+            for (int b = tid; b < N / 2; b += 256) {
+                const int blk = b / nx, j = b - blk * nx, p = blk * n + j;
+                const float2 v0 = v[p], vn = v[p + nx];
+                float2 x1 = vn;
+                if (j > 0) { const float2 w = wave[j * dw0]; x1 = make_float2(vn.x * w.x - vn.y * w.y, vn.y * w.x + vn.x * w.y); }
+                v[p] = make_float2(v0.x + x1.x, v0.y + x1.y);
+                v[p + nx] = make_float2(v0.x - x1.x, v0.y - x1.y);
+            }
+            __syncthreads();
+        }
+    }
+    for (int f_idx = (c.factors[0] & 1) ? 0 : 1; f_idx < c.nf; ++f_idx) {
+        const int factor = c.factors[f_idx];
+        const int nx = n;
+        n *= factor; dw0 /= factor;
+        if (factor == 3) {
+            const float sin_120 = (float)0.86602540378443864676372317075294;
+            for (int b = tid; b < N / 3; b += 256) {
+                const int blk = b / nx, j = b - blk * nx, p = blk * n + j, dw = j * dw0;
+                const float2 v0 = v[p], a = v[p + nx], bb = v[p + 2 * nx];
+                float r0, i0, r1, i1, r2, i2;
+                if (j == 0) {
+                    r1 = a.x + bb.x; i1 = a.y + bb.y;
+                    r2 = sin_120 * (a.y - bb.y); i2 = sin_120 * (bb.x - a.x);
+                } else {
+                    const float2 aw = cmul_f(a, wave[dw]), bw = cmul_f(bb, wave[dw * 2]);
+                    r1 = aw.x + bw.x; i1 = aw.y + bw.y;
+                    r2 = sin_120 * (aw.y - bw.y); i2 = sin_120 * (bw.x - aw.x);
+                }
+                r0 = v0.x; i0 = v0.y;
+                v[p] = make_float2(r0 + r1, i0 + i1);
+                r0 -= 0.5f * r1; i0 -= 0.5f * i1;
+                v[p + nx] = make_float2(r0 + r2, i0 + i2);
+                v[p + 2 * nx] = make_float2(r0 - r2, i0 - i2);
+            }
+        } else if (factor == 5) {
+            const float fft5_2 = (float)0.559016994374947424102293417182819, fft5_3 = (float)-0.951056516295153572116439333379382;
+            const float fft5_4 = (float)-1.538841768587626701285145288018455, fft5_5 = (float)0.363271264002680442947733378740309;
+            for (int b = tid; b < N / 5; b += 256) {
+                const int blk = b / nx, j = b - blk * nx, p = blk * n + j, dw = j * dw0;
+                const float2 a0 = v[p], a1 = v[p + nx], a2 = v[p + 2 * nx], a3 = v[p + 3 * nx], a4 = v[p + 4 * nx];
+                const float2 w1 = wave[dw], w2 = wave[dw * 2], w3 = wave[dw * 3], w4 = wave[dw * 4];
+                float r0, i0, r1, i1, r2, i2, r3, i3, r4, i4, r5, i5;
+                r3 = a1.x * w1.x - a1.y * w1.y; i3 = a1.x * w1.y + a1.y * w1.x;
+                r2 = a4.x * w4.x - a4.y * w4.y; i2 = a4.x * w4.y + a4.y * w4.x;
+                r1 = r3 + r2; i1 = i3 + i2;
+                r3 -= r2; i3 -= i2;
+                r4 = a3.x * w3.x - a3.y * w3.y; i4 = a3.x * w3.y + a3.y * w3.x;
+                r0 = a2.x * w2.x - a2.y * w2.y; i0 = a2.x * w2.y + a2.y * w2.x;
+                r2 = r4 + r0; i2 = i4 + i0;
+                r4 -= r0; i4 -= i0;
+                r0 = a0.x; i0 = a0.y;
+                r5 = r1 + r2; i5 = i1 + i2;
+                v[p] = make_float2(r0 + r5, i0 + i5);
+                r0 -= 0.25f * r5; i0 -= 0.25f * i5;
+                r1 = fft5_2 * (r1 - r2); i1 = fft5_2 * (i1 - i2);
+                r2 = -fft5_3 * (i3 + i4); i2 = fft5_3 * (r3 + r4);
+                i3 *= -fft5_5; r3 *= fft5_5;
+                i4 *= -fft5_4; r4 *= fft5_4;
+                r5 = r2 + i3; i5 = i2 + r3;
+                r2 -= i4; i2 -= r4;
+                r3 = r0 + r1; i3 = i0 + i1;
+                r0 -= r1; i0 -= i1;
+                v[p + nx] = make_float2(r3 + r2, i3 + i2);
+                v[p + 4 * nx] = make_float2(r3 - r2, i3 - i2);
+                v[p + 2 * nx] = make_float2(r0 + r5, i0 + i5);
+                v[p + 3 * nx] = make_float2(r0 - r5, i0 - i5);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < N; i += 256) d[(size_t)i * stride] = v[i];
+}
+
 // 2-D forward transform of an m x n complex image: rows (src -> tmp), then columns (tmp -> dst)
 void launch_dft2d_exact(const float2* src, float2* tmp, float2* dst, int n, int m, const DftPlanDev& rows, const DftPlanDev& cols, hipStream_t s) {
+    if (n <= kDftMaxN && m <= kDftMaxN) {
+        hipLaunchKernelGGL(k_dft_line_wg, dim3(m), dim3(256), (size_t)n * 8, s, src, tmp, n, 1, rows);
+        hipLaunchKernelGGL(k_dft_line_wg, dim3(n), dim3(256), (size_t)m * 8, s, tmp, dst, 1, n, cols);
+        return;
+    }
     hipLaunchKernelGGL(k_dft_lines, dim3((m + 63) / 64), dim3(64), 0, s, src, tmp, m, n, 1, rows);
     hipLaunchKernelGGL(k_dft_lines, dim3((n + 63) / 64), dim3(64), 0, s, tmp, dst, n, 1, n, cols);
 }
