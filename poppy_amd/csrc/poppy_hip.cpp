@@ -88,8 +88,9 @@ struct poppy_hip_ctx {
     int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
-    OrbDetector orb;
-    ForegroundFilter foreground;
+    OrbDetector orb, orb_b;
+    ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
+    hipStream_t aux_stream = nullptr;
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
     double last_detail[2] = {0, 0};
@@ -188,6 +189,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     (void)hipStreamSynchronize(c->copy_stream);
@@ -824,30 +826,51 @@ int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const
     c->pair_ready = false;
     rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
     rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
-    ForegroundFilter& fg = c->foreground;
     const size_t P = (size_t)W * H;
     std::vector<uint8_t> g[2] = {std::vector<uint8_t>(P), std::vector<uint8_t>(P)};
     double d[2] = {0, 0};
-    for (int i = 0; i < 2; ++i) {                  // Extractor::foreground -> dft_detail2 -> the ORB input of Extractor::keypoints
-        const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, c->stream, nullptr);
-        if (!gf) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
-        if (fg.detail(gf, W, H, c->stream, &d[i])) { c->err = "dft_detail2: " + fg.err; return POPPY_E_DEVICE; }
-        const uint8_t* gi = fg.orb_input(gf, W, H, i, c->stream);
-        if (!gi) { c->err = "orb_input: " + fg.err; return POPPY_E_DEVICE; }
-        HIPCHK(c, hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, c->stream));
+    if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                         // the uploads above
+    // The two images go through the chain independently (Extractor::foreground -> dft_detail2 -> the ORB input of
+    // Extractor::keypoints; image 2 also through gabor_filter(corrected2 / 255), src/poppy.hpp:119-122): one host thread and
+    // one stream each, so that the medians of one image run beside the Gabor bank of the other.
+    std::string errs[2];
+    int rcs[2] = {POPPY_OK, POPPY_OK};
+    auto chain_of = [&](int i) {
+        if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
+        ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
+        hipStream_t st = i ? c->aux_stream : c->stream;
+        const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
+        if (!gf) { errs[i] = "foreground: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
+        if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        hipError_t e = hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && i == 1) {
+            const float* gab = fg.gabor_field(c->c2, W, H, st);
+            if (!gab) { errs[i] = "gabor_field: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+            e = hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; }
+    };
+    {
+        std::thread other(chain_of, 1);
+        chain_of(0);
+        other.join();
     }
-    const float* gab = fg.gabor_field(c->c2, W, H, c->stream);          // gabor_filter(corrected2 / 255), src/poppy.hpp:119-122
-    if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
-    HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
     const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
     c->last_detail[0] = d[0]; c->last_detail[1] = d[1];
     const int nfeatures = (int)(c->cfg.max_keypoints * detail);
     c->last_nfeatures = nfeatures;
     std::vector<OrbKeyPoint> k1, k2;
-    if (c->orb.detect(g[0].data(), W, W, H, nfeatures, c->stream, k1) < 0 || c->orb.detect(g[1].data(), W, W, H, nfeatures, c->stream, k2) < 0) {
-        c->err = "orb_detect: " + c->orb.err;
-        return POPPY_E_DEVICE;
+    {   // the two detections are independent too
+        int r1 = 0, r2 = 0;
+        std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g[1].data(), W, W, H, nfeatures, c->aux_stream, k2) : -2; });
+        r1 = c->orb.detect(g[0].data(), W, W, H, nfeatures, c->stream, k1);
+        other.join();
+        if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }
     const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
     std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
