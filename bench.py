@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--mode", choices=["chain", "phase"], default=None, help="default: chain at N=1, phase at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-setup", action="store_true", help="skip the pair set-up timing (poppy_hip_pair_begin)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed region and the per-kernel step (no phase-mode / batched / download / set-up extras): "
+                         "the command the rocprofv3 summaries under profiles/ are taken from")
     ap.add_argument("--width", type=int, default=None, help="override the 1080p headline size (e.g. 3840 for BASELINE configs[2])")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 60)")
@@ -162,7 +165,7 @@ def main():
     # N = 1 only: the same 60 frames as independent phase-mode frames t_j = j/60 (what every rank of an N > 1 run
     # does), so the driver's N-sweep has a like-for-like single-GPU point beside the chained headline
     phase_fps = None
-    if world == 1 and mode == "chain":
+    if world == 1 and mode == "chain" and not args.headline_only:
         ph = sharding.phase_schedule(0, 1, FRAMES)
         ctx.reset(); ctx.render_many(ph, chain=False); ctx.sync()
         t1 = time.perf_counter()
@@ -174,7 +177,7 @@ def main():
     # N = 1 only: BASELINE.json configs[4] in miniature — several independent pairs on this GPU at once, each a chained
     # 60-frame morph driven by its own host thread and context (pairs never depend on each other)
     batched_fps, batched_pairs = None, 3
-    if world == 1 and mode == "chain" and not args.no_setup:
+    if world == 1 and mode == "chain" and not args.no_setup and not args.headline_only:
         import threading
         extra = []
         for _ in range(batched_pairs - 1):
@@ -202,7 +205,7 @@ def main():
     # PCIe-inclusive rate: every frame handed to a writer callback from pinned host memory (the library pipelines the
     # downloads behind the rendering), rank 0, not `value`
     pcie_fps = None
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         seen = [0]
 
         def sink(frame):
@@ -218,7 +221,7 @@ def main():
     # pair set-up from the raw images (pre-ORB chain, ORB, matcher, gabor2; once per pair), rank 0, outside the timed
     # region: reported beside `value`, which is the per-frame operator on a resident pair
     setup_ms = None
-    if rank == 0 and not args.no_setup:
+    if rank == 0 and not args.no_setup and not args.headline_only:
         try:
             a_h, b_h = ta.cpu().numpy(), tb.cpu().numpy()
             c2 = capi.Context(local, number_of_frames=FRAMES)
@@ -249,7 +252,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_g_final_pmc.json"))).get(f"{W}x{H}", {}).get("k_warp4")
             if pm:
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
-                traffic_src = "profiles/r01_g_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = "profiles/r01_h_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         except (OSError, ValueError):
             pass
         out = {

@@ -5,7 +5,7 @@
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only"
 K4="--width 3840 --height 2160 --frames 20"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace -o t -- $B > gpurun_out/${tag}_trace.json 2> gpurun_out/${tag}_trace.log
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -o f -- $B > /dev/null 2> gpurun_out/${tag}_fetch.log
