@@ -249,7 +249,7 @@ def main():
         achieved = wk.get("GBps") or 0.0
         traffic, traffic_src = None, None            # PMC counters need their own rocprofv3 passes: quoted from profiles/
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_g_final_pmc.json"))).get(f"{W}x{H}", {}).get("k_warp4")
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_h_final_pmc.json"))).get(f"{W}x{H}", {}).get("k_warp4")
             if pm:
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
                 traffic_src = "profiles/r01_h_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
