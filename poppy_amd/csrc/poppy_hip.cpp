@@ -535,7 +535,11 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     // the id map is left cleared by the warp kernel of the frame before (its only reader); only a slot's first frame
     // and frames after a debug frame (which keeps the map for poppy_hip_debug_fetch) need the memset
     if (!f.map_clean) HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
-    HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
+    // Chained frames: the host waits for the plan upload itself (it is ~100 us ahead of the GPU, the copy takes ~10) instead of
+    // putting a cross-stream wait in front of the raster, which costs the critical path ~4 us per frame.
+    static const bool host_wait = getenv("POPPY_HIP_STREAMWAIT") == nullptr;
+    if (chained && host_wait) HIPCHK(c, hipEventSynchronize(f.uploaded));
+    else HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
     if (all_marks) th.mark("upload+clear");
     launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, head);
     if (all_marks) th.mark("raster");
