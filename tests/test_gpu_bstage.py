@@ -139,3 +139,64 @@ def test_full_size_round_trip_properties(ctx):
     assert (a == b).all()
     tm = ctx.fetch("triMap")
     assert tm.min() >= 0 and tm.max() <= len(ctx.triangles()[0])
+
+
+def test_frame_4k_vs_oracle(ctx):
+    """BASELINE.json configs[2] size: one 3840x2160 frame against the oracle (wide kernels, fused levels, 8-level pyramid)."""
+    w, h, n = 3840, 2160, 200
+    c1, c2 = synth.gen_pair(w, h)
+    g = synth.unit_field(w, h, 16)
+    p1, p2 = synth.point_pairs(w, h, n, seed=13, dup=0, oob=0)
+    want, _ = O.morph_images(c1, c2, g, p1, p2, 0.4, 0.4, 64)
+    got = ctx.morph_images(c1, c2, g, p1, p2, 0.4, 0.4)
+    _same("4K frame", got[0] if isinstance(got, tuple) else got, want)
+
+
+def test_phase_frames_in_flight_and_downloads_match_single_frames():
+    """Phase-mode frames run on their own streams, several in flight, and the writer receives them through the pinned
+    ring in order: every delivered frame must equal the frame rendered on its own."""
+    w, h, n, N = 320, 200, 40, 10
+    c1 = synth.textured_bgr(w, h, 81); c2 = synth.textured_bgr(w, h, 82)
+    g = synth.unit_field(w, h, 17)
+    p1, p2 = synth.point_pairs(w, h, n, seed=11, dup=0, oob=0)
+    c = capi.Context(0, number_of_frames=N)
+    c.pair_load(c1, c2, g, p1, p2)
+    shapes = np.array([j / float(N) for j in range(N)])
+    got = []
+    c.render_many(shapes, chain=False, write=lambda f: got.append(f.copy()))
+    assert len(got) == N
+    for j in range(N):
+        c.reset()
+        one = c.render(float(shapes[j]), float(shapes[j]), chain=False)
+        _same(f"phase frame {j}", got[j], one)
+    c.close()
+
+
+def test_two_pairs_concurrently_match_sequential():
+    """Independent contexts driven from two host threads (the batched configuration) give the frames of a lone run."""
+    import threading
+    w, h, n, N = 256, 192, 30, 8
+    pairs = []
+    for k in range(2):
+        c1 = synth.textured_bgr(w, h, 91 + k); c2 = synth.textured_bgr(w, h, 95 + k)
+        pairs.append((c1, c2, synth.unit_field(w, h, 18 + k), *synth.point_pairs(w, h, n, seed=21 + k, dup=0, oob=0)))
+    ratios = np.array([capi.lib().poppy_frame_ratio(j, N, -1.0) for j in range(N)])
+
+    def run(pair, out):
+        c = capi.Context(0, number_of_frames=N)
+        c.pair_load(*pair)
+        c.render_many(ratios, chain=True, write=lambda f: out.append(f.copy()))
+        c.close()
+    alone = [[], []]
+    for k in range(2):
+        run(pairs[k], alone[k])
+    both = [[], []]
+    th = [threading.Thread(target=run, args=(pairs[k], both[k])) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert len(both[k]) == N
+        for j in range(N):
+            _same(f"pair {k} frame {j}", both[k][j], alone[k][j])
