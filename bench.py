@@ -104,20 +104,34 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    # POPPY_BENCH_ONE_GPU=1 is a rehearsal of the N > 1 path on a single-GPU box (every rank on GPU 0, gloo as the
+    # backend, the pair staged through host memory for the broadcast); its numbers mean nothing
+    rehearsal = os.environ.get("POPPY_BENCH_ONE_GPU") == "1" and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mode = args.mode or ("chain" if world == 1 else "phase")
     if mode == "chain" and world > 1:
         raise SystemExit("chained mode is sequential by construction (SURVEY.md F5); use --mode phase for N>1")
 
     # ---- inputs: generated on rank 0, broadcast once over RCCL, resident in HBM before timing --------------
-    ta, tb, tg, tp = sharding.pair_tensors(torch, dev, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
-    if world > 1:
-        sharding.broadcast_pair(dist, (ta, tb, tg, tp), src=0)
+    if rehearsal:
+        cpu = torch.device("cpu")
+        host = sharding.pair_tensors(torch, cpu, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
+        sharding.broadcast_pair(dist, host, src=0)
+        ta, tb, tg, tp = [t.to(dev) for t in host]
+    else:
+        ta, tb, tg, tp = sharding.pair_tensors(torch, dev, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
+        if world > 1:
+            sharding.broadcast_pair(dist, (ta, tb, tg, tp), src=0)
     torch.cuda.synchronize()
     pts = tp.cpu().numpy()
     p1r, p2r = np.ascontiguousarray(pts[0]), np.ascontiguousarray(pts[1])
@@ -160,7 +174,7 @@ def main():
     summary = ctx.timing_summary()
     ctx.set_timing(0)
 
-    dt_max = sharding.max_over_ranks(torch, dist, dt, dev) if world > 1 else dt
+    dt_max = sharding.max_over_ranks(torch, dist, dt, torch.device("cpu") if rehearsal else dev) if world > 1 else dt
 
     # N = 1 only: the same 60 frames as independent phase-mode frames t_j = j/60 (what every rank of an N > 1 run
     # does), so the driver's N-sweep has a like-for-like single-GPU point beside the chained headline
