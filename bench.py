@@ -276,7 +276,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 pixels / f32 pyramid (bit-compatible with the reference: no FMA contraction)",
+            "dtype": "u8+f32",
+            "dtype_note": "u8 pixels and fixed-point remap, f32 pyramid and unsharp; bit-compatible with the reference (no FMA contraction)",
             "data": "synthetic (integer-defined shapes pair, synthetic mask field and 436+4 point pairs; poppy_amd/synth.py)",
             "config": {"workload": f"{W}x{H} pair, {FRAMES}-frame morph per GPU ({total_frames} frames total), "
                                    f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
