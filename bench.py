@@ -12,7 +12,7 @@ Frames stay in HBM (inputs are resident before the timed region, outputs are not
 rate is printed as an extra key, never as `value`.
 
 Output: ONE JSON line on rank 0 (see the driver contract), extended with
-  roofline     : the fused map+remap kernel (k_warp4): 16 B/px (faithful path) + 8 B/px for the lbmask it
+  roofline     : the fused map+remap kernel (k_warp_tile; k_warp4 for odd geometries): 16 B/px (faithful path) + 8 B/px for the lbmask it
                  computes on the way (m2 in, mask out); the 4 B/px id-map clear it also writes is not counted,
                  average launch duration measured live with HIP events on the library's stream;
   kernels      : the same for every kernel group of the frame (one extra untimed step; "warp" is the timed region's);
@@ -158,7 +158,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_timing(2)          # HIP events around the roofline kernel (k_warp4) only, on the stream it is launched on
+    ctx.set_timing(2)          # HIP events around the roofline kernel (k_warp_tile) only, on the stream it is launched on
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -263,10 +263,11 @@ def main():
         achieved = wk.get("GBps") or 0.0
         traffic, traffic_src = None, None            # PMC counters need their own rocprofv3 passes: quoted from profiles/
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_h_final_pmc.json"))).get(f"{W}x{H}", {}).get("k_warp4")
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_i_warp_pmc.json"))).get(f"{W}x{H}", {})
+            pm = pm.get("k_warp_tile") if ctx.last_warp_kind() == 1 else pm.get("k_warp4")
             if pm:
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
-                traffic_src = "profiles/r01_h_final_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = "profiles/r01_i_warp_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         except (OSError, ValueError):
             pass
         out = {
@@ -283,7 +284,7 @@ def main():
                                    f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
                                    "pyramid_levels 64, per-frame operator on a resident pair",
                        "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_warp4 (fused create_map + remap of both sources + lbmask)",
+            "roofline": {"bound": "hbm", "kernel": ("k_warp_tile" if ctx.last_warp_kind() == 1 else "k_warp4") + " (fused create_map + remap of both sources + lbmask)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n},

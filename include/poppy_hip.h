@@ -183,6 +183,10 @@ int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, 
  * names: "triMap"(i32 HxW) "trImg1" "trImg2"(u8 HxWx3) "lbmask"(f32 HxW) "lapBlend" "unsharp"(f32 HxWx3)
  * "unsharp" is only available after poppy_hip_set_debug(ctx, 1).                                       */
 int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
+/* Which warp kernel rendered the last frame: 1 = the packed-arithmetic kernel (every triangle matrix within the range the
+ * host checks, the normal case), 0 = the general kernel (degenerate matrices or odd geometry).  Same output bits either
+ * way; exported so that the parity tests can tell which one they exercised.                              */
+int poppy_hip_last_warp_kind(poppy_hip_ctx* ctx);
 int poppy_hip_debug_fetch(poppy_hip_ctx* ctx, const char* name, void* host_dst, size_t bytes);
 int poppy_hip_debug_triangles(poppy_hip_ctx* ctx, int* n_tris, int* idx3, float* M1, float* M2, int max_tris);
 
@@ -192,11 +196,17 @@ int poppy_plan_frame(int width, int height, const float* src_points1, const floa
                      double shape_ratio, int max_tris, int* n_tris, int* idx3, int* tri_xy,
                      float* M1, float* M2, float* inv1, float* inv2, float* morphed_pts);
 
+/* Host-only: packs T pairs of inverse matrices (as poppy_plan_frame returns them) into the (T+1) x 20 float records the
+ * tiled warp kernel reads (record 0 = identity; layout in poppy_amd/csrc/frame_plan.h) and returns 1 when every matrix is
+ * inside the range for which that kernel's arithmetic is proven identical to the general one, 0 when the frame must take
+ * the general kernel, < 0 on bad arguments.  Exported for the CPU test suite.                              */
+int poppy_warp_records(const float* inv1, const float* inv2, int n_tris, int width, int height, float* records);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
  *   on = 0  off;
  *   on = 1  around every kernel group of a frame (the frame is then issued launch by launch instead of through its
  *           captured graph, so whole-frame throughput is a little lower while this is on);
- *   on = 2  around the fused map+remap kernel (k_warp4) only; the rest of the frame runs as usual.
+ *   on = 2  around the fused map+remap kernel (k_warp_tile / k_warp4) only; the rest of the frame runs as usual.
  * timing_summary drains the streams and returns, per kernel group, the summed duration and the number of
  * launches since the last summary / set_timing call; returns the number of entries written.            */
 int poppy_hip_set_timing(poppy_hip_ctx* ctx, int on);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "poppy_settings_default", "poppy_hip_create", "poppy_hip_destroy", "poppy_hip_last_error", "poppy_hip_create_error",
     "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
-    "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
+    "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -61,10 +61,12 @@ def lib():
         L.poppy_hip_morph_frames.argtypes = [vp, d, vp, vp]
         L.poppy_hip_dissolve.argtypes = [vp, vp, sz, vp, sz, i, i, d, vp, sz]
         L.poppy_hip_set_debug.argtypes = [vp, i]
+        L.poppy_hip_last_warp_kind.argtypes = [vp]
         L.poppy_hip_set_timing.argtypes = [vp, i]
         L.poppy_hip_debug_fetch.argtypes = [vp, C.c_char_p, vp, sz]
         L.poppy_hip_debug_triangles.argtypes = [vp, vp, vp, vp, vp, i]
         L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.poppy_warp_records.argtypes = [vp, vp, i, i, i, vp]
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
@@ -108,6 +110,18 @@ def plan_frame(w, h, p1, p2, shape):
         raise PoppyError(f"poppy_plan_frame: {rc}")
     t = nt.value
     return dict(idx3=idx3[:t], tri_xy=tri[:t], M1=M1[:t], M2=M2[:t], inv1=i1[:t], inv2=i2[:t], morphed=mp)
+
+
+def warp_records(inv1, inv2, w, h):
+    """Host-only: (records (T+1, 20) float32, admitted to the tiled warp kernel?)."""
+    inv1 = np.ascontiguousarray(inv1, np.float32).reshape(-1, 9)
+    inv2 = np.ascontiguousarray(inv2, np.float32).reshape(-1, 9)
+    t = len(inv1)
+    rec = np.zeros((t + 1, 20), np.float32)
+    rc = lib().poppy_warp_records(_p(inv1), _p(inv2), t, w, h, _p(rec))
+    if rc < 0:
+        raise PoppyError(f"poppy_warp_records: {rc}")
+    return rec, bool(rc)
 
 
 def radial_gradient(w, h):
@@ -299,6 +313,9 @@ class Context:
         out = np.empty((h, w, 3), np.uint8)
         self._chk(lib().poppy_hip_dissolve(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, _p(out), w * 3), "dissolve")
         return out
+
+    def last_warp_kind(self):
+        return int(lib().poppy_hip_last_warp_kind(self.h))
 
     def set_debug(self, on=True):
         lib().poppy_hip_set_debug(self.h, int(on))

@@ -370,4 +370,37 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
     return 0;
 }
 
+namespace {
+bool warp_matrix_ok(const float* m, int w, int h, bool& zero) {
+    zero = true;
+    for (int i = 0; i < 9; ++i) {
+        if (!std::isfinite(m[i]) || std::fabs(m[i]) > 1099511627776.f) return false;
+        if (m[i] != 0.f) zero = false;
+    }
+    if (zero) return true;
+    const double spread = std::fabs((double)m[6]) * (w - 1) + std::fabs((double)m[7]) * (h - 1);
+    const double lo = (double)m[8] - spread, hi = (double)m[8] + spread;
+    const double kMin = 1.0 / 1048576.0, kMax = 1048576.0;
+    return (lo >= kMin && hi <= kMax) || (hi <= -kMin && lo >= -kMax);
+}
+}  // namespace
+
+bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* rec) {
+    static const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool ok = true;
+    for (int t = -1; t < n_tris; ++t, rec += kWarpRecordFloats) {
+        const float* a = t < 0 ? ident : inv1 + (size_t)t * 9;
+        const float* b = t < 0 ? ident : inv2 + (size_t)t * 9;
+        bool za, zb;
+        ok = warp_matrix_ok(a, w, h, za) && ok;
+        ok = warp_matrix_ok(b, w, h, zb) && ok;
+        rec[0] = a[0]; rec[1] = a[3]; rec[2] = a[1]; rec[3] = a[4]; rec[4] = a[2]; rec[5] = a[5];
+        rec[6] = b[0]; rec[7] = b[3]; rec[8] = b[1]; rec[9] = b[4]; rec[10] = b[2]; rec[11] = b[5];
+        rec[12] = a[6]; rec[13] = b[6]; rec[14] = a[7]; rec[15] = b[7];
+        rec[16] = za ? 0.00001f : a[8]; rec[17] = zb ? 0.00001f : b[8];
+        rec[18] = rec[19] = 0.f;
+    }
+    return ok;
+}
+
 }  // namespace poppy_hip

@@ -37,6 +37,16 @@ constexpr int kPlanRasterRows = 16;  // rows of one triangle per raster work ite
 int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f>& src2,
                double shape_ratio, FramePlan& plan);
 
+// Per-triangle records of the fast warp kernel (kernels_warp_fast.hip): (T+1) x 20 floats, record 0 = identity, record
+// i+1 = triangle i with both inverse matrices interleaved as
+//   {h0,h3}a {h1,h4}a {h2,h5}a {h0,h3}b {h1,h4}b {h2,h5}b {h6a,h6b} {h7a,h7b} {h8a,h8b} pad pad      (a = inv1, b = inv2)
+// An all-zero matrix (singular triangle, lapack.cpp:1044-1045) gets h8 = 1e-5f, which is what create_map substitutes for
+// its z = 0 (algo.cpp:166-167).  Returns false when some matrix could take the kernel's bare division sequence outside the
+// range where it equals IEEE division (non-finite or > 2^40 entries, or a denominator h6*x + h7*y + h8 that can leave
+// [2^-20, 2^20] in magnitude or change sign over the image); such frames use the general kernel.
+constexpr int kWarpRecordFloats = 20;
+bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* records);
+
 void clip_points_ref(std::vector<P2f>& pts, int cols, int rows);   // src/util.cpp:453-460
 bool invert3x3(const float* m, float* out);                        // OCV/core/src/lapack.cpp:965-993
 

@@ -40,6 +40,12 @@ void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const ui
                  uint8_t* tr1, uint8_t* tr2, int w, int h, const WarpExtras& ex, hipStream_t s,
                  hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
+// The same warp from per-triangle records (frame_plan.h: pack_warp_records), for frames whose matrices the host admitted
+// and geometries warp_fast_geometry() accepts (kernels_warp_fast.hip).  Bit-identical output, about half the instructions.
+bool warp_fast_geometry(int w, int h);
+void launch_warp_fast(int32_t* triMap, const float* records, int n_records, const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
+                      int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+
 // one Gaussian-pyramid reduction step for L, R (3 channels) and the mask (1 channel) in one launch.
 // level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,

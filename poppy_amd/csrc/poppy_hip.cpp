@@ -83,7 +83,8 @@ struct poppy_hip_ctx {
     std::vector<P2f> pts1_0, pts1, pts2;
     // per-frame plan blobs (pinned host + device) live in the frame slots, so the host can plan ahead of the GPU
     int max_tris = 0;
-    // blob layout: [header 64 B: f32 unsharp amount][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32][RasterTri T][work 2*n i32]
+    // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
+    //              [RasterTri T][work 2*n i32]
     size_t blob_bytes = 0;
     int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
     hipStream_t copy_stream = nullptr;
@@ -93,6 +94,7 @@ struct poppy_hip_ctx {
     hipStream_t aux_stream = nullptr;
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
+    bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
     double last_detail[2] = {0, 0};
     // diagnostics
     bool debug = false;
@@ -198,6 +200,11 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     delete c;
 }
 
+int poppy_warp_records(const float* inv1, const float* inv2, int n_tris, int width, int height, float* records) {
+    if (n_tris < 0 || width < 1 || height < 1 || !records || (n_tris > 0 && (!inv1 || !inv2))) return POPPY_E_ARG;
+    return pack_warp_records(inv1, inv2, n_tris, width, height, records) ? 1 : 0;
+}
+int poppy_hip_last_warp_kind(poppy_hip_ctx* c) { return c ? (c->last_warp_fast ? 1 : 0) : POPPY_E_ARG; }
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -214,7 +221,8 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 3);
-    const size_t bytes = ((kBlobHeader + (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 + 15) / 16) * 16;
+    const size_t bytes = ((kBlobHeader + (size_t)(need + 1) * kWarpRecordFloats * 4 +
+                          (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 + 15) / 16) * 16;
     for (FrameSlot& f : c->slots) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob
         if (f.h_blob) (void)hipHostFree(f.h_blob);
@@ -487,12 +495,13 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
     *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
-    int* h_tri = (int*)(f.h_blob + kBlobHeader);
+    const size_t rec_bytes = (size_t)(T + 1) * kWarpRecordFloats * sizeof(float);
+    int* h_tri = (int*)(f.h_blob + kBlobHeader + rec_bytes);
     float* h_inv = (float*)(h_tri + (size_t)T * 6);
-    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 64 + 96*T: 8-byte aligned
+    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 144 + 176*T: 8-byte aligned
     int* h_work = (int*)(h_edges + T);
     const int n_work = (int)(c->plan.work.size() / 2);
-    const size_t used = kBlobHeader + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
+    const size_t used = kBlobHeader + rec_bytes + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
     if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     if (T) {
         memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
@@ -501,7 +510,13 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         memcpy(h_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
         memcpy(h_work, c->plan.work.data(), (size_t)n_work * 8);
     }
-    const int* d_tri = (const int*)(f.d_blob + kBlobHeader);
+    // the fast warp kernel takes the frame when every matrix passes the host's range check (always, short of degenerate input)
+    static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
+    const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader)) &&
+                           warp_fast_geometry(W, H) && !exact_warp_only;
+    c->last_warp_fast = fast_warp;
+    const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
+    const int* d_tri = (const int*)(f.d_blob + kBlobHeader + rec_bytes);
     const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
     const RasterTri* d_edges = (const RasterTri*)(d_inv + (size_t)T * 18);
     const int* d_work = (const int*)(d_edges + T);
@@ -555,10 +570,12 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     f.map_clean = ex.clear_ids != 0;
     if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
         hipEvent_t t0 = tm.take(nullptr), t1 = tm.take("warp");
-        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
     } else {
         tm.mark(nullptr);
-        launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
     if (use_graph) HIPCHK(c, hipGraphLaunch(f.body, s));

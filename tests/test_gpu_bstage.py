@@ -4,6 +4,8 @@ Bar: bit-exact on every integer/byte stage (triMap, warped images, final frame) 
 reproduce the reference's float association and are built without FMA contraction — bit-exact on the float
 stages as well (lbmask, lapBlend, unsharp).  north_star allows 1 LSB on blended pixels; we assert 0.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ import oracle_lib as O
 from poppy_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+TILED = 0 if os.environ.get("POPPY_HIP_GENERALWARP") is not None else 1    # the switch forces the general warp kernel
 
 
 @pytest.fixture(scope="module")
@@ -200,3 +203,39 @@ def test_two_pairs_concurrently_match_sequential():
         assert len(both[k]) == N
         for j in range(N):
             _same(f"pair {k} frame {j}", both[k][j], alone[k][j])
+
+
+def test_warp_kernel_selection(ctx):
+    """The tiled warp kernel takes frames whose width is a multiple of 4; other widths use the general kernel.
+    Both are checked bit for bit against the oracle by the tests above; this one pins which ran."""
+    for (w, h), kind in (((640, 360), 1), ((97, 61), 0)):
+        c1 = synth.textured_bgr(w, h, 5); c2 = synth.textured_bgr(w, h, 6)
+        g = synth.unit_field(w, h, 3)
+        p1, p2 = synth.point_pairs(w, h, 12, seed=1, dup=0, oob=0)
+        ctx.morph_images(c1, c2, g, p1, p2, 0.5, 0.5)
+        assert ctx.last_warp_kind() == (kind and TILED)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1000, 96), (1920, 1080)])
+def test_strong_deformation_vs_oracle(ctx, w, h):
+    """Second point set rotated 35 degrees and scaled 0.8 about the centre: steep per-triangle matrices, footprints far
+    from their pixels, many triangles per tile (record-cache slot collisions), large out-of-image regions."""
+    rng = np.random.default_rng(w * 7 + h)
+    n = 300 if w * h > 500000 else 120
+    p1 = np.stack([rng.uniform(0, w - 1, n), rng.uniform(0, h - 1, n)], 1).astype(np.float32)
+    a = np.deg2rad(35.0)
+    c = np.array([(w - 1) / 2, (h - 1) / 2], np.float32)
+    R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]], np.float32) * np.float32(0.8)
+    p2 = ((p1 - c) @ R.T + c + rng.normal(0, 2.0, (n, 2))).astype(np.float32)
+    p2[:, 0] = np.clip(p2[:, 0], 0, w - 1); p2[:, 1] = np.clip(p2[:, 1], 0, h - 1)
+    corners = np.array([[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]], np.float32)
+    p1 = np.concatenate([p1, corners]); p2 = np.concatenate([p2, corners])
+    c1 = synth.textured_bgr(w, h, 21); c2 = synth.textured_bgr(w, h, 22)
+    g = synth.unit_field(w, h, 9)
+    for s in (0.25, 0.8):
+        want, wmp, d = O.morph_images(c1, c2, g, p1, p2, s, s, 64, debug=True)
+        got, gmp = ctx.morph_images(c1, c2, g, p1, p2, s, s)
+        assert ctx.last_warp_kind() == TILED
+        for name in ("triMap", "trImg1", "trImg2"):
+            _same(f"{name} {w}x{h} s={s}", ctx.fetch(name), d[name])
+        _same("frame", got, want)

@@ -83,3 +83,38 @@ def test_match_points_all_out_of_image():
     p = np.array([[-5, 3], [700, 2]], np.float32)
     a, b, imd = capi.match_points(p, p, 64, 48, 1.0)
     assert len(a) == 0 and len(b) == 0
+
+
+def test_warp_records_layout_and_admission():
+    """Records of the tiled warp kernel (poppy_amd/csrc/frame_plan.h): layout, identity record, the zero-matrix
+    substitution of create_map's z == 0 case (src/algo.cpp:166-167) and the admission rule."""
+    from poppy_amd import synth
+    w, h = 640, 480
+    p1, p2 = synth.point_pairs(w, h, 60, seed=3, dup=0, oob=0)
+    plan = capi.plan_frame(w, h, p1, p2, 0.4)
+    i1 = plan["inv1"].reshape(-1, 9); i2 = plan["inv2"].reshape(-1, 9)
+    rec, ok = capi.warp_records(i1, i2, w, h)
+    assert ok and rec.shape == (len(i1) + 1, 20)
+    ident = np.zeros(20, np.float32); ident[[0, 3, 6, 9, 16, 17]] = 1
+    assert np.array_equal(rec[0], ident)
+    # a = inv1, b = inv2: {h0,h3}a {h1,h4}a {h2,h5}a {h0,h3}b {h1,h4}b {h2,h5}b {h6a,h6b} {h7a,h7b} {h8a,h8b} pad pad
+    order_a = [0, 3, 1, 4, 2, 5]
+    assert np.array_equal(rec[1:, 0:6], i1[:, order_a]) and np.array_equal(rec[1:, 6:12], i2[:, order_a])
+    assert np.array_equal(rec[1:, 12:18:2], i1[:, 6:9]) and np.array_equal(rec[1:, 13:18:2], i2[:, 6:9])
+    assert not rec[:, 18:].any()
+
+    one = np.array([[1, 0, 0, 0, 1, 0, 0, 0, 1]], np.float32)
+    zero = np.zeros((1, 9), np.float32)
+    rec, ok = capi.warp_records(zero, one, w, h)              # singular triangle: all-zero inverse, z := 1e-5
+    assert ok and rec[1, 16] == np.float32(0.00001) and rec[1, 17] == 1 and not rec[1, 0:6].any()
+
+    def admitted(m):
+        return capi.warp_records(np.asarray([m], np.float32), one, w, h)[1]
+    assert admitted([1, 0, 0, 0, 1, 0, 1e-4, 0, 1])           # denominator stays in [1, 1.064]
+    assert not admitted([1, 0, 0, 0, 1, 0, -2e-3, 0, 1])      # 1 - 0.002 * 639 changes sign across the image
+    assert not admitted([1, 0, 0, 0, 1, 0, 0, 0, 0])          # z == 0 everywhere with a non-zero matrix
+    assert not admitted([1, 0, 0, 0, 1, 0, 0, 0, 1e-7])       # below 2^-20
+    assert not admitted([1, 0, 0, 0, 1, 0, 0, 0, 2e6])        # above 2^20
+    assert admitted([1, 0, 0, 0, 1, 0, 0, 0, -1])             # negative denominators are fine while they keep their sign
+    assert not admitted([np.inf, 0, 0, 0, 1, 0, 0, 0, 1]) and not admitted([np.nan, 0, 0, 0, 1, 0, 0, 0, 1])
+    assert not admitted([2e12, 0, 0, 0, 1, 0, 0, 0, 1])       # > 2^40
