@@ -114,6 +114,15 @@ int poppy_hip_orb_describe(poppy_hip_ctx* ctx, const uint8_t* gray, size_t strid
 int poppy_hip_hamming_match(poppy_hip_ctx* ctx, const uint8_t* query32, int n_query, const uint8_t* train32, int n_train,
                             int* out3, int* n_matches);
 
+/* Descriptor matching as the reference sketched it (src/experiments.hpp:14-144, dead code there):
+ *   hamming_knn2   : BFMatcher(NORM_HAMMING).knnMatch(k = 2) — rows of out4 = trainIdx0, distance0, trainIdx1, distance1,
+ *                    ordered by (distance, train index) (OCV/core/src/batch_distance.cpp:225-248), -1 where there is none;
+ *   ratio_symmetry : ratioTest (a query survives with two neighbours and distance0 / distance1 <= ratio) on both
+ *                    directions, then symmetryTest; rows of out3 = queryIdx, trainIdx, distance.  Host only.
+ * ransacTest (findFundamentalMat) of the same sketch is not provided.                                          */
+int poppy_hip_hamming_knn2(poppy_hip_ctx* ctx, const uint8_t* query32, int n_query, const uint8_t* train32, int n_train, int* out4);
+int poppy_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, int* out3, int* n_out);
+
 /* Matcher::find (general branch) + Matcher::prepare on raw point lists (src/matcher.cpp:118-131,246-332):
  * drop out-of-image pairs, morph distance, greedy nearest-neighbour pairing, threshold filter, 4 corners.
  * Host only.  out1/out2 need room for n_points + 4 pairs.                                              */
@@ -152,6 +161,13 @@ int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* ctx,
 int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                          int width, int height);
 /* nfeatures and the two dft_detail2 values of the last poppy_hip_pair_begin */
+/* Opt-in quality mode with no counterpart in the reference's live code: pair set-up as poppy_hip_pair_begin, but the point
+ * pairs come from ORB descriptors (ORB::compute on both keypoint sets, 2-NN both ways, ratio test, symmetry test) instead of
+ * the positional greedy matcher; surviving pairs in query order, out-of-image pairs dropped, four corners appended.
+ * POPPY_E_NOMATCH when nothing survives (use poppy_hip_dissolve).  ratio: 0.7 in the reference's sketch.        */
+int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
+                                     int width, int height, float ratio);
+
 int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail2);
 /* Pieces of the chain, host in / host out, for tests and for callers that cache intermediates:
  * poppy_hip_orb_input: goodFeatures (w*h) -> g = the ORB input image; optional us (grey of the unsharp-masked image), gb (Gabor

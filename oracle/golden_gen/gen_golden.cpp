@@ -31,7 +31,12 @@
 #include "draw.hpp"
 #include "extractor.hpp"
 #include "settings.hpp"
-namespace poppy { double dft_detail2(const cv::Mat& src, cv::Mat& dst); }  // defined in experiments.hpp, emitted by extractor.o
+namespace poppy {   // defined in experiments.hpp, emitted by extractor.o
+double dft_detail2(const cv::Mat& src, cv::Mat& dst);
+int ratioTest(std::vector<std::vector<cv::DMatch>>& matches);
+void symmetryTest(const std::vector<std::vector<cv::DMatch>>& matches1, const std::vector<std::vector<cv::DMatch>>& matches2,
+                  std::vector<cv::DMatch>& symMatches);
+}
 #include "poppy.hpp"
 #include <opencv2/imgproc.hpp>
 #include <opencv2/features2d.hpp>
@@ -317,6 +322,33 @@ static void dump_orb() {
         vector<int> buf;
         for (auto& m : ms) { buf.push_back(m.queryIdx); buf.push_back(m.trainIdx); buf.push_back((int)m.distance); }
         write_raw(pf + "bfmatch", "i32", { (int)ms.size(), 3 }, buf.data(), buf.size() * 4);
+        // the descriptor-matching sketch of src/experiments.hpp:14-144: 2-NN both ways, ratio test, symmetry test
+        vector<vector<DMatch>> m12, m21;
+        bf.knnMatch(d1, d2, m12, 2);
+        bf.knnMatch(d2, d1, m21, 2);
+        auto dump_knn = [&](const string& name, const vector<vector<DMatch>>& mm) {
+            vector<int> kb;
+            for (auto& v : mm) for (int k = 0; k < 2; ++k) {
+                kb.push_back(k < (int)v.size() ? v[k].trainIdx : -1);
+                kb.push_back(k < (int)v.size() ? (int)v[k].distance : -1);
+            }
+            write_raw(name, "i32", { (int)mm.size(), 4 }, kb.data(), kb.size() * 4);
+        };
+        dump_knn(pf + "knn12", m12);
+        dump_knn(pf + "knn21", m21);
+        int rm1 = poppy::ratioTest(m12), rm2 = poppy::ratioTest(m21);
+        vector<int> keep1, keep2;
+        for (auto& v : m12) keep1.push_back(v.size() > 1 ? 1 : 0);
+        for (auto& v : m21) keep2.push_back(v.size() > 1 ? 1 : 0);
+        write_raw(pf + "ratio12", "i32", { (int)keep1.size() }, keep1.data(), keep1.size() * 4);
+        write_raw(pf + "ratio21", "i32", { (int)keep2.size() }, keep2.data(), keep2.size() * 4);
+        vector<DMatch> sym;
+        poppy::symmetryTest(m12, m21, sym);
+        vector<int> sb;
+        for (auto& m : sym) { sb.push_back(m.queryIdx); sb.push_back(m.trainIdx); sb.push_back((int)m.distance); }
+        if (sb.empty()) sb.assign(3, 0);
+        write_raw(pf + "sym", "i32", { (int)sym.size(), 3 }, sb.data(), sym.size() * 12);
+        fprintf(stderr, "  knn: ratio test removed %d / %d, %zu symmetric matches\n", rm1, rm2, sym.size());
         fprintf(stderr, "orb nfeatures=%d: %zu / %zu keypoints\n", (int)nf[i], k1.size(), k2.size());
     }
 }

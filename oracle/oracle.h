@@ -98,6 +98,10 @@ int morph_images(const ImageU8& c1, const ImageU8& c2, const ImageF& gabor2,
 // ORB::create(nfeatures)->detect(image): n x 7 floats (x, y, size, angle, response, octave, class_id), order significant
 int orb_detect(const ImageU8& image, int nfeatures, std::vector<float>& kps, std::vector<float>* fastLevel0 = nullptr);
 void hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out);
+// descriptor-matching sketch of src/experiments.hpp:14-144 (BFMatcher::knnMatch k=2, ratioTest, symmetryTest)
+void hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out4);
+void ratio_test(const int* knn4, int n, float ratio, std::vector<int>& keep);
+void symmetry_test(const int* knn12, const int* keep12, int n1, const int* knn21, const int* keep21, int n2, std::vector<int>& out3);
 // ORB::compute (WTA_K 2): n x 32 bytes.  trig_mode 0 = cosf/sinf, 1 = (float)cos(double) (diagnostic only)
 int orb_describe(const ImageU8& image, const std::vector<float>& kps7, std::vector<uint8_t>& desc, int trig_mode = 0);
 

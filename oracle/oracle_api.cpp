@@ -114,6 +114,18 @@ int orc_orb_describe(const uint8_t* img, int w, int h, const float* kps7, int n,
     std::vector<float> k(kps7, kps7 + (size_t)n * 7); std::vector<uint8_t> d;
     int m = orb_describe(wrap_u8(img, w, h, 1), k, d, trig_mode); put(desc, d); return m;
 }
+int orc_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, int* out4) {
+    std::vector<int> o; hamming_knn2(q, nq, t, nt, bytes, o); put(out4, o); return nq;
+}
+int orc_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, int* keep12, int* keep21, int* out3) {
+    std::vector<int> k1, k2, o;
+    ratio_test(knn12, n1, ratio, k1); ratio_test(knn21, n2, ratio, k2);
+    symmetry_test(knn12, k1.data(), n1, knn21, k2.data(), n2, o);
+    if (keep12) put(keep12, k1);
+    if (keep21) put(keep21, k2);
+    put(out3, o);
+    return (int)o.size() / 3;
+}
 int orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, int* out3) {
     std::vector<int> o; hamming_match(q, nq, t, nt, bytes, o); put(out3, o); return (int)o.size() / 3;
 }

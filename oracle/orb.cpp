@@ -358,4 +358,53 @@ void hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes
     }
 }
 
+// BFMatcher(NORM_HAMMING).knnMatch(k = 2): sorted insertion with strict comparisons, so among equal distances the
+// lower train index comes first (OCV/core/src/batch_distance.cpp:225-248; K = min(2, nt), :286).
+// out: nq x 4 ints (trainIdx0, distance0, trainIdx1, distance1), -1 where there is no neighbour
+void hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, std::vector<int>& out) {
+    out.assign((size_t)nq * 4, -1);
+    const int K = nt < 2 ? nt : 2;
+    for (int i = 0; i < nq; ++i) {
+        int dist[2] = {INT32_MAX, INT32_MAX}, idx[2] = {-1, -1};
+        for (int j = 0; j < nt && K > 0; ++j) {
+            int d = 0;
+            for (int b = 0; b < bytes; ++b) d += __builtin_popcount((unsigned)(q[(size_t)i * bytes + b] ^ t[(size_t)j * bytes + b]));
+            if (d < dist[K - 1]) {
+                int k;
+                for (k = K - 2; k >= 0 && dist[k] > d; --k) { idx[k + 1] = idx[k]; dist[k + 1] = dist[k]; }
+                idx[k + 1] = j; dist[k + 1] = d;
+            }
+        }
+        for (int k = 0; k < K; ++k)
+            if (idx[k] >= 0) { out[(size_t)i * 4 + 2 * k] = idx[k]; out[(size_t)i * 4 + 2 * k + 1] = dist[k]; }
+    }
+}
+
+// ratioTest (src/experiments.hpp:14-37): a query keeps its match when it has two neighbours and
+// distance0 / distance1 (float division of the float-converted distances) is not > ratio.  0/0 = NaN is "not >": kept.
+void ratio_test(const int* knn4, int n, float ratio, std::vector<int>& keep) {
+    keep.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (knn4[4 * i] < 0 || knn4[4 * i + 2] < 0) continue;
+        const float d0 = (float)knn4[4 * i + 1], d1 = (float)knn4[4 * i + 3];
+        keep[i] = !(d0 / d1 > ratio);
+    }
+}
+
+// symmetryTest (src/experiments.hpp:114-144): for every surviving 1->2 match, in query order, the first surviving
+// 2->1 match that points back.  out: n x 3 ints (queryIdx, trainIdx, distance)
+void symmetry_test(const int* knn12, const int* keep12, int n1, const int* knn21, const int* keep21, int n2, std::vector<int>& out) {
+    out.clear();
+    for (int i = 0; i < n1; ++i) {
+        if (!keep12[i]) continue;
+        for (int j = 0; j < n2; ++j) {
+            if (!keep21[j]) continue;
+            if (i == knn21[4 * j] && j == knn12[4 * i]) {
+                out.push_back(i); out.push_back(knn12[4 * i]); out.push_back(knn12[4 * i + 1]);
+                break;
+            }
+        }
+    }
+}
+
 }  // namespace oracle

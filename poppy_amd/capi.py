@@ -25,7 +25,8 @@ SYMBOLS = [
     "poppy_settings_default", "poppy_hip_create", "poppy_hip_destroy", "poppy_hip_last_error", "poppy_hip_create_error",
     "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
-    "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
+    "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_hamming_knn2", "poppy_ratio_symmetry",
+    "poppy_hip_pair_begin_descriptors", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -67,6 +68,9 @@ def lib():
         L.poppy_hip_debug_triangles.argtypes = [vp, vp, vp, vp, vp, i]
         L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.poppy_warp_records.argtypes = [vp, vp, i, i, i, vp]
+        L.poppy_hip_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp]
+        L.poppy_ratio_symmetry.argtypes = [vp, i, vp, i, C.c_float, vp, vp]
+        L.poppy_hip_pair_begin_descriptors.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i, i, C.c_float]
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
@@ -122,6 +126,18 @@ def warp_records(inv1, inv2, w, h):
     if rc < 0:
         raise PoppyError(f"poppy_warp_records: {rc}")
     return rec, bool(rc)
+
+
+def ratio_symmetry(knn12, knn21, ratio=0.7):
+    """Host-only ratioTest + symmetryTest (src/experiments.hpp:14-144): rows queryIdx, trainIdx, distance."""
+    knn12 = np.ascontiguousarray(knn12, np.int32).reshape(-1, 4)
+    knn21 = np.ascontiguousarray(knn21, np.int32).reshape(-1, 4)
+    out = np.zeros((max(len(knn12), 1), 3), np.int32)
+    n = C.c_int(0)
+    rc = lib().poppy_ratio_symmetry(_p(knn12), len(knn12), _p(knn21), len(knn21), ratio, _p(out), C.byref(n))
+    if rc:
+        raise PoppyError(f"poppy_ratio_symmetry: {rc}")
+    return out[:n.value]
 
 
 def radial_gradient(w, h):
@@ -277,6 +293,21 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_hamming_match(self.h, _p(q), len(q), _p(t), len(t), _p(out), C.byref(n)), "hamming_match")
         return out[:n.value].copy()
+
+    def hamming_knn2(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(q), 4), np.int32)
+        self._chk(lib().poppy_hip_hamming_knn2(self.h, _p(q), len(q), _p(t), len(t), _p(out)), "hamming_knn2")
+        return out
+
+    def pair_begin_descriptors(self, bgr1, bgr2, ratio=0.7):
+        """Opt-in descriptor mode of the pair set-up; returns nfeatures."""
+        a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
+        h, w = a.shape[:2]
+        self._chk(lib().poppy_hip_pair_begin_descriptors(self.h, _p(a), w * 3, _p(b), w * 3, w, h, ratio), "pair_begin_descriptors")
+        nf = C.c_int(0)
+        lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), None)
+        return nf.value
 
     def pair_begin_prefiltered(self, bgr1, bgr2, g1, g2, gabor2, nfeatures):
         a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)

@@ -29,5 +29,6 @@ void launch_orb_describe(const uint8_t* blurred, const OrbLevelSet& S, const int
 
 // brute-force Hamming 1-NN: out[i] = (best train index, distance); ties -> lowest train index
 void launch_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out2, hipStream_t s);
+void launch_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out4, hipStream_t s);   // (idx0, d0, idx1, d1)
 
 }  // namespace poppy_hip

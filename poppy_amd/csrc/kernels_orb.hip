@@ -306,9 +306,53 @@ __global__ void __launch_bounds__(256) k_hamming(const uint32_t* __restrict__ qu
     if (lane == 0 && qi < nq) { out2[2 * qi] = bestJ; out2[2 * qi + 1] = bestD; }
 }
 
+// BFMatcher::knnMatch(k = 2): the two nearest train descriptors per query, ordered by (distance, train index) — OpenCV's
+// sorted insertion uses strict comparisons, so equal distances keep the lower index first (batch_distance.cpp:225-248).
+// Same streaming as k_hamming; each lane keeps its two best, the wave merges them.  out4 = (idx0, d0, idx1, d1), -1 = none.
+__device__ __forceinline__ bool knn_less(int d, int j, int od, int oj) { return d < od || (d == od && j < oj); }
+
+__global__ void __launch_bounds__(256) k_hamming_knn2(const uint32_t* __restrict__ query, int nq, const uint32_t* __restrict__ train, int nt, int* __restrict__ out4) {
+    __shared__ uint32_t tile[kHamTile * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + wave;
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = qi < nq ? query[(size_t)qi * 8 + k] : 0u;
+    int d0 = INT_MAX, j0 = INT_MAX, d1 = INT_MAX, j1 = INT_MAX;
+    for (int base = 0; base < nt; base += kHamTile) {
+        const int cnt = min(kHamTile, nt - base);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[e] = train[(size_t)base * 8 + e];
+        __syncthreads();
+        for (int j = lane; j < cnt; j += 64) {
+            int d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[j * 8 + k]);
+            const int jj = base + j;                              // ascending per lane
+            if (d < d0) { d1 = d0; j1 = j0; d0 = d; j0 = jj; }
+            else if (d < d1) { d1 = d; j1 = jj; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {                      // merge two sorted pairs, keep the best two
+        const int a0 = __shfl_xor(d0, off), b0 = __shfl_xor(j0, off), a1 = __shfl_xor(d1, off), b1 = __shfl_xor(j1, off);
+        if (knn_less(a0, b0, d0, j0)) {
+            if (knn_less(a1, b1, d0, j0)) { d1 = a1; j1 = b1; } else { d1 = d0; j1 = j0; }
+            d0 = a0; j0 = b0;
+        } else if (knn_less(a0, b0, d1, j1)) { d1 = a0; j1 = b0; }
+    }
+    if (lane == 0 && qi < nq) {
+        out4[4 * qi] = d0 == INT_MAX ? -1 : j0; out4[4 * qi + 1] = d0 == INT_MAX ? -1 : d0;
+        out4[4 * qi + 2] = d1 == INT_MAX ? -1 : j1; out4[4 * qi + 3] = d1 == INT_MAX ? -1 : d1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+void launch_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, int* out4, hipStream_t s) {
+    if (nq > 0) hipLaunchKernelGGL(k_hamming_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint32_t*)query, nq, (const uint32_t*)train, nt, out4);
+}
 void launch_orb_blur(const uint8_t* atlas, uint8_t* blurred, const OrbLevelSet& S, hipStream_t s) {
     dim3 grid((S.lv[0].w + 2 * kOrbBorder + 255) / 256, S.lv[0].h + 2 * kOrbBorder, S.n);
     hipLaunchKernelGGL(k_orb_blur, grid, dim3(256), 0, s, atlas, blurred, S);

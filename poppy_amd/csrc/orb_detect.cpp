@@ -222,4 +222,22 @@ int OrbDetector::hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, hip
     return nq;
 }
 
+int OrbDetector::hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, hipStream_t s, int* out4) {
+    if (nq <= 0) return 0;
+    if (nt <= 0) { for (int i = 0; i < nq * 4; ++i) out4[i] = -1; return nq; }
+    uint8_t *dq = nullptr, *dt = nullptr; int* dout = nullptr;
+    ORB_CHK(hipMalloc((void**)&dq, (size_t)nq * 32));
+    hipError_t e = hipMalloc((void**)&dt, (size_t)nt * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)nq * 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { launch_hamming_knn2(dq, nq, dt, nt, dout, s); e = hipMemcpyAsync(out4, dout, (size_t)nq * 4 * sizeof(int), hipMemcpyDeviceToHost, s); }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (dq) (void)hipFree(dq);
+    if (dt) (void)hipFree(dt);
+    if (dout) (void)hipFree(dout);
+    ORB_CHK(e);
+    return nq;
+}
+
 }  // namespace poppy_hip

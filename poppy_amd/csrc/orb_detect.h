@@ -17,6 +17,7 @@ public:
     int describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out);
     // BFMatcher(NORM_HAMMING).match on 32-byte descriptors: out3 rows (queryIdx, trainIdx, distance)
     int hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, hipStream_t s, int* out3);
+    int hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, hipStream_t s, int* out4);   // rows (idx0, d0, idx1, d1)
     void release();
     std::string err;
 

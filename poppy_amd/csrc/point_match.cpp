@@ -268,4 +268,34 @@ void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h,
     for (const P2f& c : corners) { s1.push_back(c); s2.push_back(c); }
 }
 
+// Descriptor-matching sketch of src/experiments.hpp:14-144 on the 2-NN lists of both directions (rows idx0, d0, idx1, d1):
+// ratioTest drops a query without two neighbours or with d0 / d1 > ratio (float division of the float-converted
+// distances; 0/0 is NaN and "not >", so exact duplicates stay); symmetryTest keeps, for every surviving 1->2 match in
+// query order, the first surviving 2->1 match that points back.  out rows: queryIdx, trainIdx, distance.
+void ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, std::vector<int>& out3) {
+    auto keep = [ratio](const int* k) {
+        if (k[0] < 0 || k[2] < 0) return false;
+        return !((float)k[1] / (float)k[3] > ratio);
+    };
+    std::vector<char> k2(n2);
+    for (int j = 0; j < n2; ++j) k2[j] = keep(knn21 + 4 * j);
+    out3.clear();
+    for (int i = 0; i < n1; ++i) {
+        if (!keep(knn12 + 4 * i)) continue;
+        for (int j = 0; j < n2; ++j) {
+            if (!k2[j]) continue;
+            if (i == knn21[4 * j] && j == knn12[4 * i]) {
+                out3.push_back(i); out3.push_back(knn12[4 * i]); out3.push_back(knn12[4 * i + 1]);
+                break;
+            }
+        }
+    }
+}
+
+void add_image_corners(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h) {      // src/util.cpp:268-279
+    const float fw = (float)(w - 1), fh = (float)(h - 1);
+    const P2f corners[4] = {{0, 0}, {fw, 0}, {0, fh}, {fw, fh}};
+    for (const P2f& c : corners) { s1.push_back(c); s2.push_back(c); }
+}
+
 }  // namespace poppy_hip

@@ -17,4 +17,7 @@ void drop_out_of_image(std::vector<P2f>& p1, std::vector<P2f>& p2, int cols, int
 double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h);               // morph_distance
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist);
 
+void ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, std::vector<int>& out3);      // experiments.hpp:14-144
+void add_image_corners(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h);                              // add_corners
+
 }  // namespace poppy_hip

@@ -94,6 +94,7 @@ struct poppy_hip_ctx {
     hipStream_t aux_stream = nullptr;
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
+    int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
     double last_detail[2] = {0, 0};
     // diagnostics
@@ -794,6 +795,22 @@ int poppy_hip_hamming_match(poppy_hip_ctx* c, const uint8_t* query, int nq, cons
     return POPPY_OK;
 }
 
+int poppy_hip_hamming_knn2(poppy_hip_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt, int* out4) {
+    if (!c || nq < 0 || nt < 0 || (nq && !query) || (nt && !train) || (nq && !out4)) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->orb.hamming_knn2(query, nq, train, nt, c->stream, out4) < 0) { c->err = "hamming_knn2: " + c->orb.err; return POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
+int poppy_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, int* out3, int* n_out) {
+    if (n1 < 0 || n2 < 0 || !n_out || (n1 && !knn12) || (n2 && !knn21)) return POPPY_E_ARG;
+    std::vector<int> o;
+    ratio_symmetry(knn12, n1, knn21, n2, ratio, o);
+    *n_out = (int)o.size() / 3;
+    if (out3 && !o.empty()) memcpy(out3, o.data(), o.size() * sizeof(int));
+    return POPPY_OK;
+}
+
 int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
     if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
     std::vector<P2f> a(n), b(n);
@@ -839,7 +856,7 @@ int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, in
 }
 
 // Pair set-up from the raw images: the pre-ORB filter chain on the GPU, then the same steps as pair_begin_prefiltered.
-int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H) {
+static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
     if (!c) return POPPY_E_ARG;
     if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
@@ -893,16 +910,65 @@ int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const
         other.join();
         if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }
-    const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
-    std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
-    for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
-    int m = 0;
-    rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
-    if (rc) return fail(c, rc, "poppy_match_points failed");
-    rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
+    if (ratio >= 0.f) {
+        // Opt-in descriptor mode (the reference only sketched it, src/experiments.hpp:14-144): ORB::compute on both
+        // keypoint sets, 2-NN Hamming both ways, ratio test, symmetry test; the surviving pairs, in query order, become the
+        // point sets (out-of-image pairs dropped, the four corners appended).  No positional re-pairing, no threshold.
+        std::vector<uint8_t> d1(k1.size() * 32), d2(k2.size() * 32);
+        auto rows7 = [](const std::vector<OrbKeyPoint>& k) {            // cv::KeyPoint field order, all as float
+            std::vector<float> r(k.size() * 7);
+            for (size_t i = 0; i < k.size(); ++i) {
+                float* o = &r[i * 7];
+                o[0] = k[i].x; o[1] = k[i].y; o[2] = k[i].size; o[3] = k[i].angle; o[4] = k[i].response; o[5] = (float)k[i].octave; o[6] = (float)k[i].class_id;
+            }
+            return r;
+        };
+        const std::vector<float> r1v = rows7(k1), r2v = rows7(k2);
+        {
+            int r1 = 0, r2 = 0;
+            std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.describe(g[1].data(), W, W, H, r2v.data(), (int)k2.size(), c->aux_stream, d2.data()) : -2; });
+            r1 = c->orb.describe(g[0].data(), W, W, H, r1v.data(), (int)k1.size(), c->stream, d1.data());
+            other.join();
+            if (r1 < 0 || r2 < 0) { c->err = "orb_describe: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
+        }
+        std::vector<int> k12(k1.size() * 4), k21(k2.size() * 4), sym;
+        if (c->orb.hamming_knn2(d1.data(), (int)k1.size(), d2.data(), (int)k2.size(), c->stream, k12.data()) < 0 ||
+            c->orb.hamming_knn2(d2.data(), (int)k2.size(), d1.data(), (int)k1.size(), c->stream, k21.data()) < 0) {
+            c->err = "hamming_knn2: " + c->orb.err;
+            return POPPY_E_DEVICE;
+        }
+        ratio_symmetry(k12.data(), (int)k1.size(), k21.data(), (int)k2.size(), ratio, sym);
+        std::vector<P2f> a, b;
+        for (size_t i = 0; i + 3 <= sym.size(); i += 3) {
+            a.push_back(P2f{k1[sym[i]].x, k1[sym[i]].y});
+            b.push_back(P2f{k2[sym[i + 1]].x, k2[sym[i + 1]].y});
+        }
+        drop_out_of_image(a, b, W, H);
+        c->last_descriptor_matches = (int)a.size();
+        if (a.empty()) return fail(c, POPPY_E_NOMATCH, "no symmetric descriptor matches");
+        c->initial_morph_dist = morph_distance_ref(a, b, W, H);
+        add_image_corners(a, b, W, H);
+        rc = set_points(c, (const float*)a.data(), (const float*)b.data(), (int)a.size()); if (rc) return rc;
+    } else {
+        const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
+        std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
+        for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
+        int m = 0;
+        rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
+        if (rc) return fail(c, rc, "poppy_match_points failed");
+        rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
+    }
     rc = finish_pair_load(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return POPPY_OK;
+}
+
+int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H) {
+    return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, -1.f);
+}
+int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
+    if (!(ratio >= 0.f)) return c ? fail(c, POPPY_E_ARG, "ratio must be >= 0") : POPPY_E_ARG;
+    return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, ratio);
 }
 
 // intermediates of the last poppy_hip_pair_begin, for the tolerance tests: nfeatures, the two dft_detail2 values

@@ -252,6 +252,23 @@ def hamming_match(q, t):
     return out[:n]
 
 
+def hamming_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros((len(q), 4), np.int32)
+    lib().orc_hamming_knn2(_vp(q), len(q), _vp(t), len(t), q.shape[1], _vp(out))
+    return out
+
+
+def ratio_symmetry(knn12, knn21, ratio=0.7):
+    """(keep12, keep21, symmetric matches n x 3) of src/experiments.hpp's ratioTest + symmetryTest."""
+    knn12 = np.ascontiguousarray(knn12, np.int32); knn21 = np.ascontiguousarray(knn21, np.int32)
+    k1 = np.zeros(len(knn12), np.int32); k2 = np.zeros(len(knn21), np.int32)
+    out = np.zeros((max(len(knn12), 1), 3), np.int32)
+    lib().orc_ratio_symmetry.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = lib().orc_ratio_symmetry(_vp(knn12), len(knn12), _vp(knn21), len(knn21), ratio, _vp(k1), _vp(k2), _vp(out))
+    return k1, k2, out[:n]
+
+
 def distance_map(p1, p2):
     p1, p2 = _f(p1), _f(p2)
     out = np.zeros((len(p1), 5), np.float64)

@@ -69,6 +69,26 @@ def test_orb_describe_and_hamming_vs_opencv(ctx, case, nf):
         G.check(case, f"n{nf}_desc{im}", d)
         descs[im] = d
     G.check(case, f"n{nf}_bfmatch", ctx.hamming_match(descs["1"], descs["2"]))
+    # the reference's descriptor-matching sketch (src/experiments.hpp:14-144) on the same descriptors
+    from poppy_amd import capi
+    k12, k21 = ctx.hamming_knn2(descs["1"], descs["2"]), ctx.hamming_knn2(descs["2"], descs["1"])
+    G.check(case, f"n{nf}_knn12", k12)
+    G.check(case, f"n{nf}_knn21", k21)
+    G.check(case, f"n{nf}_sym", capi.ratio_symmetry(k12, k21, 0.7))
+
+
+def test_knn2_ties_and_ragged(ctx):
+    rng = np.random.RandomState(6)
+    q = rng.randint(0, 256, (131, 32)).astype(np.uint8)
+    t = rng.randint(0, 256, (1537, 32)).astype(np.uint8)
+    t[900] = t[3]; t[17] = q[5]; t[1200] = q[5]; t[1536] = q[5]      # duplicates: ordered by train index
+    got = ctx.hamming_knn2(q, t)
+    assert np.array_equal(got, O.hamming_knn2(q, t))
+    assert got[5].tolist() == [17, 0, 1200, 0]
+    assert np.array_equal(ctx.hamming_knn2(q, t[:1]), O.hamming_knn2(q, t[:1]))
+    assert (ctx.hamming_knn2(q, t[:0]) == -1).all()
+    low = (rng.randint(0, 4, (300, 32)) == 0).astype(np.uint8)          # few distinct distances: many ties
+    assert np.array_equal(ctx.hamming_knn2(low[:100], low), O.hamming_knn2(low[:100], low))
 
 
 def test_hamming_ties_and_ragged(ctx):

@@ -63,6 +63,32 @@ def test_pair_begin_from_raw_images_reproduces_poppy_morph(case):
     c.close()
 
 
+def test_pair_begin_descriptors_mode():
+    """Opt-in descriptor matching: the point pairs must be what the reference's sketch (knnMatch k=2 both ways,
+    ratioTest 0.7, symmetryTest; src/experiments.hpp:14-144) selects from the reference pipeline's own keypoints, in query
+    order, plus the four corners; the frames then come from the ordinary per-frame path."""
+    import oracle_lib as O
+    from poppy_amd import capi
+    case = "a_256x256_chain"
+    inp = G.astage_inputs(case)
+    c = capi.Context(0, number_of_frames=4)
+    nf = c.pair_begin_descriptors(inp["img1"], inp["img2"], 0.7)
+    assert nf == int(G.full(case, "detail")[3])
+    p1, p2 = c.pair_points()
+    kp1, kp2 = G.full(case, "kp1"), G.full(case, "kp2")              # cv::KeyPoint rows of the reference run
+    d1 = O.orb_describe(G.full(case, "g1"), kp1); d2 = O.orb_describe(G.full(case, "g2"), kp2)
+    _, _, sym = O.ratio_symmetry(O.hamming_knn2(d1, d2), O.hamming_knn2(d2, d1), 0.7)
+    h, w = inp["img1"].shape[:2]
+    corners = np.array([[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]], np.float32)
+    want1 = np.concatenate([kp1[sym[:, 0], :2], corners]); want2 = np.concatenate([kp2[sym[:, 1], :2], corners])
+    assert len(sym) > 20
+    assert np.array_equal(p1, want1.astype(np.float32)) and np.array_equal(p2, want2.astype(np.float32))
+    frames = c.morph_frames(-1.0)                                      # the ordinary per-frame path on those pairs
+    assert len(frames) == 4 and frames[0].shape == inp["img1"].shape
+    assert np.array_equal(frames[-1], inp["img2"]) or np.abs(frames[-1].astype(int) - inp["img2"].astype(int)).mean() < 20
+    c.close()
+
+
 @pytest.mark.parametrize("w,h,seed", [(97, 61, 2), (64, 130, 3)])
 def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
     import oracle_lib as O

@@ -118,3 +118,14 @@ def test_warp_records_layout_and_admission():
     assert admitted([1, 0, 0, 0, 1, 0, 0, 0, -1])             # negative denominators are fine while they keep their sign
     assert not admitted([np.inf, 0, 0, 0, 1, 0, 0, 0, 1]) and not admitted([np.nan, 0, 0, 0, 1, 0, 0, 0, 1])
     assert not admitted([2e12, 0, 0, 0, 1, 0, 0, 0, 1])       # > 2^40
+
+
+def test_ratio_symmetry_host_vs_reference_lists():
+    """poppy_ratio_symmetry (host) on the reference's own 2-NN lists reproduces its symmetric matches."""
+    for case, nf in (("o_256x256", 300), ("o_640x480", 500), ("o_1920x1080", 516)):
+        k12, k21 = G.full(case, f"n{nf}_knn12"), G.full(case, f"n{nf}_knn21")
+        G.check(case, f"n{nf}_sym", capi.ratio_symmetry(k12, k21, 0.7))
+    # no second neighbour -> dropped; 0/0 -> kept; ratio 0 keeps only exact matches
+    k12 = np.array([[0, 5, -1, -1], [1, 0, 0, 0]], np.int32); k21 = np.array([[0, 5, 1, 9], [1, 0, 0, 0]], np.int32)
+    assert capi.ratio_symmetry(k12, k21, 0.7).tolist() == [[1, 1, 0]]
+    assert len(capi.ratio_symmetry(k12[:0], k21, 0.7)) == 0

@@ -88,3 +88,29 @@ def test_orb_describe_and_bfmatch_bit_exact(case, nf):
         d[im] = O.orb_describe(inp["g" + im], G.full(case, f"n{nf}_kp{im}"))
         G.check(case, f"n{nf}_desc{im}", d[im])
     G.check(case, f"n{nf}_bfmatch", O.hamming_match(d["1"], d["2"]))
+    # descriptor-matching sketch (src/experiments.hpp:14-144): BFMatcher::knnMatch k=2 both ways, ratioTest, symmetryTest
+    k12, k21 = O.hamming_knn2(d["1"], d["2"]), O.hamming_knn2(d["2"], d["1"])
+    G.check(case, f"n{nf}_knn12", k12)
+    G.check(case, f"n{nf}_knn21", k21)
+    keep12, keep21, sym = O.ratio_symmetry(k12, k21, 0.7)
+    G.check(case, f"n{nf}_ratio12", keep12)
+    G.check(case, f"n{nf}_ratio21", keep21)
+    G.check(case, f"n{nf}_sym", sym)
+
+
+def test_knn2_edge_cases():
+    """Ties keep the lower train index first; fewer than two train descriptors leave no second neighbour (K = min(2, n),
+    OCV/core/src/batch_distance.cpp:286) and the ratio test then drops the query (experiments.hpp:30-33);
+    0/0 is not > 0.7, so two exact duplicates survive the ratio test."""
+    import numpy as np
+    q = np.zeros((2, 32), np.uint8); q[1, 0] = 0xFF
+    t = np.zeros((4, 32), np.uint8); t[0, 0] = 1; t[1, 1] = 1; t[2, 2] = 3; t[3, 0] = 0xFF
+    k = O.hamming_knn2(q, t)
+    assert k.tolist() == [[0, 1, 1, 1], [3, 0, 0, 7]]
+    assert O.hamming_knn2(q, t[:1]).tolist() == [[0, 1, -1, -1], [0, 7, -1, -1]]
+    assert O.hamming_knn2(q, t[:0]).tolist() == [[-1, -1, -1, -1]] * 2
+    dup = np.zeros((2, 32), np.uint8)
+    k12 = O.hamming_knn2(dup[:1], dup)
+    assert k12.tolist() == [[0, 0, 1, 0]]
+    keep12, keep21, sym = O.ratio_symmetry(k12, O.hamming_knn2(dup, dup[:1]))
+    assert keep12.tolist() == [1] and keep21.tolist() == [0, 0] and len(sym) == 0
