@@ -31,6 +31,8 @@
 #include "draw.hpp"
 #include "extractor.hpp"
 #include "settings.hpp"
+#include "transformer.hpp"
+#include "procrustes.hpp"
 namespace poppy {   // defined in experiments.hpp, emitted by extractor.o
 double dft_detail2(const cv::Mat& src, cv::Mat& dst);
 int ratioTest(std::vector<std::vector<cv::DMatch>>& matches);
@@ -616,6 +618,84 @@ static void dump_margin() {
     dump_mat("padded", out);
 }
 
+// Auto-align (Matcher::autoAlign, src/matcher.cpp:133-244) and its pieces (Transformer, src/transformer.cpp; Procrustes),
+// each run on fresh copies of the same inputs, plus the OpenCV primitives they are made of.
+static void dump_align() {
+    Mat img2 = read_mat("img2");
+    vector<Point2f> p1 = read_pts("pts1"), p2 = read_pts("pts2");
+    vector<double> cfg = read_f64("cfg");
+    int w = (int)cfg[0], h = (int)cfg[1];
+    Mat aff = read_mat("aff");
+    Transformer tr(w, h);
+    {   // warpAffine as Transformer uses it
+        Mat o;
+        tr.translate(img2, o, Point2f(5, -3)); dump_mat("wa_t1", o);
+        tr.translate(img2, o, Point2f(-40, 17)); dump_mat("wa_t2", o);
+        Point2f c1(w / 3.f, h / 2.f), c2(w * 0.61f, h * 0.27f);
+        dump_mat("rm1", getRotationMatrix2D(c1, 12.0 + 1.0 / 3.0, 1.0));
+        dump_mat("rm2", getRotationMatrix2D(c2, -100.0 / 3.0, 1.0));
+        tr.rotate(img2, o, c1, 12.0 + 1.0 / 3.0); dump_mat("wa_r1", o);
+        tr.rotate(img2, o, c2, -100.0 / 3.0); dump_mat("wa_r2", o);
+        warpAffine(img2, o, aff, img2.size()); dump_mat("wa_a1", o);
+        Mat inplace = img2.clone();
+        warpAffine(inplace, inplace, aff, inplace.size());
+        if (cv::norm(inplace, o, NORM_INF) != 0) { fprintf(stderr, "FATAL: in-place warpAffine differs\n"); exit(2); }
+    }
+    {   // primitives of Procrustes on the raw point sets
+        Mat X(p1), Y(p2);
+        Scalar mu = cv::mean(X);
+        dump_f64("prim_mean", { mu[0], mu[1] });
+        Mat sq; pow(X, 2.0, sq);
+        Scalar ss = sum(sq);
+        dump_f64("prim_sumsq", { ss[0], ss[1] });
+        Mat A = X.reshape(1).t() * Y.reshape(1);
+        dump_mat("prim_gemm", A);
+        Mat An = A / 1000.0;
+        Mat U, s, Vt;
+        SVDecomp(An, s, U, Vt);
+        dump_mat("prim_svd_in", An); dump_mat("prim_svd_s", s); dump_mat("prim_svd_u", U); dump_mat("prim_svd_vt", Vt);
+        Mat T; cv::transform(X, T, Vt);
+        dump_mat("prim_transform", T.reshape(1));
+        Mat P = getPerspectiveTransform(p1.data(), p2.data());
+        dump_mat("prim_persp", P);
+        vector<Point2f> q; perspectiveTransform(p1, q, P);
+        dump_pts("prim_persp_pts", q);
+    }
+    dump_f64("md0", { (double)morph_distance(p1, p2, w, h) });
+    {
+        Procrustes procr(true, false);
+        float err = procr.procrustes(p1, p2);
+        dump_mat("pc_rotation", procr.rotation);
+        dump_f64("pc_scalars", { (double)procr.scale, (double)procr.error, (double)err });
+        dump_pts("pc_yprime", procr.yPrimeAsVector());
+        dump_mat("pc_translation", procr.translation);
+    }
+    {
+        Mat c2 = img2.clone(); vector<Point2f> a = p1, b = p2;
+        double d = tr.retranslate(c2, a, b);
+        dump_mat("rt_img", c2); dump_pts("rt_pts2", b); dump_f64("rt_dist", { d });
+    }
+    {
+        Mat c2 = img2.clone(); vector<Point2f> a = p1, b = p2;
+        double d = tr.reprocrustes(c2, a, b);
+        dump_mat("rp_img", c2); dump_pts("rp_pts2", b); dump_f64("rp_dist", { d });
+    }
+    {
+        Mat c2 = img2.clone(); vector<Point2f> a = p1, b = p2;
+        double d = tr.rerotate(c2, a, b);
+        dump_mat("rr_img", c2); dump_pts("rr_pts2", b); dump_f64("rr_dist", { d });
+    }
+    {
+        Mat img1(h, w, CV_8UC3, Scalar(0, 0, 0));
+        Features ft1, ft2;
+        Matcher m(img1, img2, ft1, ft2);
+        Mat c1 = img1.clone(), c2 = img2.clone(); vector<Point2f> a = p1, b = p2;
+        m.autoAlign(c1, c2, a, b);
+        dump_mat("aa_img", c2); dump_pts("aa_pts1", a); dump_pts("aa_pts2", b);
+        dump_f64("aa_dist", { (double)morph_distance(a, b, w, h) });
+    }
+}
+
 static void dump_logcheck() {      // cv::log / cv::magnitude on given floats (debugging aid for the oracle)
     Mat x = read_mat("x"), y;
     log(x, y);
@@ -632,6 +712,7 @@ int main(int argc, char** argv) {
     else if (mode == "orb") dump_orb();
     else if (mode == "match") dump_match();
     else if (mode == "astage") dump_astage();
+    else if (mode == "align") dump_align();
     else if (mode == "prims") dump_prims();
     else if (mode == "fstage") dump_fstage();
     else if (mode == "detail") dump_detail();

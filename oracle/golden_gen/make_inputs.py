@@ -151,6 +151,28 @@ def prims_inputs():
                 remap_src=src, remap_mx=mx, remap_my=my, mats33=mats)
 
 
+ALIGN = {
+    # name: (w, h, n, angle_deg, shift_x, shift_y, scale, seed)   second point set = first one rotated / shifted / scaled + jitter
+    "l_320x240": (320, 240, 60, 7.0, 6.0, -4.0, 1.03, 61),
+    "l_640x480": (640, 480, 150, -11.0, -9.0, 5.0, 0.97, 62),
+    "l_317x211": (317, 211, 40, 3.0, 2.0, 3.0, 1.0, 63),
+}
+
+
+def align_inputs(name):
+    w, h, n, ang, sx, sy, sc, seed = ALIGN[name]
+    img2 = synth.textured_bgr(w, h, seed)
+    rng = synth.XorShift64Star(seed)
+    p1 = np.array([[w / 8.0 + rng.uniform(0, 3 * w) / 4.0, h / 8.0 + rng.uniform(0, 3 * h) / 4.0] for _ in range(n)], dtype=np.float64)
+    a = np.deg2rad(ang)
+    c = np.array([w / 2.0, h / 2.0])
+    R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) * sc
+    jit = np.array([[(rng.uniform(0, 200) - 100) / 100.0, (rng.uniform(0, 200) - 100) / 100.0] for _ in range(n)])
+    p2 = (p1 - c) @ R.T + c + np.array([sx, sy]) + jit
+    aff = np.array([[0.98, 0.07, 3.25], [-0.05, 1.03, -2.5]], dtype=np.float64)
+    return dict(img2=img2, pts1=p1.astype(np.float32), pts2=p2.astype(np.float32), cfg=np.array([w, h], dtype=np.float64), aff=aff)
+
+
 def all_cases():
     out = []
     out += [("bstage", n, bstage_inputs) for n in BSTAGE]
@@ -161,6 +183,7 @@ def all_cases():
     out += [("fstage", n, fstage_inputs) for n in FSTAGE]
     out += [("detail", n, detail_inputs) for n in DETAIL]
     out += [("margin", n, margin_inputs) for n in MARGIN]
+    out += [("align", n, align_inputs) for n in ALIGN]
     return out
 
 

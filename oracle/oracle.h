@@ -112,6 +112,26 @@ void filter_invalid_points(std::vector<Pt>& p1, std::vector<Pt>& p2, int cols, i
 double morph_distance(const std::vector<Pt>& p1, const std::vector<Pt>& p2, int w, int h);
 void match_prepare(std::vector<Pt>& s1, std::vector<Pt>& s2, int w, int h, double tolerance, double initialMorphDist);
 
+// ---- align.cpp: auto-align (src/matcher.cpp:133-244, src/transformer.cpp, src/procrustes.cpp) -------------------
+void warp_affine(const ImageU8& src, const double Mfwd[6], ImageU8& dst);      // cv::warpAffine, INTER_LINEAR, BORDER_CONSTANT 0
+void rotation_matrix(float cx, float cy, double angle_deg, double scale, double M[6]);
+void translate_image(const ImageU8& src, float tx, float ty, ImageU8& dst);
+void rotate_image(const ImageU8& src, float cx, float cy, double angle_deg, ImageU8& dst);
+void rotate_points(std::vector<Pt>& pts, Pt center, double ang_deg);
+void mean2(const std::vector<Pt>& p, double mu[2]);
+void sum_squares2(const std::vector<Pt>& p, double ss[2]);
+void gemm_at_b(const std::vector<Pt>& X, const std::vector<Pt>& Y, float A[4]);
+void svd2(const float A[4], float w[2], float U[4], float Vt[4]);
+void transform2(const std::vector<Pt>& src, const float m[4], std::vector<Pt>& dst);
+struct ProcrustesResult { float rotation[4]; float scale, error; std::vector<Pt> yprime; float translation[2]; };
+void procrustes(const std::vector<Pt>& X, const std::vector<Pt>& Y, ProcrustesResult& R);
+void perspective_from_4(const Pt* src, const Pt* dst, double M[9]);
+void perspective_points(std::vector<Pt>& pts, const double m[9]);
+double retranslate(ImageU8& corrected2, const std::vector<Pt>& p1, std::vector<Pt>& p2, int w, int h);
+double rerotate(ImageU8& corrected2, const std::vector<Pt>& p1, std::vector<Pt>& p2, int w, int h);
+double reprocrustes(ImageU8& corrected2, const std::vector<Pt>& p1, std::vector<Pt>& p2, int w, int h);
+void auto_align(ImageU8& corrected2, std::vector<Pt>& p1, std::vector<Pt>& p2, int w, int h);
+
 // ---- prefilter.cpp: Extractor::foreground (src/extractor.cpp:136-229) -------------------------
 void bgr_to_gray_u8(const ImageU8& bgr, ImageU8& gray);
 struct Mog2 {                                   // BackgroundSubtractorMOG2(500, 16, true), one channel

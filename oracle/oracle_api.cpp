@@ -172,4 +172,36 @@ void orc_gabor_filter_direct(const float* src, int w, int h, int c, int ks, cons
 
 void orc_blur_margin(const uint8_t* src, int w, int h, int uw, int uh, uint8_t* dst) { ImageU8 o; blur_margin(wrap_u8(src, w, h, 3), uw, uh, o); put_img(dst, o); }
 
+// ---- auto-align ----------------------------------------------------------------------------------------------
+void orc_warp_affine(const uint8_t* src, int w, int h, int c, const double* M6, uint8_t* dst) {
+    ImageU8 o; warp_affine(wrap_u8(src, w, h, c), M6, o); memcpy(dst, o.d.data(), o.d.size());
+}
+void orc_rotation_matrix(float cx, float cy, double angle, double scale, double* M6) { rotation_matrix(cx, cy, angle, scale, M6); }
+void orc_align_prims(const float* x, const float* y, int n, double* mean2_, double* sumsq2, float* gemm4, const float* svd_in4, float* svd_w2,
+                     float* svd_u4, float* svd_vt4, const float* tr_m4, float* tr_out, double* persp9, float* persp_pts) {
+    auto X = wrap_pts(x, n), Y = wrap_pts(y, n);
+    mean2(X, mean2_); sum_squares2(X, sumsq2); gemm_at_b(X, Y, gemm4);
+    svd2(svd_in4, svd_w2, svd_u4, svd_vt4);
+    std::vector<Pt> t; transform2(X, tr_m4, t); put((Pt*)tr_out, t);
+    perspective_from_4(X.data(), Y.data(), persp9);
+    auto q = X; perspective_points(q, persp9); put((Pt*)persp_pts, q);
+}
+void orc_procrustes(const float* x, const float* y, int n, float* rot4, float* scalars2, float* yprime, float* trans2) {
+    ProcrustesResult R; procrustes(wrap_pts(x, n), wrap_pts(y, n), R);
+    memcpy(rot4, R.rotation, 16); scalars2[0] = R.scale; scalars2[1] = R.error; put((Pt*)yprime, R.yprime); memcpy(trans2, R.translation, 8);
+}
+// which: 0 retranslate, 1 reprocrustes, 2 rerotate, 3 autoAlign.  img (w*h*3) and p2 are updated in place; p1 only by 3 (never changes).
+double orc_align_step(int which, uint8_t* img, int w, int h, const float* p1, float* p2, int n) {
+    ImageU8 im = wrap_u8(img, w, h, 3);
+    auto a = wrap_pts(p1, n), b = wrap_pts(p2, n);
+    double d = 0;
+    if (which == 0) d = retranslate(im, a, b, w, h);
+    else if (which == 1) d = reprocrustes(im, a, b, w, h);
+    else if (which == 2) d = rerotate(im, a, b, w, h);
+    else { auto_align(im, a, b, w, h); d = morph_distance(a, b, w, h); }
+    memcpy(img, im.d.data(), im.d.size());
+    put((Pt*)p2, b);
+    return d;
+}
+
 }  // extern "C"

@@ -367,3 +367,51 @@ def blur_margin(img, uw, uh):
     a = np.ascontiguousarray(img, np.uint8); o = np.zeros((uh, uw, 3), np.uint8)
     lib().orc_blur_margin(_vp(a), a.shape[1], a.shape[0], uw, uh, _vp(o))
     return o
+
+
+# ---- auto-align (oracle/align.cpp) --------------------------------------------------------------------------------
+def warp_affine(img, M):
+    img = np.ascontiguousarray(img, np.uint8)
+    M = np.ascontiguousarray(M, np.float64).reshape(6)
+    h, w = img.shape[:2]
+    c = img.shape[2] if img.ndim == 3 else 1
+    out = np.zeros_like(img)
+    lib().orc_warp_affine(_vp(img), w, h, c, _vp(M), _vp(out))
+    return out
+
+
+def rotation_matrix(cx, cy, angle, scale=1.0):
+    M = np.zeros(6, np.float64)
+    lib().orc_rotation_matrix.argtypes = [C.c_float, C.c_float, C.c_double, C.c_double, C.c_void_p]
+    lib().orc_rotation_matrix(cx, cy, angle, scale, _vp(M))
+    return M.reshape(2, 3)
+
+
+def align_prims(x, y, svd_in, tr_m):
+    x, y = _f(x), _f(y)
+    n = len(x)
+    r = dict(mean=np.zeros(2), sumsq=np.zeros(2), gemm=np.zeros((2, 2), np.float32), svd_w=np.zeros((2, 1), np.float32),
+             svd_u=np.zeros((2, 2), np.float32), svd_vt=np.zeros((2, 2), np.float32), transform=np.zeros((n, 2), np.float32),
+             persp=np.zeros((3, 3)), persp_pts=np.zeros((n, 2), np.float32))
+    si = np.ascontiguousarray(svd_in, np.float32); tm = np.ascontiguousarray(tr_m, np.float32)
+    lib().orc_align_prims(_vp(x), _vp(y), n, _vp(r["mean"]), _vp(r["sumsq"]), _vp(r["gemm"]), _vp(si), _vp(r["svd_w"]), _vp(r["svd_u"]),
+                          _vp(r["svd_vt"]), _vp(tm), _vp(r["transform"]), _vp(r["persp"]), _vp(r["persp_pts"]))
+    return r
+
+
+def procrustes(x, y):
+    x, y = _f(x), _f(y)
+    rot = np.zeros((2, 2), np.float32); sc = np.zeros(2, np.float32); yp = np.zeros((len(x), 2), np.float32); tr = np.zeros((1, 2), np.float32)
+    lib().orc_procrustes(_vp(x), _vp(y), len(x), _vp(rot), _vp(sc), _vp(yp), _vp(tr))
+    return dict(rotation=rot, scale=sc[0], error=sc[1], yprime=yp, translation=tr)
+
+
+def align_step(which, img, p1, p2):
+    """which: 'retranslate' | 'reprocrustes' | 'rerotate' | 'auto'.  Returns (image, pts2, distance)."""
+    code = {"retranslate": 0, "reprocrustes": 1, "rerotate": 2, "auto": 3}[which]
+    im = np.ascontiguousarray(img, np.uint8).copy()
+    p1 = _f(p1); q = _f(p2).copy()
+    h, w = im.shape[:2]
+    lib().orc_align_step.restype = C.c_double
+    d = lib().orc_align_step(code, _vp(im), w, h, _vp(p1), _vp(q), len(p1))
+    return im, q, d
