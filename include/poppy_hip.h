@@ -43,6 +43,7 @@ typedef struct {
     int max_keypoints;       /* 300 */
     int pyramid_levels;      /* 64  */
     int enable_radial_mask;  /* 0   */
+    int enable_auto_align;   /* 0: Matcher::autoAlign on corrected2 and its points before matching (src/matcher.cpp:29-32) */
 } poppy_settings;
 
 void poppy_settings_default(poppy_settings* s);
@@ -122,6 +123,26 @@ int poppy_hip_hamming_match(poppy_hip_ctx* ctx, const uint8_t* query32, int n_qu
  * ransacTest (findFundamentalMat) of the same sketch is not provided.                                          */
 int poppy_hip_hamming_knn2(poppy_hip_ctx* ctx, const uint8_t* query32, int n_query, const uint8_t* train32, int n_train, int* out4);
 int poppy_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, int* out3, int* n_out);
+
+/* ---- auto-align (Settings::enable_auto_align) ---------------------------------------------------
+ * warp_affine : cv::warpAffine(src, dst, M, src.size()) for 8UC3, INTER_LINEAR, BORDER_CONSTANT 0, M = 2x3 forward map
+ *               (OCV/imgproc/src/imgwarp.cpp:2155-2290,2582-2640) — what Transformer::translate / rotate and
+ *               reprocrustes apply to corrected2 (src/transformer.cpp:21-30,268).
+ * auto_align  : Matcher::autoAlign (src/matcher.cpp:133-244) on a host image and two point lists: image2 and points2 are
+ *               replaced by their aligned versions; *distance = morph distance afterwards.
+ * align_step  : one Transformer step on the same arguments — 0 retranslate, 1 reprocrustes, 2 rerotate
+ *               (src/transformer.cpp:99-217,260-269); *distance = the value the step returns.
+ * procrustes / perspective_from4 (host only): Procrustes(true,false)::procrustes (src/procrustes.cpp:52-114; rotation 2x2,
+ *               scale_error[2], yprime n x 2) and cv::getPerspectiveTransform of four point pairs (3x3 doubles).
+ * poppy_hip_pair_begin runs auto_align itself when settings.enable_auto_align is set.                              */
+int poppy_hip_warp_affine(poppy_hip_ctx* ctx, const uint8_t* src, size_t src_stride, int width, int height, const double* m2x3,
+                          uint8_t* dst, size_t dst_stride);
+int poppy_hip_auto_align(poppy_hip_ctx* ctx, uint8_t* image2, size_t stride, int width, int height,
+                         const float* points1, float* points2, int n_points, double* distance);
+int poppy_hip_align_step(poppy_hip_ctx* ctx, int which, uint8_t* image2, size_t stride, int width, int height,
+                         const float* points1, float* points2, int n_points, double* distance);
+int poppy_procrustes(const float* x, const float* y, int n_points, float* rotation4, float* scale_error2, float* yprime);
+int poppy_perspective_from4(const float* src4, const float* dst4, double* m3x3);
 
 /* Matcher::find (general branch) + Matcher::prepare on raw point lists (src/matcher.cpp:118-131,246-332):
  * drop out-of-image pairs, morph distance, greedy nearest-neighbour pairing, threshold filter, 4 corners.

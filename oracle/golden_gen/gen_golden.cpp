@@ -405,7 +405,8 @@ static void dump_astage() {
     Mat a = read_mat("img1"), b = read_mat("img2");
     vector<double> cfg = read_f64("cfg");   // nframes, phase, levels
     int nframes = (int)cfg[0]; double phase = cfg[1]; int levels = (int)cfg[2];
-    poppy::init(false, nframes, 1.0, false, false, false, false, false, 30, levels, "FFV1", false, 8);
+    const bool autoAlign = cfg.size() > 3 && cfg[3] != 0;
+    poppy::init(false, nframes, 1.0, autoAlign, false, false, false, false, 30, levels, "FFV1", false, 8);
 
     Extractor ex(a, b);
     auto gf = ex.prepareFeatures();
@@ -463,6 +464,7 @@ static void dump_astage() {
     matcher.find(c1, c2, s1, s2);
     dump_pts("found1", s1); dump_pts("found2", s2);
     dump_f64("initialMorphDist", { matcher.initialMorphDist_ });
+    if (autoAlign) dump_mat("corrected2", c2);
     Mat c2f, gabor2;
     c2.convertTo(c2f, CV_32F, 1.0 / 255);
     gabor_filter(c2f, gabor2);

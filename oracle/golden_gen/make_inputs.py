@@ -52,6 +52,8 @@ ASTAGE = {
     "a_256x256_chain": (256, 256, 6, -1.0, 64),
     "a_256x256_phase": (256, 256, 1, 0.5, 64),
     "a_512x384_chain": (512, 384, 4, -1.0, 64),
+    "a_256x256_align": (256, 256, 3, -1.0, 64, 1),      # enable_auto_align (src/matcher.cpp:29-32)
+    "a_384x288_align": (384, 288, 2, -1.0, 64, 1),
 }
 
 
@@ -127,9 +129,10 @@ def match_inputs(name):
 
 
 def astage_inputs(name):
-    w, h, nframes, phase, levels = ASTAGE[name]
+    w, h, nframes, phase, levels = ASTAGE[name][:5]
+    align = ASTAGE[name][5] if len(ASTAGE[name]) > 5 else 0
     a, b = synth.gen_pair(w, h)
-    return dict(img1=a, img2=b, cfg=np.array([nframes, phase, levels], dtype=np.float64))
+    return dict(img1=a, img2=b, cfg=np.array([nframes, phase, levels] + ([align] if align else []), dtype=np.float64))
 
 
 def prims_inputs():

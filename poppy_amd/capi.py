@@ -15,7 +15,7 @@ _lib = None
 
 class PoppySettings(C.Structure):
     _fields_ = [("number_of_frames", C.c_int), ("match_tolerance", C.c_double), ("max_keypoints", C.c_int),
-                ("pyramid_levels", C.c_int), ("enable_radial_mask", C.c_int)]
+                ("pyramid_levels", C.c_int), ("enable_radial_mask", C.c_int), ("enable_auto_align", C.c_int)]
 
 
 WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
@@ -26,7 +26,8 @@ SYMBOLS = [
     "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_hamming_knn2", "poppy_ratio_symmetry",
-    "poppy_hip_pair_begin_descriptors", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
+    "poppy_hip_pair_begin_descriptors", "poppy_hip_warp_affine", "poppy_hip_auto_align", "poppy_hip_align_step",
+    "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -69,6 +70,11 @@ def lib():
         L.poppy_plan_frame.argtypes = [i, i, vp, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.poppy_warp_records.argtypes = [vp, vp, i, i, i, vp]
         L.poppy_hip_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp]
+        L.poppy_hip_warp_affine.argtypes = [vp, vp, C.c_size_t, i, i, vp, vp, C.c_size_t]
+        L.poppy_hip_auto_align.argtypes = [vp, vp, C.c_size_t, i, i, vp, vp, i, vp]
+        L.poppy_hip_align_step.argtypes = [vp, i, vp, C.c_size_t, i, i, vp, vp, i, vp]
+        L.poppy_procrustes.argtypes = [vp, vp, i, vp, vp, vp]
+        L.poppy_perspective_from4.argtypes = [vp, vp, vp]
         L.poppy_ratio_symmetry.argtypes = [vp, i, vp, i, C.c_float, vp, vp]
         L.poppy_hip_pair_begin_descriptors.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i, i, C.c_float]
         L.poppy_hip_timing_summary.argtypes = [vp, vp, vp, vp, i]
@@ -138,6 +144,25 @@ def ratio_symmetry(knn12, knn21, ratio=0.7):
     if rc:
         raise PoppyError(f"poppy_ratio_symmetry: {rc}")
     return out[:n.value]
+
+
+def procrustes(x, y):
+    """Host-only Procrustes(true, false)::procrustes: dict(rotation 2x2, scale, error, yprime n x 2)."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 2); y = np.ascontiguousarray(y, np.float32).reshape(-1, 2)
+    rot = np.zeros((2, 2), np.float32); se = np.zeros(2, np.float32); yp = np.zeros_like(x)
+    rc = lib().poppy_procrustes(_p(x), _p(y), len(x), _p(rot), _p(se), _p(yp))
+    if rc:
+        raise PoppyError(f"poppy_procrustes: {rc}")
+    return dict(rotation=rot, scale=se[0], error=se[1], yprime=yp)
+
+
+def perspective_from4(src4, dst4):
+    s = np.ascontiguousarray(src4, np.float32).reshape(4, 2); d = np.ascontiguousarray(dst4, np.float32).reshape(4, 2)
+    m = np.zeros((3, 3), np.float64)
+    rc = lib().poppy_perspective_from4(_p(s), _p(d), _p(m))
+    if rc:
+        raise PoppyError(f"poppy_perspective_from4: {rc}")
+    return m
 
 
 def radial_gradient(w, h):
@@ -293,6 +318,27 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_hamming_match(self.h, _p(q), len(q), _p(t), len(t), _p(out), C.byref(n)), "hamming_match")
         return out[:n.value].copy()
+
+    def warp_affine(self, img, M):
+        a = np.ascontiguousarray(img, np.uint8)
+        h, w = a.shape[:2]
+        m = np.ascontiguousarray(M, np.float64).reshape(6)
+        out = np.zeros_like(a)
+        self._chk(lib().poppy_hip_warp_affine(self.h, _p(a), w * 3, w, h, _p(m), _p(out), w * 3), "warp_affine")
+        return out
+
+    def align(self, which, img, p1, p2):
+        """which: 'retranslate' | 'reprocrustes' | 'rerotate' | 'auto' -> (image, points2, distance)."""
+        im = np.ascontiguousarray(img, np.uint8).copy()
+        a = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(p2, np.float32).reshape(-1, 2).copy()
+        h, w = im.shape[:2]
+        d = C.c_double(0)
+        if which == "auto":
+            self._chk(lib().poppy_hip_auto_align(self.h, _p(im), w * 3, w, h, _p(a), _p(b), len(a), C.byref(d)), "auto_align")
+        else:
+            code = {"retranslate": 0, "reprocrustes": 1, "rerotate": 2}[which]
+            self._chk(lib().poppy_hip_align_step(self.h, code, _p(im), w * 3, w, h, _p(a), _p(b), len(a), C.byref(d)), "align_step")
+        return im, b, d.value
 
     def hamming_knn2(self, query, train):
         q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)

@@ -24,6 +24,7 @@
 #include "kernels_prefilter.h"
 #include "orb_detect.h"
 #include "point_match.h"
+#include "auto_align.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -94,6 +95,8 @@ struct poppy_hip_ctx {
     hipStream_t aux_stream = nullptr;
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
+    AutoAligner aligner;
+    uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
     double last_detail[2] = {0, 0};
@@ -123,7 +126,7 @@ static int fail(poppy_hip_ctx* c, int code, const char* msg) { c->err = msg; ret
 extern "C" {
 
 void poppy_settings_default(poppy_settings* s) {
-    s->number_of_frames = 60; s->match_tolerance = 1.0; s->max_keypoints = 300; s->pyramid_levels = 64; s->enable_radial_mask = 0;
+    s->number_of_frames = 60; s->match_tolerance = 1.0; s->max_keypoints = 300; s->pyramid_levels = 64; s->enable_radial_mask = 0; s->enable_auto_align = 0;
 }
 const char* poppy_hip_create_error(void) { return g_create_error.c_str(); }
 const char* poppy_hip_last_error(const poppy_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
@@ -196,6 +199,8 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     (void)hipStreamSynchronize(c->copy_stream);
+    if (c->d_align) (void)hipFree(c->d_align);
+    c->aligner.release();
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -811,6 +816,72 @@ int poppy_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, flo
     return POPPY_OK;
 }
 
+// ---- auto-align ------------------------------------------------------------------------------------------------------
+static int align_stage(poppy_hip_ctx* c, const uint8_t* img, size_t stride, int W, int H) {
+    const size_t bytes = (size_t)W * H * 3;
+    if (c->d_align_bytes < bytes) {
+        if (c->d_align) (void)hipFree(c->d_align);
+        c->d_align = nullptr; c->d_align_bytes = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_align, bytes));
+        c->d_align_bytes = bytes;
+    }
+    HIPCHK(c, hipMemcpy2DAsync(c->d_align, (size_t)W * 3, img, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    return POPPY_OK;
+}
+
+int poppy_hip_warp_affine(poppy_hip_ctx* c, const uint8_t* src, size_t ss, int W, int H, const double* M, uint8_t* dst, size_t ds) {
+    if (!c) return POPPY_E_ARG;
+    if (!src || !dst || !M || W <= 0 || H <= 0 || ss < (size_t)W * 3 || ds < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad warp_affine arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = align_stage(c, src, ss, W, H); if (rc) return rc;
+    uint8_t* d_out = nullptr; int* d_tab = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_out, (size_t)W * H * 3));
+    hipError_t e = hipMalloc((void**)&d_tab, (size_t)2 * (W + H) * sizeof(int));
+    bool ok = e == hipSuccess && warp_affine_device(c->d_align, d_out, W, H, M, d_tab, c->stream);
+    if (ok) ok = hipMemcpy2DAsync(dst, ds, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                 hipStreamSynchronize(c->stream) == hipSuccess;
+    (void)hipFree(d_out); if (d_tab) (void)hipFree(d_tab);
+    return ok ? POPPY_OK : fail(c, POPPY_E_DEVICE, "warp_affine failed");
+}
+
+static int align_host_entry(poppy_hip_ctx* c, int which, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
+    if (!c) return POPPY_E_ARG;
+    if (!img || !p1 || !p2 || n < 4 || W <= 0 || H <= 0 || stride < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad align arguments (at least 4 point pairs)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = align_stage(c, img, stride, W, H); if (rc) return rc;
+    std::vector<P2f> a(n), b(n);
+    memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8);
+    rc = which < 0 ? c->aligner.run(c->d_align, W, H, a, b, c->stream, dist) : c->aligner.step(which, c->d_align, W, H, a, b, c->stream, dist);
+    if (rc) return fail(c, rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE, c->aligner.err.c_str());
+    memcpy(p2, b.data(), (size_t)n * 8);
+    HIPCHK(c, hipMemcpy2DAsync(img, stride, c->d_align, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+int poppy_hip_auto_align(poppy_hip_ctx* c, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
+    return align_host_entry(c, -1, img, stride, W, H, p1, p2, n, dist);
+}
+int poppy_hip_align_step(poppy_hip_ctx* c, int which, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
+    if (which < 0 || which > 2) return c ? fail(c, POPPY_E_ARG, "align_step: which must be 0, 1 or 2") : POPPY_E_ARG;
+    return align_host_entry(c, which, img, stride, W, H, p1, p2, n, dist);
+}
+int poppy_procrustes(const float* x, const float* y, int n, float* rot4, float* se2, float* yprime) {
+    if (!x || !y || n < 1) return POPPY_E_ARG;
+    std::vector<P2f> a(n), b(n);
+    memcpy(a.data(), x, (size_t)n * 8); memcpy(b.data(), y, (size_t)n * 8);
+    ProcrustesFit f;
+    procrustes_fit(a, b, f);
+    if (rot4) memcpy(rot4, f.rotation, 16);
+    if (se2) { se2[0] = f.scale; se2[1] = f.error; }
+    if (yprime) memcpy(yprime, f.yprime.data(), (size_t)n * 8);
+    return POPPY_OK;
+}
+int poppy_perspective_from4(const float* s4, const float* d4, double* m) {
+    if (!s4 || !d4 || !m) return POPPY_E_ARG;
+    perspective_from_4((const P2f*)s4, (const P2f*)d4, m);
+    return POPPY_OK;
+}
+
 int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
     if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
     std::vector<P2f> a(n), b(n);
@@ -874,6 +945,8 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     // one stream each, so that the medians of one image run beside the Gabor bank of the other.
     std::string errs[2];
     int rcs[2] = {POPPY_OK, POPPY_OK};
+    // with auto-align, gabor2 belongs to the ALIGNED second image (src/poppy.hpp:116-122 runs after Matcher::find): computed further down
+    const bool align_first = c->cfg.enable_auto_align != 0 && ratio < 0.f;
     auto chain_of = [&](int i) {
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
         ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
@@ -884,7 +957,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         hipError_t e = hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && i == 1) {
+        if (e == hipSuccess && i == 1 && !align_first) {
             const float* gab = fg.gabor_field(c->c2, W, H, st);
             if (!gab) { errs[i] = "gabor_field: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
             e = hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, st);
@@ -953,6 +1026,16 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
         std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
         for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
+        if (align_first) {                                                  // Matcher::find, src/matcher.cpp:29-32
+            if (n < 4) return fail(c, POPPY_E_UNSUPPORTED, "auto-align needs at least 4 keypoint pairs (the reference reads 4 unconditionally)");
+            std::vector<P2f> a(n), b(n);
+            memcpy(a.data(), p1.data(), n * 8); memcpy(b.data(), p2.data(), n * 8);
+            if (c->aligner.run(c->c2, W, H, a, b, c->stream, nullptr)) return fail(c, POPPY_E_DEVICE, c->aligner.err.c_str());
+            memcpy(p2.data(), b.data(), n * 8);
+            const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->stream);
+            if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return POPPY_E_DEVICE; }
+            HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
+        }
         int m = 0;
         rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
         if (rc) return fail(c, rc, "poppy_match_points failed");

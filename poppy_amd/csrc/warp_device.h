@@ -24,15 +24,13 @@ __device__ __forceinline__ void bilinear_weights(int fx, int fy, int& w00, int& 
     if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
 }
 
-__device__ __forceinline__ void sample3(const uint8_t* __restrict__ src, int W, int H, float mx, float my, uint8_t* out) {
-    int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
+// remapBilinear on one pixel: (ix, iy) = integer part already saturated to short, (fx, fy) = 5-bit fractions
+__device__ __forceinline__ void sample3_fixed(const uint8_t* __restrict__ src, int W, int H, int ix, int iy, int fx, int fy, uint8_t* out) {
     int w00, w01, w10, w11;
-    bilinear_weights(sx & 31, sy & 31, w00, w01, w10, w11);
-    int ix = sx >> 5, iy = sy >> 5;
-    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
+    bilinear_weights(fx, fy, w00, w01, w10, w11);
     bool x0 = (unsigned)ix < (unsigned)W, x1 = (unsigned)(ix + 1) < (unsigned)W;
     bool y0 = (unsigned)iy < (unsigned)H, y1 = (unsigned)(iy + 1) < (unsigned)H;
-    const uint8_t* p00 = src + ((size_t)iy * W + ix) * 3;
+    const uint8_t* p00 = src + ((long long)iy * W + ix) * 3;
     const uint8_t* p10 = p00 + (size_t)W * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -41,6 +39,13 @@ __device__ __forceinline__ void sample3(const uint8_t* __restrict__ src, int W, 
         int acc = __mul24(v00, w00) + __mul24(v01, w01) + __mul24(v10, w10) + __mul24(v11, w11);
         out[k] = sat_u8((acc + (1 << 14)) >> 15);
     }
+}
+
+__device__ __forceinline__ void sample3(const uint8_t* __restrict__ src, int W, int H, float mx, float my, uint8_t* out) {
+    int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
+    int ix = sx >> 5, iy = sy >> 5;
+    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
+    sample3_fixed(src, W, H, ix, iy, sx & 31, sy & 31, out);
 }
 
 __device__ __forceinline__ void map_point(const float* __restrict__ h, int x, int y, float& mx, float& my) {

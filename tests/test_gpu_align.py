@@ -1,0 +1,74 @@
+"""GPU parity of the auto-align through the C ABI: cv::warpAffine kernel, the three Transformer steps,
+Matcher::autoAlign, and poppy_hip_pair_begin with enable_auto_align — against the reference fixtures (tests/golden/l_*,
+a_*_align) and the oracle.  Everything is compared bit for bit."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from poppy_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+CASES = ["l_317x211", "l_320x240", "l_640x480"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_warp_affine_vs_opencv(ctx, case):
+    inp = G.make_inputs.align_inputs(case)
+    img = inp["img2"]
+    G.check(case, "wa_t1", ctx.warp_affine(img, [1, 0, 5, 0, 1, -3]))
+    G.check(case, "wa_t2", ctx.warp_affine(img, [1, 0, -40, 0, 1, 17]))
+    G.check(case, "wa_r1", ctx.warp_affine(img, G.full(case, "rm1")))
+    G.check(case, "wa_r2", ctx.warp_affine(img, G.full(case, "rm2")))
+    G.check(case, "wa_a1", ctx.warp_affine(img, inp["aff"]))
+
+
+def test_warp_affine_odd_maps_vs_oracle(ctx):
+    """Singular, mirrored, far-away and strongly scaled maps, ragged size."""
+    img = synth.textured_bgr(203, 97, 8)
+    for M in ([0, 0, 10, 0, 0, 20], [-1, 0, 202, 0, 1, 0], [1, 0, 1e7, 0, 1, -1e7], [3.7, 0.2, -100, -0.3, 0.25, 40],
+              [1, 0, 0.5, 0, 1, 0.25], [1e-9, 0, 0, 0, 1e-9, 0]):
+        assert np.array_equal(ctx.warp_affine(img, M), O.warp_affine(img, M)), M
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("step,pf", [("retranslate", "rt"), ("reprocrustes", "rp"), ("rerotate", "rr")])
+def test_transformer_steps_vs_reference(ctx, case, step, pf):
+    inp = G.make_inputs.align_inputs(case)
+    img, p2, d = ctx.align(step, inp["img2"], inp["pts1"], inp["pts2"])
+    G.check(case, pf + "_pts2", p2)
+    assert d == G.full(case, pf + "_dist")[0]
+    G.check(case, pf + "_img", img)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_auto_align_vs_reference(ctx, case):
+    inp = G.make_inputs.align_inputs(case)
+    img, p2, d = ctx.align("auto", inp["img2"], inp["pts1"], inp["pts2"])
+    G.check(case, "aa_pts2", p2)
+    assert d == G.full(case, "aa_dist")[0]
+    G.check(case, "aa_img", img)
+
+
+@pytest.mark.parametrize("case", ["a_256x256_align", "a_384x288_align"])
+def test_pair_begin_with_auto_align_reproduces_poppy_morph(case):
+    """poppy::morph with Settings::enable_auto_align from the raw pair: prepared points and every frame, bit for bit."""
+    inp = G.astage_inputs(case)
+    c = capi.Context(0, number_of_frames=int(inp["cfg"][0]), enable_auto_align=1)
+    nf, _ = c.pair_begin(inp["img1"], inp["img2"])
+    assert nf == int(G.full(case, "detail")[3])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
+    frames = c.morph_frames(-1.0)
+    assert len(frames) == int(inp["cfg"][0])
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
+    c.close()

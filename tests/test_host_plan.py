@@ -129,3 +129,16 @@ def test_ratio_symmetry_host_vs_reference_lists():
     k12 = np.array([[0, 5, -1, -1], [1, 0, 0, 0]], np.int32); k21 = np.array([[0, 5, 1, 9], [1, 0, 0, 0]], np.int32)
     assert capi.ratio_symmetry(k12, k21, 0.7).tolist() == [[1, 1, 0]]
     assert len(capi.ratio_symmetry(k12[:0], k21, 0.7)) == 0
+
+
+@pytest.mark.parametrize("case", ["l_317x211", "l_320x240", "l_640x480"])
+def test_procrustes_and_perspective_fit_host(case):
+    """Host math of the auto-align (poppy_amd/csrc/auto_align.cpp) against the reference's Procrustes and OpenCV's
+    getPerspectiveTransform (fixtures l_*; no GPU)."""
+    inp = G.make_inputs.align_inputs(case)
+    r = capi.procrustes(inp["pts1"], inp["pts2"])
+    G.check(case, "pc_rotation", r["rotation"])
+    sc = G.full(case, "pc_scalars")
+    assert np.float32(sc[0]) == r["scale"] and np.float32(sc[1]) == r["error"]
+    G.check(case, "pc_yprime", r["yprime"])
+    G.check(case, "prim_persp", capi.perspective_from4(inp["pts1"][:4], inp["pts2"][:4]))
