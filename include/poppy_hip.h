@@ -189,6 +189,10 @@ int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1
 int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                                      int width, int height, float ratio);
 
+/* The second image as the resident pair holds it — after poppy_hip_pair_begin with enable_auto_align this is the ALIGNED
+ * corrected2 that poppy::morph hands back to its caller (src/poppy.hpp:46-47; src/poppy.cpp:326 chains it into the next pair). */
+int poppy_hip_pair_corrected2(poppy_hip_ctx* ctx, uint8_t* dst, size_t dst_stride);
+
 int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail2);
 /* Pieces of the chain, host in / host out, for tests and for callers that cache intermediates:
  * poppy_hip_orb_input: goodFeatures (w*h) -> g = the ORB input image; optional us (grey of the unsharp-masked image), gb (Gabor

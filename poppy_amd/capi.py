@@ -27,7 +27,7 @@ SYMBOLS = [
     "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_hamming_knn2", "poppy_ratio_symmetry",
     "poppy_hip_pair_begin_descriptors", "poppy_hip_warp_affine", "poppy_hip_auto_align", "poppy_hip_align_step",
-    "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
+    "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -74,6 +74,7 @@ def lib():
         L.poppy_hip_auto_align.argtypes = [vp, vp, C.c_size_t, i, i, vp, vp, i, vp]
         L.poppy_hip_align_step.argtypes = [vp, i, vp, C.c_size_t, i, i, vp, vp, i, vp]
         L.poppy_procrustes.argtypes = [vp, vp, i, vp, vp, vp]
+        L.poppy_hip_pair_corrected2.argtypes = [vp, vp, C.c_size_t]
         L.poppy_perspective_from4.argtypes = [vp, vp, vp]
         L.poppy_ratio_symmetry.argtypes = [vp, i, vp, i, C.c_float, vp, vp]
         L.poppy_hip_pair_begin_descriptors.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i, i, C.c_float]
@@ -318,6 +319,11 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_hamming_match(self.h, _p(q), len(q), _p(t), len(t), _p(out), C.byref(n)), "hamming_match")
         return out[:n.value].copy()
+
+    def pair_corrected2(self, w, h):
+        out = np.zeros((h, w, 3), np.uint8)
+        self._chk(lib().poppy_hip_pair_corrected2(self.h, _p(out), w * 3), "pair_corrected2")
+        return out
 
     def warp_affine(self, img, M):
         a = np.ascontiguousarray(img, np.uint8)

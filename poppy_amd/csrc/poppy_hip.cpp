@@ -1054,6 +1054,16 @@ int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* c, const uint8_t* bgr1, size
     return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, ratio);
 }
 
+int poppy_hip_pair_corrected2(poppy_hip_ctx* c, uint8_t* dst, size_t ds) {
+    if (!c || !dst) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no resident pair");
+    if (ds < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "stride too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(dst, ds, c->c2, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return POPPY_OK;
+}
+
 // intermediates of the last poppy_hip_pair_begin, for the tolerance tests: nfeatures, the two dft_detail2 values
 int poppy_hip_pair_begin_info(poppy_hip_ctx* c, int* nfeatures, double* detail2) {
     if (!c) return POPPY_E_ARG;

@@ -67,6 +67,8 @@ def test_pair_begin_with_auto_align_reproduces_poppy_morph(case):
     p1, p2 = c.pair_points()
     G.check(case, "prepared1", p1)
     G.check(case, "prepared2", p2)
+    hh, ww = inp["img2"].shape[:2]
+    G.check(case, "corrected2", c.pair_corrected2(ww, hh))          # what poppy::morph returns to its caller
     frames = c.morph_frames(-1.0)
     assert len(frames) == int(inp["cfg"][0])
     for j, f in enumerate(frames):
