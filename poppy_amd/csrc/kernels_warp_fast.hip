@@ -116,7 +116,7 @@ constexpr int kSlots = 64;
 typedef unsigned u3v __attribute__((ext_vector_type(3)));
 
 template <int kTileW>
-__global__ void __launch_bounds__(256) k_warp_tile(const int4* __restrict__ triMap4, const float4* __restrict__ rec,
+__global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, const float4* __restrict__ rec,
                                                    const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                    uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, int n_rec,
                                                    int tiles_x, WarpExtras ex) {
@@ -141,7 +141,6 @@ __global__ void __launch_bounds__(256) k_warp_tile(const int4* __restrict__ triM
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);
-        if (ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);
         if (ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
         id[0] = (int)ids.x; id[1] = (int)ids.y; id[2] = (int)ids.z; id[3] = (int)ids.w;
         s_tag[id[0] & (kSlots - 1)] = id[0];
@@ -232,14 +231,19 @@ __global__ void __launch_bounds__(256) k_warp_tile(const int4* __restrict__ triM
     uint32_t edges = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
-    if (__builtin_amdgcn_ballot_w64(edges != 0) == 0) return;
-    for (int e = 0; e < 8; ++e) {
-        if (!((edges >> e) & 1u)) continue;
-        const int k = e & 3, im = e >> 2;
-        const uint32_t v = slow_pixel((const float*)(rec + (uint32_t)id[k] * 5u), im, im ? c2 : c1, W, H, x0 + k, y);
-        uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y * W + x0 + k) * 3;
-        dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+    if (__builtin_amdgcn_ballot_w64(edges != 0) != 0 && edges != 0) {
+        const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);      // not kept in registers for this rare path
+        for (int e = 0; e < 8; ++e) {
+            if (!((edges >> e) & 1u)) continue;
+            const int k = e & 3, im = e >> 2;
+            const uint32_t idk = k == 0 ? ids.x : k == 1 ? ids.y : k == 2 ? ids.z : ids.w;
+            const uint32_t v = slow_pixel((const float*)(rec + idk * 5u), im, im ? c2 : c1, W, H, x0 + k, y);
+            uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y * W + x0 + k) * 3;
+            dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+        }
     }
+    // this kernel is the id map's only reader: leave it cleared for the next frame's raster (last, so that the border path can still read it)
+    if (ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);
 }
 
 bool warp_fast_geometry(int w, int h) {
@@ -252,7 +256,7 @@ void launch_warp_fast(int32_t* triMap, const float* records, int n_records, cons
     static const int forced = getenv("POPPY_TILE_W") ? atoi(getenv("POPPY_TILE_W")) : 0;
     const int tw = forced ? forced : ((long long)w * h >= 4000000 ? 128 : 64);
 #define LW(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
-    hipExtLaunchKernelGGL(k_warp_tile<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const int4*)triMap, \
+    hipExtLaunchKernelGGL(k_warp_tile<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (int4*)triMap, \
                           (const float4*)records, c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, n_records, tiles_x, ex); }
     switch (tw) { case 32: LW(32); break; case 128: LW(128); break; case 256: LW(256); break; default: LW(64); }
 #undef LW
