@@ -229,7 +229,8 @@ void AutoAligner::release() {
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_last) (void)hipFree(d_last);
     if (d_tables) (void)hipFree(d_tables);
-    d_tmp = d_last = nullptr; d_tables = nullptr; W = H = 0;
+    if (d_score) (void)hipFree(d_score);
+    d_tmp = d_last = nullptr; d_tables = nullptr; d_score = nullptr; d_score_bytes = 0; W = H = 0;
 }
 
 int AutoAligner::ensure(int w, int h) {
@@ -248,40 +249,124 @@ bool AutoAligner::warp_in_place(uint8_t* d_img, const double M[6], hipStream_t s
     return true;
 }
 
-double AutoAligner::retranslate(uint8_t* d_img, const std::vector<P2f>& p1, std::vector<P2f>& p2, hipStream_t s) {
-    auto moved = [&](float dx, float dy) {
-        std::vector<P2f> o(p2.size());
-        for (size_t i = 0; i < p2.size(); ++i) o[i] = P2f{p2[i].x + dx, p2[i].y + dy};
-        return morph_distance_ref(p1, o, W, H);
+// morph_distance(p1, set_k) for n_cand candidate sets
+bool AutoAligner::score_sets(const std::vector<P2f>& p1, const std::vector<P2f>& sets, int n_cand, hipStream_t s, std::vector<double>& out) {
+    const int n = (int)p1.size();
+    const size_t pts = (size_t)n * 8, all = pts * n_cand, res = (size_t)n_cand * 4;
+    const size_t need = pts + all + 3 * res + 64;
+    if (need > d_score_bytes) {
+        if (d_score) (void)hipFree(d_score);
+        d_score = nullptr; d_score_bytes = 0;
+        if (hipMalloc((void**)&d_score, need) != hipSuccess) { failed = true; err = "auto_align: hipMalloc failed"; return false; }
+        d_score_bytes = need;
+    }
+    float* d_p1 = (float*)d_score;
+    float* d_sets = (float*)(d_score + pts);
+    float* d_total = (float*)(d_score + pts + all);
+    float* d_inner = d_total + n_cand;
+    int* d_np = (int*)(d_inner + n_cand);
+    std::vector<float> total(n_cand), inner(n_cand);
+    std::vector<int> npairs(n_cand);
+    bool ok = hipMemcpyAsync(d_p1, p1.data(), pts, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_sets, sets.data(), all, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        launch_candidate_scores(d_p1, d_sets, n, n_cand, d_total, d_np, d_inner, s);
+        ok = hipMemcpyAsync(total.data(), d_total, res, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(inner.data(), d_inner, res, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(npairs.data(), d_np, res, hipMemcpyDeviceToHost, s) == hipSuccess;
+    }
+    // host, meanwhile: hull areas of the candidates (threads) and the candidate-independent parts
+    const double area1 = hull_area_of(p1);
+    const float inner1 = inner_offset_sum(p1, p1);
+    std::vector<double> area2(n_cand);
+    std::atomic<int> next{0};
+    const int n_threads = std::max(1, std::min(std::min(32, n_cand), (int)std::thread::hardware_concurrency()));
+    auto worker = [&]() {
+        std::vector<P2f> t(n);
+        for (int k; (k = next.fetch_add(1)) < n_cand;) {
+            memcpy(t.data(), sets.data() + (size_t)k * n, pts);
+            area2[k] = hull_area_of(t);
+        }
     };
-    double current = morph_distance_ref(p1, p2, W, H);
-    const double left = moved(-1, 0), right = moved(1, 0), top = moved(0, -1), bottom = moved(0, 1);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+    if (!ok || hipStreamSynchronize(s) != hipSuccess) { failed = true; err = "auto_align: candidate scoring failed"; return false; }
+    out.resize(n_cand);
+    for (int k = 0; k < n_cand; ++k)
+        out[k] = morph_distance_combine(total[k], (size_t)npairs[k], inner1, inner[k], p1.size(), p1.size(), area1, area2[k], W, H);
+    return true;
+}
+
+double AutoAligner::retranslate(uint8_t* d_img, const std::vector<P2f>& p1, std::vector<P2f>& p2, hipStream_t s) {
+    const int n = (int)p2.size();
+    // One scoring call covers everything the search can ask for first: the point set as it is, its four unit shifts, and the first
+    // kAhead steps of a walk in each of the eight directions (a step adds the offset to the previous step's float coordinates, as
+    // the reference's loop does).  The reference's decisions are then replayed on those distances; a walk longer than kAhead
+    // steps continues with further calls.
+    constexpr int kAhead = 12, kDirs = 8;
+    static const int dir_x[kDirs] = {-1, 1, 0, 0, -1, -1, 1, 1}, dir_y[kDirs] = {0, 0, -1, 1, -1, 1, -1, 1};
+    std::vector<P2f> sets;
+    sets.reserve((size_t)(5 + kDirs * kAhead) * n);
+    auto append_shifted = [&](float dx, float dy) { for (const P2f& p : p2) sets.push_back(P2f{p.x + dx, p.y + dy}); };
+    append_shifted(0, 0); append_shifted(-1, 0); append_shifted(1, 0); append_shifted(0, -1); append_shifted(0, 1);
+    std::vector<std::vector<P2f>> walk_end(kDirs);
+    for (int k = 0; k < kDirs; ++k) {
+        std::vector<P2f> t = p2;
+        for (int b = 0; b < kAhead; ++b) {
+            for (P2f& p : t) { if (dir_x[k]) p.x += (long)dir_x[k]; if (dir_y[k]) p.y += (long)dir_y[k]; }
+            sets.insert(sets.end(), t.begin(), t.end());
+        }
+        walk_end[k] = t;
+    }
+    std::vector<double> d;
+    if (!score_sets(p1, sets, 5 + kDirs * kAhead, s, d)) return 0;
+    double current = d[0];
     long xdir = 0, ydir = 0;
-    if (left < current) xdir = -1; else if (right < current) xdir = +1;
-    if (top < current) ydir = -1; else if (bottom < current) ydir = +1;
+    if (d[1] < current) xdir = -1; else if (d[2] < current) xdir = +1;
+    if (d[3] < current) ydir = -1; else if (d[4] < current) ydir = +1;
     long xsteps = 1, ysteps = 1;
     auto walk = [&](long dx, long dy, long* nx, long* ny) {          // keep stepping while the distance does not grow
+        int k = 0;
+        while (dir_x[k] != dx || dir_y[k] != dy) ++k;
         double last = current;
-        std::vector<P2f> t = p2;
-        for (;;) {
-            for (P2f& p : t) { if (dx) p.x += dx; if (dy) p.y += dy; }
-            const double d = morph_distance_ref(p1, t, W, H);
-            if (d > last) break;
-            current = last = d;
+        for (int b = 0; b < kAhead; ++b) {
+            const double v = d[5 + k * kAhead + b];
+            if (v > last) return;
+            current = last = v;
             if (nx) ++*nx;
             if (ny) ++*ny;
+        }
+        std::vector<P2f> t = walk_end[k], more;
+        std::vector<double> dm;
+        for (;;) {
+            more.clear();
+            for (int b = 0; b < kAhead; ++b) {
+                for (P2f& p : t) { if (dx) p.x += dx; if (dy) p.y += dy; }
+                more.insert(more.end(), t.begin(), t.end());
+            }
+            if (!score_sets(p1, more, kAhead, s, dm)) return;
+            for (int b = 0; b < kAhead; ++b) {
+                if (dm[b] > last) return;
+                current = last = dm[b];
+                if (nx) ++*nx;
+                if (ny) ++*ny;
+            }
         }
     };
     if (xdir != 0 && ydir != 0) walk(xdir, ydir, &xsteps, &ysteps);
     else {
         if (xdir != 0) walk(xdir, 0, &xsteps, nullptr);
-        if (ydir != 0) walk(0, ydir, nullptr, &ysteps);
+        if (ydir != 0 && !failed) walk(0, ydir, nullptr, &ysteps);
     }
+    if (failed) return 0;
     const float tx = (float)(xdir * xsteps), ty = (float)(ydir * ysteps);
     const double M[6] = {1, 0, (double)tx, 0, 1, (double)ty};
     if (!warp_in_place(d_img, M, s)) return 0;
     for (P2f& p : p2) { p.x += tx; p.y += ty; }
-    return morph_distance_ref(p1, p2, W, H);
+    if (!score_sets(p1, p2, 1, s, d)) return 0;
+    return d[0];
 }
 
 static void rotate_about(std::vector<P2f>& pts, P2f c, double deg) {
@@ -297,25 +382,30 @@ double AutoAligner::rerotate(uint8_t* d_img, const std::vector<P2f>& p1, std::ve
     P2f centre{0, 0};
     for (const P2f& p : p2) { centre.x += p.x; centre.y += p.y; }
     centre.x /= p2.size(); centre.y /= p2.size();
-    // 1080 candidate angles, each scored by the sequential morph distance: independent, so host threads take them side by side
     constexpr int kAngles = 1080;
-    std::vector<double> score(kAngles);
-    std::atomic<int> next{0};
-    const int n_threads = std::max(1, std::min(64, (int)std::thread::hardware_concurrency()));
-    auto worker = [&]() {
-        for (int i; (i = next.fetch_add(1)) < kAngles;) {
-            std::vector<P2f> t = p2;
-            rotate_about(t, centre, i / 3.0);
-            score[i] = morph_distance_ref(p1, t, W, H);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-    worker();
-    for (std::thread& t : pool) t.join();
+    const int n = (int)p2.size();
+    std::vector<P2f> sets((size_t)kAngles * n);                 // the rotations use the host's libm, on threads
+    {
+        std::atomic<int> next{0};
+        const int n_threads = std::max(1, std::min(32, (int)std::thread::hardware_concurrency()));
+        auto worker = [&]() {
+            std::vector<P2f> t;
+            for (int i; (i = next.fetch_add(1)) < kAngles;) {
+                t = p2;
+                rotate_about(t, centre, i / 3.0);
+                memcpy(sets.data() + (size_t)i * n, t.data(), (size_t)n * 8);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (std::thread& t : pool) t.join();
+    }
+    std::vector<double> d;
+    if (!score_sets(p1, sets, kAngles, s, d)) return 0;
     double lowest = std::numeric_limits<double>::max(), angle = 0;
     for (int i = 0; i < kAngles; ++i)
-        if (score[i] < lowest) { lowest = score[i]; angle = i / 3.0; }
+        if (d[i] < lowest) { lowest = d[i]; angle = i / 3.0; }
     double M[6];
     rotation_matrix_2d(centre.x, centre.y, -angle, 1.0, M);
     if (!warp_in_place(d_img, M, s)) return 0;
@@ -330,11 +420,13 @@ double AutoAligner::reprocrustes(uint8_t* d_img, const std::vector<P2f>& p1, std
     perspective_from_4(p2.data(), fit.yprime.data(), M);          // the reference fits the map to the first four pairs only
     perspective_points(p2, M);
     if (!warp_in_place(d_img, M, s)) return 0;                     // its first two rows, as an affine map
-    return morph_distance_ref(p1, p2, W, H);
+    std::vector<double> d;
+    if (!score_sets(p1, p2, 1, s, d)) return 0;
+    return d[0];
 }
 
 int AutoAligner::step(int which, uint8_t* d_img, int w, int h, const std::vector<P2f>& p1, std::vector<P2f>& p2, hipStream_t s, double* dist) {
-    if (p1.size() != p2.size() || p1.size() < 4) { err = "auto_align: needs at least 4 point pairs"; return -1; }
+    if (p1.size() != p2.size() || p1.size() < 4 || p1.size() > (size_t)kAlignMaxPoints) { err = "auto_align: needs 4 .. 4096 point pairs"; return -1; }
     if (int rc = ensure(w, h)) return rc;
     failed = false;
     const double d = which == 0 ? retranslate(d_img, p1, p2, s) : which == 1 ? reprocrustes(d_img, p1, p2, s) : rerotate(d_img, p1, p2, s);
@@ -344,7 +436,7 @@ int AutoAligner::step(int which, uint8_t* d_img, int w, int h, const std::vector
 }
 
 int AutoAligner::run(uint8_t* d_img, int w, int h, const std::vector<P2f>& p1, std::vector<P2f>& p2, hipStream_t s, double* final_distance) {
-    if (p1.size() != p2.size() || p1.size() < 4) { err = "auto_align: needs at least 4 point pairs"; return -1; }
+    if (p1.size() != p2.size() || p1.size() < 4 || p1.size() > (size_t)kAlignMaxPoints) { err = "auto_align: needs 4 .. 4096 point pairs"; return -1; }
     if (int rc = ensure(w, h)) return rc;
     failed = false;
     const size_t bytes = (size_t)w * h * 3;

@@ -221,22 +221,32 @@ double hull_area(const std::vector<P2f>& pts) {
 
 }  // namespace
 
-double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h) {
+double hull_area_of(const std::vector<P2f>& pts) { return hull_area(pts); }
+
+float inner_offset_sum(const std::vector<P2f>& a, const std::vector<P2f>& b) {
+    float acc = 0;
+    for (size_t i = 0; i < a.size(); ++i)
+        for (size_t j = 0; j < a.size(); ++j) { const float vx = a[i].x - b[j].x, vy = a[i].y - b[j].y; acc += vx + vy; }
+    return acc;
+}
+
+double morph_distance_combine(float total, size_t n_pairs, float inner1_sum, float inner2_sum, size_t n1, size_t n2,
+                              double area1, double area2, int w, int h) {
     const long double width = w, height = h;
+    const float in1 = (float)((inner1_sum / (n1 * n1)) / (width + height));
+    const float in2 = (float)((inner2_sum / (n2 * n2)) / (width + height));
+    const long double r = ((total / (n_pairs)) / hypotl(width, height)) + fabs(in1 - in2) + (fabs(area1 - area2) / (width * height)) / 3.0;
+    return (double)r;
+}
+
+double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h) {
     std::vector<PointPair> pairs;
     greedy_pairs(p1, p2, pairs);
-    const double area1 = hull_area(p1), area2 = hull_area(p2);
-    float in1 = 0, in2 = 0;
-    for (size_t i = 0; i < p1.size(); ++i)
-        for (size_t j = 0; j < p1.size(); ++j) { const float vx = p1[i].x - p1[j].x, vy = p1[i].y - p1[j].y; in1 += vx + vy; }
-    in1 = (float)((in1 / (p1.size() * p1.size())) / (width + height));
-    for (size_t i = 0; i < p2.size(); ++i)
-        for (size_t j = 0; j < p2.size(); ++j) { const float vx = p2[i].x - p1[j].x, vy = p2[i].y - p1[j].y; in2 += vx + vy; }   // second set against the FIRST, as in the reference
-    in2 = (float)((in2 / (p2.size() * p2.size())) / (width + height));
     float total = 0;
     for (const PointPair& e : pairs) total += hypotf(e.b.x - e.a.x, e.b.y - e.a.y);
-    const long double r = ((total / (pairs.size())) / hypotl(width, height)) + fabs(in1 - in2) + (fabs(area1 - area2) / (width * height)) / 3.0;
-    return (double)r;
+    // the second inner sum runs the second set against the FIRST, as in the reference
+    return morph_distance_combine(total, pairs.size(), inner_offset_sum(p1, p1), inner_offset_sum(p2, p1), p1.size(), p2.size(),
+                                  hull_area(p1), hull_area(p2), w, h);
 }
 
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist) {

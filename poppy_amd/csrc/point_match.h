@@ -15,6 +15,11 @@ struct PointPair { double dist; P2f a, b; };
 void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs);   // make_distance_map
 void drop_out_of_image(std::vector<P2f>& p1, std::vector<P2f>& p2, int cols, int rows);                         // filter_invalid_points + resize
 double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h);               // morph_distance
+// morph_distance in parts, for callers that compute the O(N^2) sums elsewhere (auto_align.cpp scores rotation candidates on the GPU)
+double hull_area_of(const std::vector<P2f>& pts);                                 // |contourArea(approxPolyDP(convexHull(pts), 0.001))|
+float inner_offset_sum(const std::vector<P2f>& a, const std::vector<P2f>& b);     // float sum over i, j of (a[i].x - b[j].x) + (a[i].y - b[j].y)
+double morph_distance_combine(float total, size_t n_pairs, float inner1_sum, float inner2_sum, size_t n1, size_t n2,
+                              double area1, double area2, int w, int h);
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist);
 
 void ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, std::vector<int>& out3);      // experiments.hpp:14-144
