@@ -1,0 +1,114 @@
+// context.h — the library's context (one per GPU) and the helpers shared by its translation units:
+//   poppy_hip.cpp   context life cycle, HBM layout, the per-frame path and the resident-pair API
+//   pair_setup.cpp  everything that happens once per pair: pre-ORB chain, ORB, matching, auto-align, margins
+#pragma once
+#include "../../include/poppy_hip.h"
+#include "foreground.h"
+#include "frame_plan.h"
+#include "kernels.h"
+#include "kernels_prefilter.h"
+#include "orb_detect.h"
+#include "point_match.h"
+#include "auto_align.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+
+using namespace poppy_hip;
+
+struct FrameSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;           // end of the frame last rendered here
+    hipEvent_t prepared = nullptr;       // id map and mask of the frame being rendered here are written
+    uint8_t *tr1 = nullptr, *tr2 = nullptr, *out = nullptr;
+    float *pyrL = nullptr, *pyrR = nullptr, *pyrM = nullptr, *pyrB = nullptr;
+    float *tmp = nullptr, *diff = nullptr;      // only for 1-pixel-wide / -high images (separate unsharp passes)
+    float* unsharpF = nullptr;                  // debug copy of the float unsharp result, allocated on demand
+    int32_t* triMap = nullptr;
+    bool map_clean = false;                     // triMap is all zero (the warp kernel clears it behind itself)
+    uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
+    void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
+    hipEvent_t uploaded = nullptr;                  // the device copy is complete
+    hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
+};
+constexpr size_t kBlobHeader = 64;
+
+struct poppy_hip_ctx {
+    int device = 0;
+    poppy_settings cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int W = 0, H = 0;
+    bool pair_ready = false;
+    // resident buffers
+    uint8_t *c1 = nullptr, *c2 = nullptr;
+    float *gabor2 = nullptr, *m2 = nullptr;
+    std::vector<FrameSlot> slots;        // per-frame working sets, used round-robin
+    hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
+    const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
+    hipEvent_t cur1_ready = nullptr;     // producer of cur1 when it is a slot's output, else null
+    hipStream_t cur1_stream = nullptr;   // ... and the stream that producer ran on
+    // Frames that feed on a previous frame all run on `stream`: a cross-stream event on the critical path costs more
+    // than the kernels it would overlap.  Frames that read the loaded image run entirely on their slot's stream
+    // (created on first use: every extra stream competes for the few hardware queues), so in phase mode several
+    // frames are in flight at once.
+    int next_slot = 0, last_slot = -1;
+    std::vector<PyrLevel> levels;        // 0..pyramid_levels
+    PyrLevel* d_levels = nullptr;
+    int first_tail = 1;
+    // points
+    std::vector<P2f> pts1_0, pts1, pts2;
+    // per-frame plan blobs (pinned host + device) live in the frame slots, so the host can plan ahead of the GPU
+    int max_tris = 0;
+    // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
+    //              [RasterTri T][work 2*n i32]
+    size_t blob_bytes = 0;
+    int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
+    hipStream_t copy_stream = nullptr;
+    FramePlan plan;
+    OrbDetector orb, orb_b;
+    ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
+    hipStream_t aux_stream = nullptr;
+    double initial_morph_dist = 0;
+    int last_nfeatures = 0;
+    AutoAligner aligner;
+    uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
+    int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
+    bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
+    double last_detail[2] = {0, 0};
+    // diagnostics
+    bool debug = false;
+    int timing = 0;                      // 0 off, 1 every kernel group (direct launches), 2 the warp kernel only
+    struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
+    std::vector<Mark> marks; size_t marks_used = 0;
+    // staging for host-image entry points
+    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
+    static const int kStageRing = 3;          // pinned frames in flight towards the writer
+    hipStream_t dl_stream = nullptr;
+    hipEvent_t dl_done[kStageRing] = {};
+};
+
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return POPPY_E_DEVICE;                                                                    \
+        }                                                                                             \
+    } while (0)
+
+inline int fail(poppy_hip_ctx* c, int code, const char* msg) { c->err = msg; return code; }
+
+// shared between the translation units (defined in poppy_hip.cpp)
+int alloc_pair(poppy_hip_ctx* c, int W, int H);                                   // resident buffers + frame slots for a W x H pair
+int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H);
+int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n);
+int finish_pair_load(poppy_hip_ctx* c);                                           // m2 from gabor2, chain state reset, pair_ready

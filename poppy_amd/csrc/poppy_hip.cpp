@@ -17,111 +17,10 @@
 //   pyrB              f32x3  ~16P        blended levels; level 0 is lapBlend
 //   out               u8x3   3P          the frame (chained mode feeds it to the next slot as c1)
 // No CPU fallback exists in this library: every entry point either runs the kernels or fails.
-#include "../../include/poppy_hip.h"
-#include "foreground.h"
-#include "frame_plan.h"
-#include "kernels.h"
-#include "kernels_prefilter.h"
-#include "orb_detect.h"
-#include "point_match.h"
-#include "auto_align.h"
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <thread>
-#include <vector>
-
-using namespace poppy_hip;
+#include "context.h"
 
 static std::string g_create_error;
 
-struct FrameSlot {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;           // end of the frame last rendered here
-    hipEvent_t prepared = nullptr;       // id map and mask of the frame being rendered here are written
-    uint8_t *tr1 = nullptr, *tr2 = nullptr, *out = nullptr;
-    float *pyrL = nullptr, *pyrR = nullptr, *pyrM = nullptr, *pyrB = nullptr;
-    float *tmp = nullptr, *diff = nullptr;      // only for 1-pixel-wide / -high images (separate unsharp passes)
-    float* unsharpF = nullptr;                  // debug copy of the float unsharp result, allocated on demand
-    int32_t* triMap = nullptr;
-    bool map_clean = false;                     // triMap is all zero (the warp kernel clears it behind itself)
-    uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
-    void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
-    hipEvent_t uploaded = nullptr;                  // the device copy is complete
-    hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
-};
-constexpr size_t kBlobHeader = 64;
-
-struct poppy_hip_ctx {
-    int device = 0;
-    poppy_settings cfg;
-    hipStream_t stream = nullptr;
-    std::string err;
-
-    int W = 0, H = 0;
-    bool pair_ready = false;
-    // resident buffers
-    uint8_t *c1 = nullptr, *c2 = nullptr;
-    float *gabor2 = nullptr, *m2 = nullptr;
-    std::vector<FrameSlot> slots;        // per-frame working sets, used round-robin
-    hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
-    const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
-    hipEvent_t cur1_ready = nullptr;     // producer of cur1 when it is a slot's output, else null
-    hipStream_t cur1_stream = nullptr;   // ... and the stream that producer ran on
-    // Frames that feed on a previous frame all run on `stream`: a cross-stream event on the critical path costs more
-    // than the kernels it would overlap.  Frames that read the loaded image run entirely on their slot's stream
-    // (created on first use: every extra stream competes for the few hardware queues), so in phase mode several
-    // frames are in flight at once.
-    int next_slot = 0, last_slot = -1;
-    std::vector<PyrLevel> levels;        // 0..pyramid_levels
-    PyrLevel* d_levels = nullptr;
-    int first_tail = 1;
-    // points
-    std::vector<P2f> pts1_0, pts1, pts2;
-    // per-frame plan blobs (pinned host + device) live in the frame slots, so the host can plan ahead of the GPU
-    int max_tris = 0;
-    // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
-    //              [RasterTri T][work 2*n i32]
-    size_t blob_bytes = 0;
-    int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
-    hipStream_t copy_stream = nullptr;
-    FramePlan plan;
-    OrbDetector orb, orb_b;
-    ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
-    hipStream_t aux_stream = nullptr;
-    double initial_morph_dist = 0;
-    int last_nfeatures = 0;
-    AutoAligner aligner;
-    uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
-    int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
-    bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
-    double last_detail[2] = {0, 0};
-    // diagnostics
-    bool debug = false;
-    int timing = 0;                      // 0 off, 1 every kernel group (direct launches), 2 the warp kernel only
-    struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
-    std::vector<Mark> marks; size_t marks_used = 0;
-    // staging for host-image entry points
-    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
-    static const int kStageRing = 3;          // pinned frames in flight towards the writer
-    hipStream_t dl_stream = nullptr;
-    hipEvent_t dl_done[kStageRing] = {};
-};
-
-#define HIPCHK(ctx, call)                                                                             \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess) {                                                                       \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
-            return POPPY_E_DEVICE;                                                                    \
-        }                                                                                             \
-    } while (0)
-
-static int fail(poppy_hip_ctx* c, int code, const char* msg) { c->err = msg; return code; }
 
 extern "C" {
 
@@ -243,7 +142,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     return POPPY_OK;
 }
 
-static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
+int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     if (c->W == W && c->H == H && c->c1) return POPPY_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (FrameSlot& f : c->slots) if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
@@ -289,7 +188,7 @@ static int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     return POPPY_OK;
 }
 
-static int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n) {
+int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n) {
     if (n < 0 || (n > 0 && (!p1 || !p2))) return fail(c, POPPY_E_ARG, "bad point sets");
     c->pts1_0.resize(n); c->pts2.resize(n);
     if (n) { memcpy(c->pts1_0.data(), p1, (size_t)n * 8); memcpy(c->pts2.data(), p2, (size_t)n * 8); }
@@ -297,7 +196,7 @@ static int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n)
     return ensure_ring(c, n);
 }
 
-static int finish_pair_load(poppy_hip_ctx* c) {
+int finish_pair_load(poppy_hip_ctx* c) {
     launch_gray_inv(c->gabor2, c->m2, c->W * c->H, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
@@ -599,7 +498,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     return POPPY_OK;
 }
 
-static int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H) {
+int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H) {
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)W * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
     return POPPY_OK;
 }
@@ -764,389 +663,6 @@ int poppy_plan_frame(int W, int H, const float* p1, const float* p2, int n, doub
     if (inv1 && T) memcpy(inv1, plan.inv1.data(), (size_t)T * 36);
     if (inv2 && T) memcpy(inv2, plan.inv2.data(), (size_t)T * 36);
     if (morphed && n) memcpy(morphed, plan.morphed.data(), (size_t)n * 8);
-    return POPPY_OK;
-}
-
-int poppy_hip_orb_detect(poppy_hip_ctx* c, const uint8_t* gray, size_t stride, int W, int H, int nfeatures, float* kps7, int max_kps, int* n_kps) {
-    if (!c || !gray || !n_kps || W <= 0 || H <= 0 || stride < (size_t)W || nfeatures < 0) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<OrbKeyPoint> kps;
-    int n = c->orb.detect(gray, stride, W, H, nfeatures, c->stream, kps);
-    if (n < 0) { c->err = "orb_detect: " + c->orb.err; return n == -2 ? POPPY_E_DEVICE : POPPY_E_ARG; }
-    *n_kps = n;
-    if (n > max_kps) return fail(c, POPPY_E_ARG, "max_kps too small");
-    for (int i = 0; i < n && kps7; ++i) {
-        float* o = kps7 + (size_t)i * 7;
-        o[0] = kps[i].x; o[1] = kps[i].y; o[2] = kps[i].size; o[3] = kps[i].angle; o[4] = kps[i].response;
-        o[5] = (float)kps[i].octave; o[6] = (float)kps[i].class_id;
-    }
-    return POPPY_OK;
-}
-
-int poppy_hip_orb_describe(poppy_hip_ctx* c, const uint8_t* gray, size_t stride, int W, int H, const float* kps7, int n, uint8_t* desc) {
-    if (!c || !gray || W <= 0 || H <= 0 || stride < (size_t)W || n < 0 || (n && (!kps7 || !desc))) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = c->orb.describe(gray, stride, W, H, kps7, n, c->stream, desc);
-    if (rc < 0) { c->err = "orb_describe: " + c->orb.err; return rc == -2 ? POPPY_E_DEVICE : POPPY_E_ARG; }
-    return POPPY_OK;
-}
-
-int poppy_hip_hamming_match(poppy_hip_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt, int* out3, int* n_matches) {
-    if (!c || nq < 0 || nt < 0 || !n_matches || (nq && !query) || (nt && !train) || (nq && nt && !out3)) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = c->orb.hamming(query, nq, train, nt, c->stream, out3);
-    if (rc < 0) { c->err = "hamming_match: " + c->orb.err; return POPPY_E_DEVICE; }
-    *n_matches = rc;
-    return POPPY_OK;
-}
-
-int poppy_hip_hamming_knn2(poppy_hip_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt, int* out4) {
-    if (!c || nq < 0 || nt < 0 || (nq && !query) || (nt && !train) || (nq && !out4)) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (c->orb.hamming_knn2(query, nq, train, nt, c->stream, out4) < 0) { c->err = "hamming_knn2: " + c->orb.err; return POPPY_E_DEVICE; }
-    return POPPY_OK;
-}
-
-int poppy_ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, int* out3, int* n_out) {
-    if (n1 < 0 || n2 < 0 || !n_out || (n1 && !knn12) || (n2 && !knn21)) return POPPY_E_ARG;
-    std::vector<int> o;
-    ratio_symmetry(knn12, n1, knn21, n2, ratio, o);
-    *n_out = (int)o.size() / 3;
-    if (out3 && !o.empty()) memcpy(out3, o.data(), o.size() * sizeof(int));
-    return POPPY_OK;
-}
-
-// ---- auto-align ------------------------------------------------------------------------------------------------------
-static int align_stage(poppy_hip_ctx* c, const uint8_t* img, size_t stride, int W, int H) {
-    const size_t bytes = (size_t)W * H * 3;
-    if (c->d_align_bytes < bytes) {
-        if (c->d_align) (void)hipFree(c->d_align);
-        c->d_align = nullptr; c->d_align_bytes = 0;
-        HIPCHK(c, hipMalloc((void**)&c->d_align, bytes));
-        c->d_align_bytes = bytes;
-    }
-    HIPCHK(c, hipMemcpy2DAsync(c->d_align, (size_t)W * 3, img, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
-    return POPPY_OK;
-}
-
-int poppy_hip_warp_affine(poppy_hip_ctx* c, const uint8_t* src, size_t ss, int W, int H, const double* M, uint8_t* dst, size_t ds) {
-    if (!c) return POPPY_E_ARG;
-    if (!src || !dst || !M || W <= 0 || H <= 0 || ss < (size_t)W * 3 || ds < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad warp_affine arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = align_stage(c, src, ss, W, H); if (rc) return rc;
-    uint8_t* d_out = nullptr; int* d_tab = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_out, (size_t)W * H * 3));
-    hipError_t e = hipMalloc((void**)&d_tab, (size_t)2 * (W + H) * sizeof(int));
-    bool ok = e == hipSuccess && warp_affine_device(c->d_align, d_out, W, H, M, d_tab, c->stream);
-    if (ok) ok = hipMemcpy2DAsync(dst, ds, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                 hipStreamSynchronize(c->stream) == hipSuccess;
-    (void)hipFree(d_out); if (d_tab) (void)hipFree(d_tab);
-    return ok ? POPPY_OK : fail(c, POPPY_E_DEVICE, "warp_affine failed");
-}
-
-static int align_host_entry(poppy_hip_ctx* c, int which, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
-    if (!c) return POPPY_E_ARG;
-    if (!img || !p1 || !p2 || n < 4 || W <= 0 || H <= 0 || stride < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad align arguments (at least 4 point pairs)");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = align_stage(c, img, stride, W, H); if (rc) return rc;
-    std::vector<P2f> a(n), b(n);
-    memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8);
-    rc = which < 0 ? c->aligner.run(c->d_align, W, H, a, b, c->stream, dist) : c->aligner.step(which, c->d_align, W, H, a, b, c->stream, dist);
-    if (rc) return fail(c, rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE, c->aligner.err.c_str());
-    memcpy(p2, b.data(), (size_t)n * 8);
-    HIPCHK(c, hipMemcpy2DAsync(img, stride, c->d_align, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return POPPY_OK;
-}
-int poppy_hip_auto_align(poppy_hip_ctx* c, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
-    return align_host_entry(c, -1, img, stride, W, H, p1, p2, n, dist);
-}
-int poppy_hip_align_step(poppy_hip_ctx* c, int which, uint8_t* img, size_t stride, int W, int H, const float* p1, float* p2, int n, double* dist) {
-    if (which < 0 || which > 2) return c ? fail(c, POPPY_E_ARG, "align_step: which must be 0, 1 or 2") : POPPY_E_ARG;
-    return align_host_entry(c, which, img, stride, W, H, p1, p2, n, dist);
-}
-int poppy_procrustes(const float* x, const float* y, int n, float* rot4, float* se2, float* yprime) {
-    if (!x || !y || n < 1) return POPPY_E_ARG;
-    std::vector<P2f> a(n), b(n);
-    memcpy(a.data(), x, (size_t)n * 8); memcpy(b.data(), y, (size_t)n * 8);
-    ProcrustesFit f;
-    procrustes_fit(a, b, f);
-    if (rot4) memcpy(rot4, f.rotation, 16);
-    if (se2) { se2[0] = f.scale; se2[1] = f.error; }
-    if (yprime) memcpy(yprime, f.yprime.data(), (size_t)n * 8);
-    return POPPY_OK;
-}
-int poppy_perspective_from4(const float* s4, const float* d4, double* m) {
-    if (!s4 || !d4 || !m) return POPPY_E_ARG;
-    perspective_from_4((const P2f*)s4, (const P2f*)d4, m);
-    return POPPY_OK;
-}
-
-int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
-    if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
-    std::vector<P2f> a(n), b(n);
-    if (n) { memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8); }
-    drop_out_of_image(a, b, W, H);
-    if (a.empty()) { *n_out = 0; if (imd) *imd = 0; return POPPY_OK; }     // caller falls back to the dissolve (poppy.hpp:125)
-    const double d = morph_distance_ref(a, b, W, H);
-    if (imd) *imd = d;
-    match_and_prepare(a, b, W, H, tol, d);
-    *n_out = (int)a.size();
-    if (o1) memcpy(o1, a.data(), a.size() * 8);
-    if (o2) memcpy(o2, b.data(), b.size() * 8);
-    return POPPY_OK;
-}
-
-int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2,
-                                     const uint8_t* g1, const uint8_t* g2, const float* gabor2, int W, int H, int nfeatures) {
-    if (!c || !bgr1 || !bgr2 || !g1 || !g2 || !gabor2) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<OrbKeyPoint> k1, k2;
-    if (c->orb.detect(g1, W, W, H, nfeatures, c->stream, k1) < 0 || c->orb.detect(g2, W, W, H, nfeatures, c->stream, k2) < 0) {
-        c->err = "orb_detect: " + c->orb.err;
-        return POPPY_E_DEVICE;
-    }
-    const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
-    std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
-    for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
-    int m = 0;
-    int rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
-    if (rc) return fail(c, rc, "poppy_match_points failed");
-    return poppy_hip_pair_load(c, bgr1, s1, bgr2, s2, gabor2, W, H, o1.data(), o2.data(), m);
-}
-
-int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, uint8_t* out, const poppy_foreground_debug* dbg) {
-    if (!c) return POPPY_E_ARG;
-    if (!bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    ForegroundDebugOut d;
-    if (dbg) { d.grey = dbg->grey; d.stages = dbg->stages; d.floats = dbg->floats; d.masked = dbg->masked; }
-    const int rc = c->foreground.run(bgr, stride, W, H, c->stream, out, dbg ? &d : nullptr);
-    if (rc) { c->err = "foreground: " + c->foreground.err; return rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE; }
-    return POPPY_OK;
-}
-
-// Pair set-up from the raw images: the pre-ORB filter chain on the GPU, then the same steps as pair_begin_prefiltered.
-static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
-    if (!c) return POPPY_E_ARG;
-    if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = alloc_pair(c, W, H); if (rc) return rc;
-    c->pair_ready = false;
-    rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
-    rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
-    const size_t P = (size_t)W * H;
-    std::vector<uint8_t> g[2] = {std::vector<uint8_t>(P), std::vector<uint8_t>(P)};
-    double d[2] = {0, 0};
-    if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                         // the uploads above
-    // The two images go through the chain independently (Extractor::foreground -> dft_detail2 -> the ORB input of
-    // Extractor::keypoints; image 2 also through gabor_filter(corrected2 / 255), src/poppy.hpp:119-122): one host thread and
-    // one stream each, so that the medians of one image run beside the Gabor bank of the other.
-    std::string errs[2];
-    int rcs[2] = {POPPY_OK, POPPY_OK};
-    // with auto-align, gabor2 belongs to the ALIGNED second image (src/poppy.hpp:116-122 runs after Matcher::find): computed further down
-    const bool align_first = c->cfg.enable_auto_align != 0 && ratio < 0.f;
-    auto chain_of = [&](int i) {
-        if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
-        ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
-        hipStream_t st = i ? c->aux_stream : c->stream;
-        const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
-        if (!gf) { errs[i] = "foreground: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-        if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-        const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
-        if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-        hipError_t e = hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && i == 1 && !align_first) {
-            const float* gab = fg.gabor_field(c->c2, W, H, st);
-            if (!gab) { errs[i] = "gabor_field: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-            e = hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, st);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; }
-    };
-    {
-        std::thread other(chain_of, 1);
-        chain_of(0);
-        other.join();
-    }
-    for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
-    const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
-    c->last_detail[0] = d[0]; c->last_detail[1] = d[1];
-    const int nfeatures = (int)(c->cfg.max_keypoints * detail);
-    c->last_nfeatures = nfeatures;
-    std::vector<OrbKeyPoint> k1, k2;
-    {   // the two detections are independent too
-        int r1 = 0, r2 = 0;
-        std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g[1].data(), W, W, H, nfeatures, c->aux_stream, k2) : -2; });
-        r1 = c->orb.detect(g[0].data(), W, W, H, nfeatures, c->stream, k1);
-        other.join();
-        if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
-    }
-    if (ratio >= 0.f) {
-        // Opt-in descriptor mode (the reference only sketched it, src/experiments.hpp:14-144): ORB::compute on both
-        // keypoint sets, 2-NN Hamming both ways, ratio test, symmetry test; the surviving pairs, in query order, become the
-        // point sets (out-of-image pairs dropped, the four corners appended).  No positional re-pairing, no threshold.
-        std::vector<uint8_t> d1(k1.size() * 32), d2(k2.size() * 32);
-        auto rows7 = [](const std::vector<OrbKeyPoint>& k) {            // cv::KeyPoint field order, all as float
-            std::vector<float> r(k.size() * 7);
-            for (size_t i = 0; i < k.size(); ++i) {
-                float* o = &r[i * 7];
-                o[0] = k[i].x; o[1] = k[i].y; o[2] = k[i].size; o[3] = k[i].angle; o[4] = k[i].response; o[5] = (float)k[i].octave; o[6] = (float)k[i].class_id;
-            }
-            return r;
-        };
-        const std::vector<float> r1v = rows7(k1), r2v = rows7(k2);
-        {
-            int r1 = 0, r2 = 0;
-            std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.describe(g[1].data(), W, W, H, r2v.data(), (int)k2.size(), c->aux_stream, d2.data()) : -2; });
-            r1 = c->orb.describe(g[0].data(), W, W, H, r1v.data(), (int)k1.size(), c->stream, d1.data());
-            other.join();
-            if (r1 < 0 || r2 < 0) { c->err = "orb_describe: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
-        }
-        std::vector<int> k12(k1.size() * 4), k21(k2.size() * 4), sym;
-        if (c->orb.hamming_knn2(d1.data(), (int)k1.size(), d2.data(), (int)k2.size(), c->stream, k12.data()) < 0 ||
-            c->orb.hamming_knn2(d2.data(), (int)k2.size(), d1.data(), (int)k1.size(), c->stream, k21.data()) < 0) {
-            c->err = "hamming_knn2: " + c->orb.err;
-            return POPPY_E_DEVICE;
-        }
-        ratio_symmetry(k12.data(), (int)k1.size(), k21.data(), (int)k2.size(), ratio, sym);
-        std::vector<P2f> a, b;
-        for (size_t i = 0; i + 3 <= sym.size(); i += 3) {
-            a.push_back(P2f{k1[sym[i]].x, k1[sym[i]].y});
-            b.push_back(P2f{k2[sym[i + 1]].x, k2[sym[i + 1]].y});
-        }
-        drop_out_of_image(a, b, W, H);
-        c->last_descriptor_matches = (int)a.size();
-        if (a.empty()) return fail(c, POPPY_E_NOMATCH, "no symmetric descriptor matches");
-        c->initial_morph_dist = morph_distance_ref(a, b, W, H);
-        add_image_corners(a, b, W, H);
-        rc = set_points(c, (const float*)a.data(), (const float*)b.data(), (int)a.size()); if (rc) return rc;
-    } else {
-        const size_t n = std::min(k1.size(), k2.size());                    // Extractor::points (extractor.cpp:96-99)
-        std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
-        for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = k2[i].x; p2[2 * i + 1] = k2[i].y; }
-        if (align_first) {                                                  // Matcher::find, src/matcher.cpp:29-32
-            if (n < 4) return fail(c, POPPY_E_UNSUPPORTED, "auto-align needs at least 4 keypoint pairs (the reference reads 4 unconditionally)");
-            std::vector<P2f> a(n), b(n);
-            memcpy(a.data(), p1.data(), n * 8); memcpy(b.data(), p2.data(), n * 8);
-            if (c->aligner.run(c->c2, W, H, a, b, c->stream, nullptr)) return fail(c, POPPY_E_DEVICE, c->aligner.err.c_str());
-            memcpy(p2.data(), b.data(), n * 8);
-            const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->stream);
-            if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return POPPY_E_DEVICE; }
-            HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
-        }
-        int m = 0;
-        rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
-        if (rc) return fail(c, rc, "poppy_match_points failed");
-        rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
-    }
-    rc = finish_pair_load(c); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return POPPY_OK;
-}
-
-int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H) {
-    return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, -1.f);
-}
-int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
-    if (!(ratio >= 0.f)) return c ? fail(c, POPPY_E_ARG, "ratio must be >= 0") : POPPY_E_ARG;
-    return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, ratio);
-}
-
-int poppy_hip_pair_corrected2(poppy_hip_ctx* c, uint8_t* dst, size_t ds) {
-    if (!c || !dst) return POPPY_E_ARG;
-    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no resident pair");
-    if (ds < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "stride too small");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy2DAsync(dst, ds, c->c2, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return POPPY_OK;
-}
-
-// intermediates of the last poppy_hip_pair_begin, for the tolerance tests: nfeatures, the two dft_detail2 values
-int poppy_hip_pair_begin_info(poppy_hip_ctx* c, int* nfeatures, double* detail2) {
-    if (!c) return POPPY_E_ARG;
-    if (nfeatures) *nfeatures = c->last_nfeatures;
-    if (detail2) { detail2[0] = c->last_detail[0]; detail2[1] = c->last_detail[1]; }
-    return POPPY_OK;
-}
-
-// Extractor::keypoints' image chain for one goodFeatures image (host in / out): us = grey(unsharp), gb = Gabor mean, g = ORB input
-int poppy_hip_orb_input(poppy_hip_ctx* c, const uint8_t* good_features, int W, int H, uint8_t* g, float* us, float* gb, double* detail) {
-    if (!c || !good_features || W <= 0 || H <= 0) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    ForegroundFilter& fg = c->foreground;
-    if (fg.prepare(W, H)) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
-    uint8_t* d_gf = fg.bgr_staging();                                   // any w*h device bytes will do as the staging area
-    HIPCHK(c, hipMemcpyAsync(d_gf, good_features, (size_t)W * H, hipMemcpyHostToDevice, c->stream));
-    if (detail && fg.detail(d_gf, W, H, c->stream, detail)) { c->err = "dft_detail2: " + fg.err; return POPPY_E_DEVICE; }
-    const uint8_t* gi = fg.orb_input(d_gf, W, H, 0, c->stream, us, gb);
-    if (!gi) { c->err = "orb_input: " + fg.err; return POPPY_E_DEVICE; }
-    if (g) HIPCHK(c, hipMemcpyAsync(g, gi, (size_t)W * H, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return POPPY_OK;
-}
-
-// gabor_filter(bgr / 255) with the default arguments (host in / out, f32x3)
-int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, float* out) {
-    if (!c || !bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return POPPY_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    ForegroundFilter& fg = c->foreground;
-    if (fg.prepare(W, H)) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
-    HIPCHK(c, hipMemcpy2DAsync(fg.bgr_staging(), (size_t)W * 3, bgr, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
-    const float* gab = fg.gabor_field(fg.bgr_staging(), W, H, c->stream);
-    if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
-    HIPCHK(c, hipMemcpyAsync(out, gab, (size_t)W * H * 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return POPPY_OK;
-}
-
-// blur_margin (src/util.cpp:574-602): what the reference's CLI does to every image before poppy::morph when the phase is not 0 / 1
-// (src/poppy.cpp:233-240,293-308): centre it in the union canvas and blur the four margin strips (127x127, sigma 6, fixed point).
-int poppy_hip_blur_margin(poppy_hip_ctx* c, const uint8_t* src, size_t stride, int W, int H, int UW, int UH, uint8_t* dst, size_t dst_stride) {
-    if (!c) return POPPY_E_ARG;
-    if (!src || !dst || W <= 0 || H <= 0 || UW < W || UH < H || stride < (size_t)W * 3 || dst_stride < (size_t)UW * 3) return fail(c, POPPY_E_ARG, "bad arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t UB = (size_t)UW * UH * 3;
-    uint8_t *canvas = nullptr, *out = nullptr; uint32_t* tmp = nullptr; int* d_taps = nullptr;
-    auto cleanup = [&]() { for (void* p : {(void*)canvas, (void*)out, (void*)tmp, (void*)d_taps}) if (p) (void)hipFree(p); };
-    // taps: exp(-x^2 / 2 sigma^2) / sum in double, to 8 fractional bits with error diffusion, centre = 256 - rest (smooth.dispatch.cpp:224-258)
-    const int n = 127; const double sigma = 6;
-    std::vector<double> v(n); double sum = 0;
-    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2 * sigma * sigma)); sum += v[i]; }
-    std::vector<int> taps(n, 0);
-    { double err = 0; int tot = 0;
-      for (int i = 0; i < n / 2; ++i) { const double adj = v[i] / sum * 256 + err; const int v0 = (int)std::nearbyint(adj); err = adj - v0; taps[i] = taps[n - 1 - i] = v0; tot += v0; }
-      taps[n / 2] = 256 - 2 * tot; }
-    hipError_t e = hipMalloc((void**)&canvas, UB);
-    if (e == hipSuccess) e = hipMalloc((void**)&out, UB);
-    if (e == hipSuccess) e = hipMalloc((void**)&tmp, UB * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_taps, n * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_taps, taps.data(), n * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(canvas, 0, UB, c->stream);
-    const double margin = (W + H) / 100.0;
-    double dx = std::fabs((double)(W - UW)) / 2.0, dy = std::fabs((double)(H - UH)) / 2.0;
-    const int rx = (int)dx, ry = (int)dy;
-    if (e == hipSuccess) e = hipMemcpy2DAsync(canvas + ((size_t)ry * UW + rx) * 3, (size_t)UW * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, canvas, UB, hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) { cleanup(); c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
-    dx = (dx == 0 ? 1.3 : dx + margin);
-    dy = (dy == 0 ? 1.3 : dy + margin);
-    const int rects[4][4] = {{0, 0, (int)dx, UH}, {(int)(UW - dx), 0, (int)dx, UH}, {0, 0, UW, (int)dy}, {0, (int)(UH - dy), UW, (int)dy}};
-    for (const auto& r : rects) launch_strip_blur(canvas, out, UW, tmp, d_taps, n, r[0], r[1], r[2], r[3], c->stream);   // left, right, top, bottom: later strips win
-    e = hipMemcpy2DAsync(dst, dst_stride, out, (size_t)UW * 3, (size_t)UW * 3, UH, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (e != hipSuccess) { c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
-    return POPPY_OK;
-}
-
-int poppy_radial_gradient(int W, int H, float* out) {
-    if (W <= 0 || H <= 0 || !out) return POPPY_E_ARG;
-    std::vector<float> r;
-    radial_gradient(W, H, r);
-    memcpy(out, r.data(), r.size() * 4);
     return POPPY_OK;
 }
 
