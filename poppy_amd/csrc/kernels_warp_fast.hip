@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
     __shared__ int s_tag[kSlots];
     __shared__ float4 s_rec[kSlots * 5];
+    __shared__ u4v s_ids[256];                  // each thread's four ids, parked for the rare border path
 
     const int tid = threadIdx.x;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -141,6 +142,8 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);
+        if (ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);   // only reader: leave it cleared
+        s_ids[tid] = ids;
         if (ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
         id[0] = (int)ids.x; id[1] = (int)ids.y; id[2] = (int)ids.z; id[3] = (int)ids.w;
         s_tag[id[0] & (kSlots - 1)] = id[0];
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
 #pragma unroll
     for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
     if (__builtin_amdgcn_ballot_w64(edges != 0) != 0 && edges != 0) {
-        const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);      // not kept in registers for this rare path
+        const u4v ids = s_ids[tid];                                                     // not kept in registers for this rare path
         for (int e = 0; e < 8; ++e) {
             if (!((edges >> e) & 1u)) continue;
             const int k = e & 3, im = e >> 2;
@@ -242,8 +245,6 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
             dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
     }
-    // this kernel is the id map's only reader: leave it cleared for the next frame's raster (last, so that the border path can still read it)
-    if (ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);
 }
 
 bool warp_fast_geometry(int w, int h) {

@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 evidence on the GPU box: kernel trace + stats of the bench command, and the two
 # HBM-traffic counter passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).  Usage:
 #   gpurun -- bash tools/profile_round.sh <tag>         ->  gpurun_out/<tag>_{trace,fetch,write}[_4k]/
-tag=${1:-r01}
+tag=${1:-r01_k}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only"
