@@ -19,7 +19,7 @@ def main():
              "group by kernel_name, counter_name order by kernel_name, counter_name")
         rows = {}
         for name, counter, n, avg in db.execute(q):
-            short = name.split("(")[0].replace("poppy_hip::", "").replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("poppy_hip::", "").replace("void ", "")
             if want in short:
                 rows.setdefault(short, []).append(f"{counter}={avg:.6g}")
         for k, v in rows.items():

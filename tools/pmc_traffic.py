@@ -19,7 +19,7 @@ def per_kernel(db_path, counter):
          "group by kernel_name, grid_size order by kernel_name, grid_size desc")
     out = {}
     for name, grid, n, avg in db.execute(q, (counter,)):
-        short = name.split("(")[0].replace("poppy_hip::", "").replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("poppy_hip::", "").replace("void ", "")
         out[(short, grid)] = (n, avg * 1024.0)
     return out
 

@@ -16,14 +16,14 @@ def main():
     lines = [f"# rocprofv3 --kernel-trace --stats: {title}", "",
              "| kernel | calls | total (us) | avg (us) | % |", "|---|---:|---:|---:|---:|"]
     for name, calls, total, avg, pct in rows:
-        short = name.split("(")[0].replace("poppy_hip::", "").replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("poppy_hip::", "").replace("void ", "")
         lines.append(f"| `{short}` | {calls} | {total:.1f} | {avg:.3f} | {pct:.2f} |")
     if "--by-grid" in sys.argv:     # one row per (kernel, launch geometry): separates the pyramid levels
         lines += ["", "| kernel | grid | block | calls | avg (us) | vgpr | lds |", "|---|---:|---:|---:|---:|---:|---:|"]
         q = ("select name, grid_x, grid_y, workgroup_x, workgroup_y, count(*), avg(duration), max(vgpr_count), max(lds_size) "
              "from kernels group by name, grid_x, grid_y, workgroup_x order by name, grid_x * grid_y desc")
         for name, gx, gy, wx, wy, n, avg, vg, ldsz in db.execute(q):
-            short = name.split("(")[0].replace("poppy_hip::", "").replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("poppy_hip::", "").replace("void ", "")
             lines.append(f"| `{short}` | {gx}x{gy} | {wx}x{wy} | {n} | {avg / 1e3:.2f} | {vg} | {ldsz} |")
     text = "\n".join(lines) + "\n"
     if out:
