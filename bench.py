@@ -232,6 +232,27 @@ def main():
         pcie_fps = args.steps * FRAMES / (time.perf_counter() - t1)
         assert seen[0] == (args.steps + 1) * FRAMES
 
+    # measured device-copy ceiling: a plain device-to-device copy moving as many bytes as the warp kernel does per
+    # launch (14 B/px read + 14 B/px written), timed with events on torch's stream; the vendor peak is not reachable by any kernel
+    copy_ceiling = None
+    if rank == 0:
+        try:
+            nbytes = 14 * W * H
+            src_t = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+            dst_t = torch.empty_like(src_t)
+            for _ in range(3):
+                dst_t.copy_(src_t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                dst_t.copy_(src_t)
+            e1.record(); torch.cuda.synchronize()
+            copy_ceiling = 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src_t, dst_t
+        except Exception as e:
+            print(f"bench.py: copy ceiling failed: {e}", file=sys.stderr)
+
     # pair set-up from the raw images (pre-ORB chain, ORB, matcher, gabor2; once per pair), rank 0, outside the timed
     # region: reported beside `value`, which is the per-frame operator on a resident pair
     setup_ms = None
@@ -287,7 +308,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("k_warp_tile" if ctx.last_warp_kind() == 1 else "k_warp4") + " (fused create_map + remap of both sources + lbmask)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n},
+                         "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n,
+                         "copy_ceiling_GBps": round(copy_ceiling, 1) if copy_ceiling else None,
+                         "copy_ceiling_note": "device-to-device copy of the same 14+14 B/px, measured in this run; "
+                                              "traffic / launch time is the figure to hold against it"},
             "kernels": kernels,
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
             "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
