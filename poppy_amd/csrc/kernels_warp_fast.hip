@@ -142,9 +142,8 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);
-        if (ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);   // only reader: leave it cleared
+        if (ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));   // both in flight together
         s_ids[tid] = ids;
-        if (ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
         id[0] = (int)ids.x; id[1] = (int)ids.y; id[2] = (int)ids.z; id[3] = (int)ids.w;
         s_tag[id[0] & (kSlots - 1)] = id[0];
 #pragma unroll
@@ -153,6 +152,8 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     }
     __syncthreads();
     // -- fill the claimed slots (a slot nobody claimed holds a stale tag: its load is harmless, nobody asks for it) --
+    // this kernel is the id map's only reader: leave it cleared for the next frame's raster (issued here so that nothing waits on it)
+    if (active && ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);
     const int fslot = tid >> 2, fpart = tid & 3;                    // 64 slots x 4 parts, then the 64 fifth parts
     const u4v fill0 = __builtin_amdgcn_raw_buffer_load_b128(rrec, (uint32_t)s_tag[fslot] * 80u + (uint32_t)fpart * 16u, 0, 0);
     u4v fill1 = {0u, 0u, 0u, 0u};
