@@ -74,3 +74,22 @@ def test_pair_begin_with_auto_align_reproduces_poppy_morph(case):
     for j, f in enumerate(frames):
         G.check(case, f"frame{j}", f)
     c.close()
+
+
+def test_align_entry_points_argument_errors_and_strides(ctx):
+    """Error behaviour (status codes, no exit / throw) and row strides of the host-facing align entry points."""
+    import ctypes as C
+    L = capi.lib()
+    img = synth.textured_bgr(64, 40, 3)
+    pts = np.array([[5, 5], [50, 6], [8, 30]], np.float32)
+    d = C.c_double(0)
+    rc = L.poppy_hip_auto_align(ctx.h, img.ctypes.data, 64 * 3, 64, 40, pts.ctypes.data, pts.copy().ctypes.data, 3, C.byref(d))
+    assert rc == -1 and b"4 point pairs" in L.poppy_hip_last_error(ctx.h)          # POPPY_E_ARG: fewer than 4 pairs
+    assert L.poppy_hip_align_step(ctx.h, 7, img.ctypes.data, 64 * 3, 64, 40, pts.ctypes.data, pts.ctypes.data, 3, C.byref(d)) == -1
+    assert L.poppy_hip_warp_affine(ctx.h, img.ctypes.data, 10, 64, 40, None, img.ctypes.data, 64 * 3) == -1
+    # padded rows in, padded rows out
+    M = np.array([0.9, 0.1, 3.0, -0.1, 0.95, 1.5], np.float64)
+    src = np.zeros((40, 80 * 3), np.uint8); src[:, :64 * 3] = img.reshape(40, -1)
+    dst = np.full((40, 72 * 3), 7, np.uint8)
+    assert L.poppy_hip_warp_affine(ctx.h, src.ctypes.data, 80 * 3, 64, 40, M.ctypes.data, dst.ctypes.data, 72 * 3) == 0
+    assert np.array_equal(dst[:, :64 * 3].reshape(40, 64, 3), O.warp_affine(img, M)) and (dst[:, 64 * 3:] == 7).all()
