@@ -94,7 +94,14 @@ int ForegroundFilter::ensure2(int w, int h) {
     gabor_bank(31, 5, 2, 0.04, M_PI / 4, b31);                // Extractor::keypoints (src/extractor.cpp:63-64)
     gabor_bank(13, 5, 10, 0.04, M_PI / 4, b13);               // gabor_filter defaults (src/util.hpp:95)
     radial_gradient(w, h, rad);
-    std::vector<double> b31d(b31.begin(), b31.end()), b13d(b13.begin(), b13.end());     // the float taps, widened (exact)
+    // the float taps, widened (exact) and regrouped [tap][orientation]: the 16 weights of a tap are one 128-byte scalar fetch
+    auto by_tap = [](const std::vector<float>& b, int ks) {
+        std::vector<double> o(b.size());
+        const int n = ks * ks;
+        for (int k = 0; k < 16; ++k) for (int t = 0; t < n; ++t) o[(size_t)t * 16 + k] = b[(size_t)k * n + t];
+        return o;
+    };
+    const std::vector<double> b31d = by_tap(b31, 31), b13d = by_tap(b13, 13);
     F2_CHK(hipMalloc((void**)&taps17, 17 * 4)); F2_CHK(hipMalloc((void**)&bank31, b31d.size() * 8)); F2_CHK(hipMalloc((void**)&bank13, b13d.size() * 8));
     F2_CHK(hipMemcpy(taps17, t17.data(), 17 * 4, hipMemcpyHostToDevice));
     F2_CHK(hipMemcpy(bank31, b31d.data(), b31d.size() * 8, hipMemcpyHostToDevice));

@@ -102,9 +102,9 @@ __global__ void __launch_bounds__(256) k_gabor_bank(const float* __restrict__ sr
     for (int dy = 0; dy < K; ++dy)
         for (int dx = 0; dx < K; ++dx) {
             const double v = (double)tile[(ly + dy) * SX + lx + dx];
-            const double* wv = bank + dy * K + dx;
+            const double* wv = bank + (dy * K + dx) * 16;                             // [tap][orientation]: one 128-byte scalar fetch per tap
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fma(wv[o * K * K], v, acc[o]);      // the product is exact in double
+            for (int o = 0; o < 16; ++o) acc[o] = fma(wv[o], v, acc[o]);              // the product is exact in double
         }
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) return;
