@@ -23,10 +23,10 @@ ForegroundFilter::~ForegroundFilter() {
 }
 
 void ForegroundFilter::release() {
-    void* bufs[] = {padded, d_bgr, grey, img[0], img[1], acc[0], acc[1], flow, used, masked, out, lut, tmp16, gw, gv, gm, dbgf, hist};
+    void* bufs[] = {padded, d_bgr, grey, meds, acc[0], acc[1], flows, masked, out, lut, tmp16, dbgf, hist};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    d_bgr = grey = img[0] = img[1] = acc[0] = acc[1] = flow = used = masked = out = lut = nullptr;
-    tmp16 = nullptr; padded = nullptr; gw = gv = gm = dbgf = nullptr; hist = nullptr;
+    d_bgr = grey = meds = acc[0] = acc[1] = flows = masked = out = lut = nullptr;
+    tmp16 = nullptr; padded = nullptr; dbgf = nullptr; hist = nullptr;
     W = H = 0;
 }
 
@@ -52,13 +52,12 @@ int ForegroundFilter::ensure(int w, int h) {
     logtab = keep;
     const size_t P = (size_t)w * h;
     FG_CHK(hipMalloc((void**)&d_bgr, P * 3)); FG_CHK(hipMalloc((void**)&grey, P));
-    FG_CHK(hipMalloc((void**)&img[0], P)); FG_CHK(hipMalloc((void**)&img[1], P));
+    FG_CHK(hipMalloc((void**)&meds, P * 12));                       // the twelve median planes
     FG_CHK(hipMalloc((void**)&acc[0], P)); FG_CHK(hipMalloc((void**)&acc[1], P));
-    FG_CHK(hipMalloc((void**)&flow, P)); FG_CHK(hipMalloc((void**)&used, P));
+    FG_CHK(hipMalloc((void**)&flows, P * kMog2Steps));             // one mask plane per MOG2 step
     FG_CHK(hipMalloc((void**)&masked, P)); FG_CHK(hipMalloc((void**)&out, P)); FG_CHK(hipMalloc((void**)&lut, 256));
     FG_CHK(hipMalloc((void**)&tmp16, P * 2));
     FG_CHK(hipMalloc((void**)&padded, median_padded_bytes(w, h)));
-    FG_CHK(hipMalloc((void**)&gw, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gv, P * 5 * 4)); FG_CHK(hipMalloc((void**)&gm, P * 5 * 4));
     FG_CHK(hipMalloc((void**)&hist, 256 * sizeof(unsigned)));
     W = w; H = h;
     return 0;
@@ -74,31 +73,38 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     };
     err.clear();
     launch_bgr2gray(bgr, stride, grey, w, h, s);
-    chk(hipMemsetAsync(gw, 0, P * 20, s), "memset"); chk(hipMemsetAsync(gv, 0, P * 20, s), "memset");
-    chk(hipMemsetAsync(gm, 0, P * 20, s), "memset"); chk(hipMemsetAsync(used, 0, P, s), "memset");
-    chk(hipMemsetAsync(acc[0], 0, P, s), "memset");
-    const float acc_scale = (float)(1.0 / (12 / 2.0));       // flow * (1.0 / (iterations / 2.0)), iterations = 12
-    int nframes = 0;
-    auto mog2 = [&](const uint8_t* image, uint8_t* a) {
-        ++nframes;
-        const double lr = 1. / std::min(2 * nframes, 500);   // learningRate < 0 -> 1 / min(2 nframes, history)
-        launch_mog2(image, gw, gv, gm, used, (dbg && dbg->stages) ? flow : nullptr, a, n, (float)lr, (float)(-lr * 0.05f), acc_scale, s);
-    };
-    int cur = 0;                                              // acc[cur] is fgMask
-    mog2(grey, acc[cur]);
-    stage_out(0, flow); stage_out(1, acc[cur]);
+    // 1. the chain of input images: the grey image and its progressive medians (ksize 1, 9, ..., 89; each of the previous one).
+    //    It does not depend on the masks, so it runs first and every plane is kept.
+    const uint8_t* inputs[kMog2Steps];
+    inputs[0] = grey;
     const uint8_t* last = grey;
     for (int i = 0; i < 12; ++i) {
-        uint8_t* med = img[i & 1];
+        uint8_t* med = meds + (size_t)i * P;
         const int ksize = i * 8 + 1;
         if (ksize <= 1) chk(hipMemcpyAsync(med, last, P, hipMemcpyDeviceToDevice, s), "copy");
         else launch_median_u8(last, padded, med, w, h, ksize, s);
-        mog2(med, acc[cur]);
-        stage_out(2 + 4 * i, med); stage_out(3 + 4 * i, flow); stage_out(4 + 4 * i, acc[cur]);
+        inputs[i + 1] = med;
+        last = med;
+    }
+    // 2. all thirteen MOG2 applies in one launch (mixture in registers), one mask plane per step
+    float alphaT[kMog2Steps], prune[kMog2Steps];
+    for (int i = 0; i < kMog2Steps; ++i) {
+        const double lr = 1. / std::min(2 * (i + 1), 500);   // learningRate < 0 -> 1 / min(2 nframes, history)
+        alphaT[i] = (float)lr; prune[i] = (float)(-lr * 0.05f);
+    }
+    launch_mog2_all(inputs, alphaT, prune, kMog2Steps, flows, n, s);
+    // 3. fgMask: accumulate the masks, blurring the accumulator after each of the twelve median steps
+    const float acc_scale = (float)(1.0 / (12 / 2.0));       // flow * (1.0 / (iterations / 2.0)), iterations = 12
+    chk(hipMemsetAsync(acc[0], 0, P, s), "memset");
+    int cur = 0;                                              // acc[cur] is fgMask
+    launch_acc_flow(acc[cur], flows, n, acc_scale, s);
+    stage_out(0, flows); stage_out(1, acc[cur]);
+    for (int i = 0; i < 12; ++i) {
+        launch_acc_flow(acc[cur], flows + (size_t)(i + 1) * P, n, acc_scale, s);
+        stage_out(2 + 4 * i, inputs[i + 1]); stage_out(3 + 4 * i, flows + (size_t)(i + 1) * P); stage_out(4 + 4 * i, acc[cur]);
         launch_gauss23_u8(acc[cur], tmp16, acc[cur ^ 1], w, h, s);
         cur ^= 1;
         stage_out(5 + 4 * i, acc[cur]);
-        last = med;
     }
     float* dbg_floats = nullptr;
     if (dbg && dbg->floats) {

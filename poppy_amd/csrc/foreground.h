@@ -52,11 +52,11 @@ private:
     float* d_wave[2] = {nullptr, nullptr};
     int dft_n[2] = {0, 0}, dft_nf[2] = {0, 0}, dft_factors[2][16] = {};
     int W = 0, H = 0;
-    uint8_t *d_bgr = nullptr, *grey = nullptr, *img[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr}, *flow = nullptr;
-    uint8_t *used = nullptr, *masked = nullptr, *out = nullptr, *lut = nullptr;
+    uint8_t *d_bgr = nullptr, *grey = nullptr, *meds = nullptr, *acc[2] = {nullptr, nullptr}, *flows = nullptr;
+    uint8_t *masked = nullptr, *out = nullptr, *lut = nullptr;
     uint16_t* tmp16 = nullptr;
     uint8_t* padded = nullptr;           // median source with replicated side columns
-    float *gw = nullptr, *gv = nullptr, *gm = nullptr, *logtab = nullptr, *dbgf = nullptr;
+    float *logtab = nullptr, *dbgf = nullptr;
     unsigned* hist = nullptr;
     bool prepared = false;
 };

@@ -3,7 +3,7 @@
 // Integer / per-pixel float work, HBM- or LDS-bound; no MFMA.  Arithmetic follows the reference's SSE3-baseline build
 // (this file is compiled with -ffp-contract=off; OCV = third/opencv-4.6.0/modules):
 //   k_bgr2gray        cvtColor(BGR2GRAY), 15-bit fixed point          OCV/imgproc/src/color_rgb.simd.hpp:646-730
-//   k_mog2            BackgroundSubtractorMOG2(500,16,true)::apply     OCV/video/src/bgfg_gaussmix2.cpp:479-523,539-755,847-884
+//   k_mog2_all        BackgroundSubtractorMOG2(500,16,true)::apply x 13     OCV/video/src/bgfg_gaussmix2.cpp:479-523,539-755,847-884
 //                     + acc += flow * (1/6) (u8 convertTo, saturating add; matrix_expressions.cpp:270-275,1330-1336)
 //   k_median_u8       medianBlur, ksize 9..89, replicated border       OCV/imgproc/src/median_blur.simd.hpp (exact median)
 //   k_gauss23_h/_v    GaussianBlur 23x23 sigma 1, 8.8 fixed point      OCV/imgproc/src/smooth.simd.hpp:1136-1199,1780-1866
@@ -11,6 +11,7 @@
 //                                                                      OCV/core/src/mathfuncs_core.simd.hpp:683-752
 //   k_equalize_lut / k_apply_lut   equalizeHist                        OCV/imgproc/src/histogram.cpp:3436-3493
 #include "kernels_prefilter.h"
+#include <cstdlib>
 #include "pyramid_device.h"
 
 namespace poppy_hip {
@@ -30,20 +31,14 @@ void launch_bgr2gray(const uint8_t* bgr, size_t stride, uint8_t* gray, int w, in
 // modes live in registers for the duration of the update (sorting swaps become register moves).
 constexpr int kMog2Modes = 5;
 
-__global__ void __launch_bounds__(256) k_mog2(const uint8_t* __restrict__ img, float* __restrict__ gw, float* __restrict__ gv,
-                                              float* __restrict__ gm, uint8_t* __restrict__ used, uint8_t* __restrict__ flow_out,
-                                              uint8_t* __restrict__ acc, int n, float alphaT, float prune, float acc_scale) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+// One BackgroundSubtractorMOG2::apply step on one pixel; returns the mask value (0, 127, 255).
+// Kept out of line on purpose: inlined into k_mog2_all's step loop, hipcc 7.2 drops the `mu[k] = data; v[k] = varInit` stores of a
+// newly opened mode (found by comparing the fused kernel with a step-by-step one on the same inputs; an optimisation barrier
+// or a memory round trip of the model between steps did not help).  The call costs nothing that matters here.
+__device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Modes], float (&mu)[kMog2Modes], int& nmodes,
+                                         float data, float alphaT, float prune) {
     const float Tb = 16.f, TB = 0.9f, Tg = 9.f, varInit = 15.f, varMin = 4.f, varMax = 75.f, tau = 0.5f;
     const float alpha1 = 1.f - alphaT;
-    float w[kMog2Modes], v[kMog2Modes], mu[kMog2Modes];
-    int nmodes = used[p];
-#pragma unroll
-    for (int k = 0; k < kMog2Modes; ++k) {
-        w[k] = gw[(size_t)k * n + p]; v[k] = gv[(size_t)k * n + p]; mu[k] = gm[(size_t)k * n + p];
-    }
-    const float data = (float)img[p];
     bool background = false, fitsPDF = false;
     float totalWeight = 0.f;
 #pragma unroll
@@ -79,7 +74,8 @@ __global__ void __launch_bounds__(256) k_mog2(const uint8_t* __restrict__ img, f
                 }
             }
             if (wgt < -prune) { wgt = 0.f; --nmodes; }
-            w[dst] = wgt;
+#pragma unroll
+            for (int k = 0; k < kMog2Modes; ++k) if (k == dst) w[k] = wgt;          // w[dst] = wgt without indexing the registers
             totalWeight += wgt;
         }
     }
@@ -114,11 +110,6 @@ __global__ void __launch_bounds__(256) k_mog2(const uint8_t* __restrict__ img, f
             }
         }
     }
-    used[p] = (uint8_t)nmodes;
-#pragma unroll
-    for (int k = 0; k < kMog2Modes; ++k) {
-        gw[(size_t)k * n + p] = w[k]; gv[(size_t)k * n + p] = v[k]; gm[(size_t)k * n + p] = mu[k];
-    }
     int out = 0;
     if (!background) {
         out = 255;
@@ -147,16 +138,45 @@ __global__ void __launch_bounds__(256) k_mog2(const uint8_t* __restrict__ img, f
             }
         }
     }
-    if (flow_out) flow_out[p] = (uint8_t)out;
-    // fgMask += flow * (1/6): convertTo(u8, alpha) rounds to nearest even and saturates, then a saturating add
-    int t = cv_round_x86((float)out * acc_scale + 0.f);
+    return out;
+}
+
+// All applies of Extractor::foreground in ONE launch.  A pixel's mixture depends on that pixel only, and the chain of input
+// images (grey, then the progressive medians) does not depend on the masks, so once the inputs exist the mixture never has to
+// leave the registers: 13 bytes in, 13 bytes out per pixel instead of 13 x 122 (the per-step kernel kept 5 modes x 3 floats in HBM).
+struct Mog2Inputs { const uint8_t* img[kMog2Steps]; float alphaT[kMog2Steps], prune[kMog2Steps]; };
+
+__global__ void __launch_bounds__(256) k_mog2_all(Mog2Inputs in, uint8_t* __restrict__ flows, int n, int steps) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float w[kMog2Modes], v[kMog2Modes], mu[kMog2Modes];
+#pragma unroll
+    for (int k = 0; k < kMog2Modes; ++k) w[k] = v[k] = mu[k] = 0.f;
+    int nmodes = 0;
+    for (int i = 0; i < steps; ++i) {
+        const float data = (float)in.img[i][p];
+        flows[(size_t)i * n + p] = (uint8_t)mog2_step(w, v, mu, nmodes, data, in.alphaT[i], in.prune[i]);
+    }
+}
+
+// fgMask += flow * scale: convertTo(u8, alpha) rounds to nearest even and saturates, then a saturating add
+// (matrix_expressions.cpp:270-275,1330-1336)
+__global__ void __launch_bounds__(256) k_acc_flow(uint8_t* __restrict__ acc, const uint8_t* __restrict__ flow, int n, float acc_scale) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int t = cv_round_x86((float)flow[p] * acc_scale + 0.f);
     t = t < 0 ? 0 : t > 255 ? 255 : t;
     const int sum = acc[p] + t;
     acc[p] = (uint8_t)(sum > 255 ? 255 : sum);
 }
-void launch_mog2(const uint8_t* img, float* gw, float* gv, float* gm, uint8_t* used, uint8_t* flow_or_null, uint8_t* acc,
-                 int n_px, float alphaT, float prune, float acc_scale, hipStream_t s) {
-    hipLaunchKernelGGL(k_mog2, dim3((n_px + 255) / 256), dim3(256), 0, s, img, gw, gv, gm, used, flow_or_null, acc, n_px, alphaT, prune, acc_scale);
+
+void launch_mog2_all(const uint8_t* const* imgs, const float* alphaT, const float* prune, int steps, uint8_t* flows, int n_px, hipStream_t s) {
+    Mog2Inputs in;
+    for (int i = 0; i < kMog2Steps; ++i) { in.img[i] = imgs[i < steps ? i : 0]; in.alphaT[i] = alphaT[i < steps ? i : 0]; in.prune[i] = prune[i < steps ? i : 0]; }
+    hipLaunchKernelGGL(k_mog2_all, dim3((n_px + 255) / 256), dim3(256), 0, s, in, flows, n_px, steps);
+}
+void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_acc_flow, dim3((n_px + 255) / 256), dim3(256), 0, s, acc, flow, n_px, acc_scale);
 }
 
 // ---- large-kernel median ---------------------------------------------------------------------------------------------
