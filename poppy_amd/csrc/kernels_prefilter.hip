@@ -203,7 +203,7 @@ __device__ __forceinline__ void med_update(uint32_t* __restrict__ hist, int lane
 // The source is first copied into a buffer with kMedPad replicated columns on either side (k_pad_cols), so that every
 // lane reads its window row as plain unaligned dwords without clamping; rows are clamped through the row pointer.
 constexpr int kMedPad = 48;                                 // >= 44 (ksize 89) + 3 spare bytes for the last dword
-constexpr int kMedMaxDw = 23;                               // dwords covering 89 bytes
+constexpr int kMedMaxDw = 23;                               // dwords covering 89 bytes: the largest instantiation
 
 __global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
     const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -212,6 +212,10 @@ __global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ sr
     dst[(size_t)y * Wp + xp] = src[(size_t)y * W + min(max(xp - kMedPad, 0), W - 1)];
 }
 
+// NDW = dwords per window row, a template parameter (ksize = 8 i + 1 -> NDW = 2 i + 1, one byte used of the last dword): with
+// a run-time count the unrolled update loops are chopped into basic blocks by uniform branches, and a kernel that runs ONE wave
+// per SIMD (LDS capacity) needs its ~12 instructions per value interleaved across values to hide their latencies.
+template <int NDW>
 __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
                                                          int ksize, int rows_per_block) {
     __shared__ uint32_t hist[kMedWords * kMedLanes];
@@ -223,18 +227,18 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
     for (int b = 0; b < kMedWords; ++b) hist[b * kMedLanes + lane] = 0;
     const bool live = x < W;                                  // lanes past the right edge idle along (no barriers in here)
     const int xc = live ? x : W - 1;
-    const int ndw = (ksize + 3) >> 2;                         // dwords per window row (the last one is partly used)
-    const int tail = ksize - 4 * (ndw - 1);                   // bytes used of the last dword
+    constexpr int ndw = NDW;                                  // dwords per window row (the last one is partly used)
+    const int tail = ksize - 4 * (ndw - 1);                   // bytes used of the last dword (1 for the ksizes of the chain)
     auto row_ptr = [&](int yy) { return srcp + (size_t)min(max(yy, 0), H - 1) * Wp + (kMedPad + xc - r); };
     auto load_row = [&](const uint8_t* p, uint32_t* regs) {
 #pragma unroll
-        for (int i = 0; i < kMedMaxDw; ++i)
-            if (i < ndw) __builtin_memcpy(&regs[i], p + 4 * i, 4);
+        for (int i = 0; i < NDW; ++i)
+            __builtin_memcpy(&regs[i], p + 4 * i, 4);
     };
     auto apply_row = [&](const uint32_t* regs, bool add) {
 #pragma unroll
-        for (int i = 0; i < kMedMaxDw; ++i) {
-            if (i < ndw) {
+        for (int i = 0; i < NDW; ++i) {
+            {
                 const int nb = (i == ndw - 1) ? tail : 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -242,13 +246,13 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
             }
         }
     };
-    uint32_t ra[kMedMaxDw], rs[kMedMaxDw];
+    uint32_t ra[NDW], rs[NDW];
     // warm-up: rows y_begin - r .. y_begin + r, loaded one ahead of the row being applied
     load_row(row_ptr(y_begin - r), ra);
     for (int yy = y_begin - r; yy <= y_begin + r; ++yy) {
-        uint32_t cur[kMedMaxDw];
+        uint32_t cur[NDW];
 #pragma unroll
-        for (int i = 0; i < kMedMaxDw; ++i) cur[i] = ra[i];
+        for (int i = 0; i < NDW; ++i) cur[i] = ra[i];
         if (yy < y_begin + r) load_row(row_ptr(yy + 1), ra);
         apply_row(cur, true);
     }
@@ -279,9 +283,9 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
         }
         if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
         if (y + 1 < y_end) {
-            uint32_t ca[kMedMaxDw], cs[kMedMaxDw];
+            uint32_t ca[NDW], cs[NDW];
 #pragma unroll
-            for (int i = 0; i < kMedMaxDw; ++i) { ca[i] = ra[i]; cs[i] = rs[i]; }
+            for (int i = 0; i < NDW; ++i) { ca[i] = ra[i]; cs[i] = rs[i]; }
             if (y + 2 < y_end) { load_row(row_ptr(y + r + 2), ra); load_row(row_ptr(y + 1 - r), rs); }   // rows of the NEXT step
             apply_row(ca, true);
             apply_row(cs, false);
@@ -298,7 +302,14 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
     int segs = std::max(1, 1024 / col_blocks);
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
-    hipLaunchKernelGGL(k_median_u8, dim3(col_blocks, segs), dim3(kMedLanes), 0, s, padded_tmp, dst, w, h, ksize, rows);
+    const int ndw = (ksize + 3) >> 2;
+#define MED(N) case N: hipLaunchKernelGGL(k_median_u8<N>, dim3(col_blocks, segs), dim3(kMedLanes), 0, s, padded_tmp, dst, w, h, ksize, rows); break;
+    switch (ndw) {
+        MED(1) MED(2) MED(3) MED(4) MED(5) MED(6) MED(7) MED(8) MED(9) MED(10) MED(11) MED(12) MED(13) MED(14) MED(15) MED(16)
+        MED(17) MED(18) MED(19) MED(20) MED(21) MED(22) MED(23)
+        default: static_assert(kMedMaxDw == 23, "instantiations cover 1..23"); break;   // ksize > 89 is rejected by the caller
+    }
+#undef MED
 }
 size_t median_padded_bytes(int w, int h) { return (size_t)(w + 2 * kMedPad) * h + 16; }
 bool prepare_median_u8() { return true; }
