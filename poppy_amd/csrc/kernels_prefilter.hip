@@ -181,23 +181,26 @@ void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scal
 
 // ---- large-kernel median ---------------------------------------------------------------------------------------------
 // One lane = one image column, sliding DOWN a segment of rows.  Each lane keeps its own 256-bin histogram of the current
-// ksize x ksize window in LDS, laid out [bin pair][lane] so that the 64 lanes of a wave always hit different banks (an LDS
-// access of a wave goes out as two halves of 32 lanes: no conflicts whatever the bins are), plus a 16-bin coarse
-// histogram for the search.  Counts are at most 89^2 < 2^16, so two bins share a dword (34 KB per wave instead of 68:
-// four waves per CU); a count never goes negative, so adding / subtracting 1 << 16 never borrows across the halves.
+// ksize x ksize window in LDS, plus a 16-bin coarse histogram for the search.  Counts are at most 89^2 < 2^16, so a counter
+// is 16 bits (34 KB per wave instead of 68: four waves per CU) and a bin is 32 dwords: lanes l and l + 32 share dword l, in
+// the low and the high half.  The two lanes sit in different halves of the wave's LDS access (32 lanes each), so the 32
+// lanes of one half always hit 32 different banks whatever their bins are; a count never goes negative, so adding or
+// subtracting 1 << 16 never borrows across the halves.  With this layout the increment is a per-lane constant and the
+// address is `value * 128 + lane constant`: ~4 VALU instructions per value next to its two `ds_add`/`ds_sub` (the kernel
+// runs one wave per SIMD and is bound by instruction issue, so that count IS the run time).
 // A step down = add one row of ksize values, remove one: the two rows are read as unaligned dwords (adjacent lanes read
-// overlapping, consecutive addresses), 8 bytes of each per trip so that the loads are in flight together, and every byte
-// costs two `ds_add`/`ds_sub`.  The median is the first value whose cumulative count exceeds ksize^2 / 2: 16 coarse +
-// 16 fine reads.
+// overlapping, consecutive addresses).  The median is the first value whose cumulative count exceeds ksize^2 / 2:
+// 16 coarse + 16 fine reads.
 constexpr int kMedLanes = 64;
-constexpr int kMedWords = 128 + 8;                         // dwords per lane: 256 fine bins + 16 coarse bins, two per dword
+constexpr int kMedBinBytes = kMedLanes * 2;                // one bin = 64 u16 counters in 32 dwords: lanes l and l + 32 share dword l
+constexpr int kMedCoarseOff = 256 * kMedBinBytes;          // 256 fine bins, then 16 coarse ones
+constexpr int kMedWords = (256 + 16) * kMedBinBytes / 4 / kMedLanes;   // dwords per lane (136)
 
-__device__ __forceinline__ void med_update(uint32_t* __restrict__ hist, int lane, int v, bool add) {
-    uint32_t* f = &hist[(v >> 1) * kMedLanes + lane];
-    uint32_t* c = &hist[(128 + (v >> 5)) * kMedLanes + lane];
-    const uint32_t df = 1u << ((v & 1) << 4), dc = 1u << (((v >> 4) & 1) << 4);
-    if (add) { atomicAdd(f, df); atomicAdd(c, dc); }
-    else     { atomicSub(f, df); atomicSub(c, dc); }
+__device__ __forceinline__ void med_update(char* __restrict__ lane_base, uint32_t unit, uint32_t v, bool add) {
+    uint32_t* f = reinterpret_cast<uint32_t*>(lane_base + v * kMedBinBytes);
+    uint32_t* c = reinterpret_cast<uint32_t*>(lane_base + kMedCoarseOff + (v >> 4) * kMedBinBytes);
+    if (add) { atomicAdd(f, unit); atomicAdd(c, unit); }
+    else     { atomicSub(f, unit); atomicSub(c, unit); }
 }
 
 // The source is first copied into a buffer with kMedPad replicated columns on either side (k_pad_cols), so that every
@@ -225,6 +228,12 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
     const int r = ksize >> 1, half = (ksize * ksize) >> 1;
     const int Wp = W + 2 * kMedPad;
     for (int b = 0; b < kMedWords; ++b) hist[b * kMedLanes + lane] = 0;
+    char* const hist_b = reinterpret_cast<char*>(hist);
+    char* const lane_base = hist_b + (lane & 31) * 4;         // the dword lanes l and l + 32 share, in bin 0
+    const uint32_t unit = 1u << ((lane >> 5) << 4);           // +1 in this lane's half of it
+    auto count_of = [&](int bin) {
+        return (int)*reinterpret_cast<const uint16_t*>(hist_b + bin * kMedBinBytes + (lane & 31) * 4 + (lane >> 5) * 2);
+    };
     const bool live = x < W;                                  // lanes past the right edge idle along (no barriers in here)
     const int xc = live ? x : W - 1;
     constexpr int ndw = NDW;                                  // dwords per window row (the last one is partly used)
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
                 const int nb = (i == ndw - 1) ? tail : 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < nb) med_update(hist, lane, (regs[i] >> (8 * k)) & 255, add);
+                    if (k < nb) med_update(lane_base, unit, (regs[i] >> (8 * k)) & 255u, add);
             }
         }
     };
@@ -260,26 +269,18 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
     for (int y = y_begin; y < y_end; ++y) {
         int s = 0, cb = 0, below = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {                         // first coarse bin whose cumulative count exceeds `half`
-            const uint32_t wv = hist[(128 + c) * kMedLanes + lane];
-#pragma unroll
-            for (int hv = 0; hv < 2; ++hv) {
-                s += (int)((wv >> (16 * hv)) & 0xffff);
-                const bool hit = s > half;
-                cb += hit ? 0 : 1;
-                below = hit ? below : s;
-            }
+        for (int c = 0; c < 16; ++c) {                        // first coarse bin whose cumulative count exceeds `half`
+            s += count_of(256 + c);
+            const bool hit = s > half;
+            cb += hit ? 0 : 1;
+            below = hit ? below : s;
         }
         int fb = 0;
         s = below;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t wv = hist[(cb * 8 + k) * kMedLanes + lane];
-#pragma unroll
-            for (int hv = 0; hv < 2; ++hv) {
-                s += (int)((wv >> (16 * hv)) & 0xffff);
-                fb += (s > half) ? 0 : 1;
-            }
+        for (int k = 0; k < 16; ++k) {
+            s += count_of(cb * 16 + k);
+            fb += (s > half) ? 0 : 1;
         }
         if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
         if (y + 1 < y_end) {
