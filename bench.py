@@ -13,7 +13,7 @@ rate is printed as an extra key, never as `value`.
 
 Output: ONE JSON line on rank 0 (see the driver contract), extended with
   roofline     : the fused map+remap kernel (k_warp_tile; k_warp4 for odd geometries): 16 B/px (faithful path) + 8 B/px for the lbmask it
-                 computes on the way (m2 in, mask out); the 4 B/px id-map clear it also writes is not counted,
+                 computes on the way (m2 in, mask out); the id map is frame-tagged and never cleared,
                  average launch duration measured live with HIP events on the library's stream;
   kernels      : the same for every kernel group of the frame (one extra untimed step; "warp" is the timed region's);
   cpu_baseline : oracle/ (CPU restatement, "port") timed on this box's host cores on a bounded sample.
@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel P
 ALGO_BYTES_PER_PX = {
-    "upload+clear": 0.0,                       # wait for the plan upload (the id map is cleared by the warp kernel)
+    "upload+clear": 0.0,                       # wait for the plan upload (the id map is frame-tagged: no clear)
     "raster": 4.0,                             # every pixel's id written once
     "warp": 24.0,                              # triMap 4 + c1 3 + c2 3 in, trImg1 3 + trImg2 3 out; lbmask rider: m2 4 in, mask 4 out
     "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3),      # level 0: u8 L,R + mask in; quarter-size f32 L,R,M out; geometric tail
@@ -307,11 +307,11 @@ def main():
         achieved = wk.get("GBps") or 0.0
         traffic, traffic_src = None, None            # PMC counters need their own rocprofv3 passes: quoted from profiles/
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_i_warp_pmc.json"))).get(f"{W}x{H}", {})
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_m_warp_pmc.json"))).get(f"{W}x{H}", {})
             pm = pm.get("k_warp_tile") if ctx.last_warp_kind() == 1 else pm.get("k_warp4")
             if pm:
                 traffic = pm["fetch_bytes"] + pm["write_bytes"]
-                traffic_src = "profiles/r01_i_warp_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = "profiles/r01_m_warp.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         except (OSError, ValueError):
             pass
         out = {
@@ -333,7 +333,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n,
                          "copy_ceiling_GBps": round(copy_ceiling, 1) if copy_ceiling else None,
-                         "copy_ceiling_note": "device-to-device copy of the same 14+14 B/px, measured in this run; "
+                         "copy_ceiling_note": "device-to-device copy of 14+14 B/px (buffers that fit the MALL; tools/micro/warp_skeleton.hip measures the kernel's own access mix on cold data: profiles/r01_m_warp.md), measured in this run; "
                                               "traffic / launch time is the figure to hold against it"},
             "kernels": kernels,
             "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),

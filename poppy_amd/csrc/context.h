@@ -32,7 +32,7 @@ struct FrameSlot {
     float *tmp = nullptr, *diff = nullptr;      // only for 1-pixel-wide / -high images (separate unsharp passes)
     float* unsharpF = nullptr;                  // debug copy of the float unsharp result, allocated on demand
     int32_t* triMap = nullptr;
-    bool map_clean = false;                     // triMap is all zero (the warp kernel clears it behind itself)
+    int map_tag = 0;                            // frame tag of the values last written to triMap (kernels.h: launch_raster); 0 = must be zeroed first
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
     void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete

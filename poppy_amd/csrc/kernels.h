@@ -15,22 +15,26 @@ struct PyrLevel {        // geometry of one pyramid level and of the pyrDown tha
 void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s);
 
 // --- once per frame --------------------------------------------------------------------------
-// triangle-id map: exact fillConvexPoly raster of every triangle, later index wins (atomicMax)
+// triangle-id map: exact fillConvexPoly raster of every triangle, later index wins (atomicMax).
+// A map value is id_base + triangle + 1, id_base = frame tag << kIdTagShift: tags grow from frame to frame, so this
+// frame's values beat whatever older frames left behind and the map needs no clearing in between; a reader takes
+// value - id_base when that is below 2^kIdTagShift and 0 ("no triangle") otherwise (decode_id, warp_device.h).  id_base 0
+// on a zeroed map is the plain map.
 // `work` = (triangle, row-chunk) pairs, kRasterChunkRows rows per chunk, built by the host per frame
 constexpr int kRasterChunkRows = 16;
 // `edges` = one RasterTri (frame_plan.h) per triangle: the fill-edge segments decided by the host plan
-void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s);
+constexpr int kIdTagShift = 20;                 // up to 2^20 - 1 triangles
+constexpr int kIdTagMax = 2047;                 // values stay positive: atomicMax on int32
+void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, uint32_t id_base, hipStream_t s);
 
 // copies `bytes` (rounded up to 16) from pinned, device-mapped host memory to device memory with a kernel
 void launch_upload(const void* host_mapped, void* dst, size_t bytes, hipStream_t s);
 
 // fused create_map + remap of both sources (src/algo.cpp:230-238): triMap + inverse matrices -> trImg1/2.
-// The kernel is the only reader of the id map and visits every pixel once, so it carries two per-pixel riders that
-// would otherwise be launches of their own:
-//   clear_ids  zero the id map behind the read, which is the state the next frame's raster needs;
+// The kernel visits every pixel once, so it carries a per-pixel rider that would otherwise be a launch of its own:
 //   m2 / mask  lbmask = clamp((1-mr) - m2*mr) in double with one rounding (src/algo.cpp:254-257); skipped when m2 is null.
 struct WarpExtras {
-    int clear_ids = 0;
+    uint32_t id_base = 0;                       // see launch_raster
     const float* m2 = nullptr;
     float* mask = nullptr;
     double alpha = 0, beta = 0;

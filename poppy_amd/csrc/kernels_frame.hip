@@ -124,12 +124,12 @@ struct RasterTriDev {
 };
 
 __global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, const RasterTriDev* __restrict__ edges,
-                                                const int2* __restrict__ work, int n_work, int32_t* __restrict__ map, int W, int H) {
+                                                const int2* __restrict__ work, int n_work, int32_t* __restrict__ map, int W, int H, uint32_t id_base) {
     if ((int)blockIdx.x >= n_work) return;
     const int2 item = work[blockIdx.x];
     const int t = item.x, chunk = item.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int value = t + 1;
+    const int value = (int)id_base + t + 1;
 
     if (chunk < 0) {                   // outline item: (v2->v0), (v0->v1), (v1->v2), one segment per wave
         if (wave < 3) {
@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(256) k_raster(const int* __restrict__ tri_xy, 
         }
     }
 }
-void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, hipStream_t s) {
+void launch_raster(const int* tri_xy, const void* edges, const int* work, int n_work, int32_t* triMap, int w, int h, uint32_t id_base, hipStream_t s) {
     if (n_work > 0)
-        hipLaunchKernelGGL(k_raster, dim3(n_work), dim3(256), 0, s, tri_xy, (const RasterTriDev*)edges, (const int2*)work, n_work, triMap, w, h);
+        hipLaunchKernelGGL(k_raster, dim3(n_work), dim3(256), 0, s, tri_xy, (const RasterTriDev*)edges, (const int2*)work, n_work, triMap, w, h, id_base);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -181,8 +181,7 @@ __global__ void __launch_bounds__(256) k_warp(int32_t* __restrict__ triMap, cons
     int y = blockIdx.y;
     if (x >= W) return;
     size_t p = (size_t)y * W + x;
-    int idx = triMap[p] - 1;
-    if (ex.clear_ids) triMap[p] = 0;
+    int idx = decode_id((uint32_t)triMap[p], ex.id_base) - 1;
     if (ex.m2) ex.mask[p] = mask_value(ex.m2[p], ex.alpha, ex.beta);
     float mx1 = (float)x, my1 = (float)y, mx2 = mx1, my2 = my1;
     if (idx >= 0) {
@@ -242,13 +241,13 @@ __global__ void __launch_bounds__(256) k_warp4(int4* __restrict__ triMap4, const
     if (q >= W4 || y >= H) return;
     const size_t g = (size_t)y * W4 + q;
     const int4 ids = triMap4[g];
-    if (ex.clear_ids) triMap4[g] = make_int4(0, 0, 0, 0);      // this kernel is the map's only reader: leave it cleared for the next raster
     if (ex.m2) {                                               // lbmask of the same four pixels
         const float4 m = ((const float4*)ex.m2)[g];
         ((float4*)ex.mask)[g] = make_float4(mask_value(m.x, ex.alpha, ex.beta), mask_value(m.y, ex.alpha, ex.beta),
                                             mask_value(m.z, ex.alpha, ex.beta), mask_value(m.w, ex.alpha, ex.beta));
     }
-    const int id[4] = {ids.x - 1, ids.y - 1, ids.z - 1, ids.w - 1};
+    const int id[4] = {decode_id((uint32_t)ids.x, ex.id_base) - 1, decode_id((uint32_t)ids.y, ex.id_base) - 1,
+                       decode_id((uint32_t)ids.z, ex.id_base) - 1, decode_id((uint32_t)ids.w, ex.id_base) - 1};
     float mx[2][4], my[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -137,14 +137,15 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     const __amdgpu_buffer_rsrc_t rmap = make_rsrc(triMap4, npx * 4u);
     const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
 
-    // -- ids, id-map clear, lbmask; claim cache slots -------------------------------------------------------------
+    // -- ids, lbmask; claim cache slots -------------------------------------------------------------
     int id[4] = {0, 0, 0, 0};
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
-        const u4v ids = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);
+        const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rmap, g * 16u, 0, 0);
         if (ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));   // both in flight together
-        s_ids[tid] = ids;
-        id[0] = (int)ids.x; id[1] = (int)ids.y; id[2] = (int)ids.z; id[3] = (int)ids.w;
+        id[0] = decode_id(raw.x, ex.id_base); id[1] = decode_id(raw.y, ex.id_base);
+        id[2] = decode_id(raw.z, ex.id_base); id[3] = decode_id(raw.w, ex.id_base);
+        s_ids[tid] = u4v{(unsigned)id[0], (unsigned)id[1], (unsigned)id[2], (unsigned)id[3]};
         s_tag[id[0] & (kSlots - 1)] = id[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k)
@@ -152,8 +153,6 @@ __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, c
     }
     __syncthreads();
     // -- fill the claimed slots (a slot nobody claimed holds a stale tag: its load is harmless, nobody asks for it) --
-    // this kernel is the id map's only reader: leave it cleared for the next frame's raster (issued here so that nothing waits on it)
-    if (active && ex.clear_ids) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, rmap, g * 16u, 0, 0);
     const int fslot = tid >> 2, fpart = tid & 3;                    // 64 slots x 4 parts, then the 64 fifth parts
     const u4v fill0 = __builtin_amdgcn_raw_buffer_load_b128(rrec, (uint32_t)s_tag[fslot] * 80u + (uint32_t)fpart * 16u, 0, 0);
     u4v fill1 = {0u, 0u, 0u, 0u};

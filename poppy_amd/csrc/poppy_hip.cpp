@@ -177,7 +177,7 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         HIPCHK(c, hipMalloc((void**)&f.tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.out, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.triMap, P * 4));
-        f.map_clean = false;
+        f.map_tag = 0;
         HIPCHK(c, hipMalloc((void**)&f.pyrL, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrR, off3 * 4));
         HIPCHK(c, hipMalloc((void**)&f.pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrM, off1 * 4));
         if (W < 2 || H < 2) { HIPCHK(c, hipMalloc((void**)&f.tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&f.diff, P * 12)); }
@@ -452,16 +452,23 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, f.done, 0));    // the frame that last used this slot's buffers
     if (all_marks) th.mark(nullptr);
     // -- independent of the previous frame ---------------------------------------------------------------------
-    // the id map is left cleared by the warp kernel of the frame before (its only reader); only a slot's first frame
-    // and frames after a debug frame (which keeps the map for poppy_hip_debug_fetch) need the memset
-    if (!f.map_clean) HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
+    // The id map is not cleared between frames: every frame writes its ids above a tag that grows from frame to frame, and
+    // its warp kernel reads everything else as "no triangle" (kernels.h: launch_raster).  A memset is needed for a slot's
+    // first frame, when the tags run out (every 2047 frames), and around debug frames, which keep a plain map for
+    // poppy_hip_debug_fetch.
+    if (c->debug || f.map_tag == 0 || f.map_tag >= kIdTagMax) {
+        HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
+        f.map_tag = 0;
+    }
+    if (!c->debug) ++f.map_tag;
+    const uint32_t id_base = (uint32_t)f.map_tag << kIdTagShift;
     // Chained frames: the host waits for the plan upload itself (it is ~100 us ahead of the GPU, the copy takes ~10) instead of
     // putting a cross-stream wait in front of the raster, which costs the critical path ~4 us per frame.
     static const bool host_wait = getenv("POPPY_HIP_STREAMWAIT") == nullptr;
     if (chained && host_wait) HIPCHK(c, hipEventSynchronize(f.uploaded));
     else HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
     if (all_marks) th.mark("upload+clear");
-    launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, head);
+    launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, id_base, head);
     if (all_marks) th.mark("raster");
     if (s != head) {
         HIPCHK(c, hipEventRecord(f.prepared, head));
@@ -470,9 +477,8 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     // -- chained mode: corrected1 is the previous frame (src/poppy.hpp:217) -------------------------------------
     if (c->cur1_ready && c->cur1_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->cur1_ready, 0));
     WarpExtras ex;
-    ex.clear_ids = c->debug ? 0 : 1;
+    ex.id_base = id_base;
     ex.m2 = c->m2; ex.mask = f.pyrM; ex.alpha = 1.0 - mask; ex.beta = -mask;       // lbmask rides along (level 0 of pyrM)
-    f.map_clean = ex.clear_ids != 0;
     if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
         hipEvent_t t0 = tm.take(nullptr), t1 = tm.take("warp");
         if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);

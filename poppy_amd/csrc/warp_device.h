@@ -6,6 +6,12 @@
 
 namespace poppy_hip {
 
+// id-map value -> triangle + 1, or 0 when the value is not of this frame (kernels.h: launch_raster)
+__device__ __forceinline__ int decode_id(uint32_t raw, uint32_t id_base) {
+    const uint32_t d = raw - id_base;
+    return d < (1u << 20) ? (int)d : 0;
+}
+
 // lbmask = clamp((1-mr) - m2*mr)            arithm.simd.hpp:1160-1216,1808 (double, one rounding)
 __device__ __forceinline__ float mask_value(float m2, double alpha, double beta) {
     double t = (double)m2 * beta + 0.0;

@@ -239,3 +239,37 @@ def test_strong_deformation_vs_oracle(ctx, w, h):
         for name in ("triMap", "trImg1", "trImg2"):
             _same(f"{name} {w}x{h} s={s}", ctx.fetch(name), d[name])
         _same("frame", got, want)
+
+
+@pytest.mark.parametrize("w,h", [(160, 96), (97, 61)])
+def test_id_map_is_not_cleared_between_frames(w, h):
+    """Outside debug mode the triangle-id map is never cleared: every frame writes its ids above a growing frame tag and
+    reads older values as "no triangle" (poppy_amd/csrc/kernels.h: launch_raster).  The point sets leave a wide
+    uncovered margin (id 0 = identity map there) and the triangles move from frame to frame, so stale ids would show;
+    with two frame slots, 4300 frames take each slot across the tag wrap-around (2047 frames).  Checked against debug-mode
+    frames (plain map, cleared by memset), which the tests above pin to the oracle.  160x96 runs the tiled kernel, 97x61 the general one."""
+    rng = np.random.default_rng(w)
+    n = 14
+    p1 = np.stack([rng.uniform(0.3 * w, 0.7 * w, n), rng.uniform(0.3 * h, 0.7 * h, n)], 1).astype(np.float32)
+    p2 = (p1 + rng.normal(0, 4.0, (n, 2))).astype(np.float32)
+    c1 = synth.textured_bgr(w, h, 31); c2 = synth.textured_bgr(w, h, 32)
+    g = synth.unit_field(w, h, 4)
+    shapes = [0.15, 0.5, 0.85, 0.3]
+    ref = capi.Context(0); ref.set_debug(True)
+    ref.pair_load(c1, c2, g, p1, p2)
+    want = [ref.render(s, s, chain=False) for s in shapes]
+    assert (ref.fetch("triMap") == 0).mean() > 0.3           # the uncovered margin is really there
+    ref.close()
+    os.environ["POPPY_HIP_SLOTS"] = "2"
+    try:
+        c = capi.Context(0)
+    finally:
+        del os.environ["POPPY_HIP_SLOTS"]
+    c.pair_load(c1, c2, g, p1, p2)
+    check = set(range(0, 6)) | set(range(4084, 4108)) | {4299}
+    for j in range(4300):
+        k = (j * 7) % len(shapes) if j % 3 else j % len(shapes)
+        got = c.render(shapes[k], shapes[k], chain=False, fetch=j in check)
+        if j in check:
+            _same(f"{w}x{h} frame {j}", got, want[k])
+    c.close()
