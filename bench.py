@@ -14,7 +14,8 @@ rate is printed as an extra key, never as `value`.
 Output: ONE JSON line on rank 0 (see the driver contract), extended with
   roofline     : the fused map+remap kernel (k_warp_tile; k_warp4 for odd geometries): 16 B/px (faithful path) + 8 B/px for the lbmask it
                  computes on the way (m2 in, mask out); the id map is frame-tagged and never cleared,
-                 average launch duration measured live with HIP events on the library's stream;
+                 average launch duration measured live with HIP events on the library's stream (one launch in seven of
+                 the timed region carries the stamps: `launches_timed`);
   kernels      : the same for every kernel group of the frame (one extra untimed step; "warp" is the timed region's);
   cpu_baseline : oracle/ (CPU restatement, "port") timed on this box's host cores on a bounded sample.
 """
@@ -181,7 +182,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_timing(2)          # HIP events around the roofline kernel (k_warp_tile) only, on the stream it is launched on
+    ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch (k_warp_tile), one launch in seven, on the stream it is launched on
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

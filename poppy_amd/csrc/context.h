@@ -23,6 +23,8 @@
 
 using namespace poppy_hip;
 
+constexpr int kWarpStampStride = 7;
+
 struct FrameSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;           // end of the frame last rendered here
@@ -82,6 +84,7 @@ struct poppy_hip_ctx {
     AutoAligner aligner;
     uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
+    unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
     double last_detail[2] = {0, 0};
     // diagnostics
