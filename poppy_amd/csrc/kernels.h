@@ -92,8 +92,10 @@ void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, fl
 // unsharp_mask(lapBlend, 1, amount, 0.3) + convertTo(CV_8U, 255)  (src/util.cpp:113-148, src/algo.cpp:263-265)
 // d_amount (device, may be null): when set, the tile kernel reads the amount from there instead of the argument, so
 // that the launch can sit in a captured graph while the value changes per frame.
+// `done` (optional): an event that completes with the launch's last kernel; for the tile kernel it rides on the dispatch
+// itself instead of being a packet of its own behind it.
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s);
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done = nullptr);
 
 // u8 cross-dissolve fallback (src/poppy.hpp:129)
 void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s);

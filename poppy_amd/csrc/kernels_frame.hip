@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
 }
 
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s) {
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done) {
     if (w > 1 && h > 1) {
         // norm(d) >= threshold with norm = correctly rounded sqrt of a double: equivalent to |d|^2 >= x*, where x* is the
         // smallest double whose square root rounds to >= threshold (found here with the host's IEEE sqrt).
@@ -843,13 +843,14 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
         dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
-        hipLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
+        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);
     hipLaunchKernelGGL(k_gauss_row, ge, dim3(256), 0, s, src, tmpRow, w, h);
     hipLaunchKernelGGL(k_gauss_col_diff, ge, dim3(256), 0, s, src, tmpRow, diff, w, h);
     hipLaunchKernelGGL(k_median_apply, gp, dim3(256), 0, s, src, diff, out_u8, out_f32_or_null, w, h, amount, threshold);
+    if (done) (void)hipEventRecord(done, s);
 }
 
 // ------------------------------------------------------------------------------------------------

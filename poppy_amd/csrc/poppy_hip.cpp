@@ -52,6 +52,8 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     if (const char* e = getenv("POPPY_HIP_SLOTS")) k = atoi(e);
     c->slots.resize(std::max(2, std::min(k, 8)));
     for (FrameSlot& f : c->slots) {
+        // (hipEventDisableSystemFence on `done` was measured: +0.6-1 % frames/s; not used, because frame downloads to the
+        // host are ordered by this event)
         if (hipEventCreateWithFlags(&f.prepared, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&f.uploaded, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) {
@@ -331,7 +333,7 @@ static_assert(kPlanRasterRows == kRasterChunkRows, "the plan's work list and k_r
 
 // pyrdown .. unsharp of one slot.  Every argument is fixed for the life of the pair (the per-frame unsharp amount is
 // read from the slot's plan blob), which is what lets the whole sequence be captured into one graph launch.
-static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* tm, float amount, bool debug) {
+static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* tm, float amount, bool debug, hipEvent_t done = nullptr) {
     const int W = c->W, H = c->H, L = c->cfg.pyramid_levels;
     const int ft = c->first_tail < L ? c->first_tail : L;
     static const bool fuse = getenv("POPPY_HIP_NOFUSE") == nullptr;
@@ -371,7 +373,7 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         --j;
     }
     if (tm) tm->mark("collapse");
-    launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s);
+    launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s, done);
     if (tm) tm->mark("unsharp");
 }
 
@@ -494,10 +496,14 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
+    // The frame's completion event rides on its last dispatch when the kernels are launched one by one: an event record of
+    // its own behind the last kernel leaves the stream idle for ~6 us before the next frame's first kernel.
+    static const bool done_packet = getenv("POPPY_HIP_DONE_PACKET") != nullptr;
+    const bool done_rides = !use_graph && !all_marks && !done_packet;
     if (use_graph) HIPCHK(c, hipGraphLaunch(f.body, s));
-    else enqueue_body(c, f, s, all_marks ? &tm : nullptr, (float)(1.0 - amount), c->debug);
+    else enqueue_body(c, f, s, all_marks ? &tm : nullptr, (float)(1.0 - amount), c->debug, done_rides ? f.done : nullptr);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(f.done, s));
+    if (!done_rides) HIPCHK(c, hipEventRecord(f.done, s));
     if (s != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, f.done, 0));   // anything queued on `stream` later sees this frame
     c->last_slot = fi;
     if (chain) {                                   // src/poppy.hpp:217-218

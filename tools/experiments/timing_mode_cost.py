@@ -19,5 +19,7 @@ def run(mode, steps=10):
     ctx.sync(); dt = time.perf_counter() - t0
     if mode: ctx.timing_summary()
     return steps * N / dt
+if len(sys.argv) > 1 and sys.argv[1] == "off":      # only the untimed loop (for a kernel trace of the plain frame loop)
+    print("timing off: %.0f fps" % run(0)); sys.exit(0)
 for rep in range(3):
     print("timing off: %.0f fps   warp timestamps on: %.0f fps" % (run(0), run(2)))
