@@ -115,9 +115,20 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
     for (int l = 0; l < kOrbLevels; ++l) {
         const int n = h_counts[l], lw = S.lv[l].w;
         const int* c = h_cand + (size_t)l * cap * 2;
+        // raster order = FAST's emission order (fast.cpp:271-290).  The kernel emits candidates in whatever order its
+        // atomics land; positions are unique, so a counting pass over the rows and a sort inside each row restore the
+        // order in O(n) (a comparison sort of the 10^5 candidates of a 1080p level costs milliseconds).
         std::vector<std::pair<int, int>> keyed(n);
-        for (int i = 0; i < n; ++i) keyed[i] = {c[2 * i], c[2 * i + 1]};
-        std::sort(keyed.begin(), keyed.end());                  // raster order = FAST's emission order (fast.cpp:271-290)
+        {
+            const int lh = S.lv[l].h;
+            std::vector<int> row_at(lh + 1, 0);
+            for (int i = 0; i < n; ++i) ++row_at[c[2 * i] / lw + 1];
+            for (int y = 0; y < lh; ++y) row_at[y + 1] += row_at[y];
+            std::vector<int> fill(row_at.begin(), row_at.end() - 1);
+            for (int i = 0; i < n; ++i) keyed[fill[c[2 * i] / lw]++] = {c[2 * i], c[2 * i + 1]};
+            for (int y = 0; y < lh; ++y)
+                if (row_at[y + 1] - row_at[y] > 1) std::sort(keyed.begin() + row_at[y], keyed.begin() + row_at[y + 1]);
+        }
         k.resize(n);
         for (int i = 0; i < n; ++i) k[i] = Cand{keyed[i].first % lw, keyed[i].first / lw, l, (float)keyed[i].second};
         retain_best(k, 2 * quota[l]);
