@@ -127,9 +127,10 @@ int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, do
     if (n) { memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8); }
     drop_out_of_image(a, b, W, H);
     if (a.empty()) { *n_out = 0; if (imd) *imd = 0; return POPPY_OK; }     // caller falls back to the dissolve (poppy.hpp:125)
-    const double d = morph_distance_ref(a, b, W, H);
+    std::vector<PointPair> pairs;
+    const double d = morph_distance_pairs(a, b, W, H, pairs);
     if (imd) *imd = d;
-    match_and_prepare(a, b, W, H, tol, d);
+    match_and_prepare_from(pairs, a, b, W, H, tol, d);
     *n_out = (int)a.size();
     if (o1) memcpy(o1, a.data(), a.size() * 8);
     if (o2) memcpy(o2, b.data(), b.size() * 8);

@@ -8,10 +8,17 @@
 // The reference translation unit is `using namespace std`, so hypot(float,float) resolves to the float overload.
 #include "point_match.h"
 #include <algorithm>
+#include <thread>
 #include <cmath>
 #include <limits>
 
 namespace poppy_hip {
+
+// glibc's hypotf for finite floats is (float)sqrt((double)x*x + (double)y*y): the squares are exact in double, their sum and
+// the root are each rounded once, and the final rounding to float never meets a double-rounding case (checked against
+// hypotf on 4*10^8 inputs, tools/micro/hypotf_check.c; the candidate-scoring kernel relies on the same identity).  The
+// libm call costs several times this, and the matcher evaluates it ~10^6 times per pair.
+static inline float hyp(float x, float y) { return (float)std::sqrt((double)x * (double)x + (double)y * (double)y); }
 
 void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs) {
     std::vector<P2f> pool = src2;
@@ -23,11 +30,11 @@ void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, st
         int pick = -1;
         for (size_t j = 0; j < pool.size(); ++j) {
             if (taken[j] || (pool[j].x == -1 && pool[j].y == -1)) continue;     // (-1,-1) doubles as the tombstone value
-            double d = hypotf(pool[j].x - a.x, pool[j].y - a.y);
+            double d = hyp(pool[j].x - a.x, pool[j].y - a.y);
             if (d < best) { best = d; pick = (int)j; }
         }
         if (pick < 0) continue;
-        pairs.push_back(PointPair{(double)hypotf(pool[pick].x - a.x, pool[pick].y - a.y), a, pool[pick]});
+        pairs.push_back(PointPair{(double)hyp(pool[pick].x - a.x, pool[pick].y - a.y), a, pool[pick]});
         taken[pick] = 1;
     }
     // multimap<double,...>: ascending keys, equal keys in insertion order
@@ -239,19 +246,52 @@ double morph_distance_combine(float total, size_t n_pairs, float inner1_sum, flo
     return (double)r;
 }
 
-double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h) {
-    std::vector<PointPair> pairs;
+// Both O(n^2) offset sums of morph_distance at once: each is one chain of float additions in (i, j) order, bound by the
+// adder's latency, so the two chains are interleaved.
+static void inner_offset_sums(const std::vector<P2f>& p1, const std::vector<P2f>& p2, float* s11, float* s21) {   // sizes equal
+    float a1 = 0, a2 = 0;
+    const size_t n = p1.size();
+    for (size_t i = 0; i < n; ++i) {
+        const P2f u = p1[i], v = p2[i];
+        for (size_t j = 0; j < n; ++j) {
+            const float wx = p1[j].x, wy = p1[j].y;
+            a1 += (u.x - wx) + (u.y - wy);
+            a2 += (v.x - wx) + (v.y - wy);
+        }
+    }
+    *s11 = a1; *s21 = a2;
+}
+
+// morph_distance, keeping the greedy pairing for the caller (match_and_prepare_from pairs the same two sets again)
+double morph_distance_pairs(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h, std::vector<PointPair>& pairs) {
+    float s11 = 0, s21 = 0;
+    const bool same_n = p1.size() == p2.size();     // inner_offset_sum(p2, p1) indexes p1 with p2's count
+    std::thread sums;
+    if (same_n && p1.size() >= 128) sums = std::thread([&]() { inner_offset_sums(p1, p2, &s11, &s21); });
     greedy_pairs(p1, p2, pairs);
     float total = 0;
-    for (const PointPair& e : pairs) total += hypotf(e.b.x - e.a.x, e.b.y - e.a.y);
+    for (const PointPair& e : pairs) total += hyp(e.b.x - e.a.x, e.b.y - e.a.y);
+    const double a1 = hull_area(p1), a2 = hull_area(p2);
+    if (sums.joinable()) sums.join();
+    else if (same_n) inner_offset_sums(p1, p2, &s11, &s21);
+    else { s11 = inner_offset_sum(p1, p1); s21 = inner_offset_sum(p2, p1); }
     // the second inner sum runs the second set against the FIRST, as in the reference
-    return morph_distance_combine(total, pairs.size(), inner_offset_sum(p1, p1), inner_offset_sum(p2, p1), p1.size(), p2.size(),
-                                  hull_area(p1), hull_area(p2), w, h);
+    return morph_distance_combine(total, pairs.size(), s11, s21, p1.size(), p2.size(), a1, a2, w, h);
+}
+
+double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h) {
+    std::vector<PointPair> pairs;
+    return morph_distance_pairs(p1, p2, w, h, pairs);
 }
 
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist) {
     std::vector<PointPair> pairs;
     greedy_pairs(s1, s2, pairs);
+    match_and_prepare_from(pairs, s1, s2, w, h, tolerance, initial_morph_dist);
+}
+
+void match_and_prepare_from(const std::vector<PointPair>& pairs, std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h,
+                            double tolerance, double initial_morph_dist) {
     const size_t n = pairs.size();
     double sum = 0.0;
     for (const PointPair& e : pairs) sum += e.dist;

@@ -21,6 +21,10 @@ float inner_offset_sum(const std::vector<P2f>& a, const std::vector<P2f>& b);   
 double morph_distance_combine(float total, size_t n_pairs, float inner1_sum, float inner2_sum, size_t n1, size_t n2,
                               double area1, double area2, int w, int h);
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist);
+// the two steps sharing one greedy pairing (the reference pairs the same sets twice: morph_distance, then match)
+double morph_distance_pairs(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h, std::vector<PointPair>& pairs);
+void match_and_prepare_from(const std::vector<PointPair>& pairs, std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h,
+                            double tolerance, double initial_morph_dist);
 
 void ratio_symmetry(const int* knn12, int n1, const int* knn21, int n2, float ratio, std::vector<int>& out3);      // experiments.hpp:14-144
 void add_image_corners(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h);                              // add_corners
