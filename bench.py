@@ -55,7 +55,7 @@ def synth_inputs():
     return a, b, g, p1, p2
 
 
-def cpu_baseline(a, b, g, p1, p2, frames=3):
+def cpu_baseline(a, b, g, p1, p2, frames=20):
     """oracle/ timed on the host: `frames` chained 1080p frames of the same workload, one thread."""
     import oracle_lib as O
     from poppy_amd import capi
