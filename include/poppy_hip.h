@@ -98,6 +98,27 @@ double poppy_frame_ratio(int j, int number_of_frames, double phase);
  * only during the call.  write may be NULL (frames stay on the device: benchmark mode).              */
 typedef void (*poppy_write_cb)(void* user, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_frames(poppy_hip_ctx* ctx, double phase, poppy_write_cb write, void* user);
+/* phase == 0 / phase == 1 follow the reference's short-circuit (src/poppy.hpp:54-70): number_of_frames copies of image 1 /
+ * image 2 as they were handed to the pair set-up (with auto-align: the UNALIGNED image 2), no frame is rendered.            */
+
+/* The whole of poppy::morph(img1, img2, corrected1, corrected2, phase, distance, output) (src/poppy.hpp:46-248) in one call,
+ * in the reference's order: phase == 0 / 1 short-circuits (:54-70, before any feature work) -> pair set-up from the raw
+ * images (poppy_hip_pair_begin) -> the printed morph distance (:142-159) -> frame loop with the reference's scheduler
+ * (:177-235; one frame when 0 < phase < 1).  distance != 0 reproduces --distance: the value is computed, no frame is
+ * written and the call returns POPPY_OK (the reference prints it and calls exit(0), :159-163; the shim does that).
+ * *morph_distance (may be NULL) receives the printed value whenever the set-up ran.
+ * No point pairs: poppy::morph means to write number_of_frames frames of img2*phase + img1*(1-phase) (:125-134) — with the
+ * phase ARGUMENT, i.e. -1 in the default mode — but the reference never gets there: with empty point lists Matcher::find ->
+ * morph_distance -> cv::convexHull throws first (tried with the golden generator).  This call writes the intended
+ * fallback frames and returns POPPY_E_NOMATCH so that a caller can tell; corrected2 comes from poppy_hip_pair_corrected2. */
+int poppy_hip_morph(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
+                    int width, int height, double phase, int distance, poppy_write_cb write, void* user,
+                    double* morph_distance);
+/* The value poppy::morph prints as "morph distance" for the resident pair (src/poppy.hpp:142-159: clip_points, make_uniq,
+ * truncate to the shorter list, morph_distance) — what --distance reports.  Host arithmetic, computed on demand.          */
+int poppy_hip_pair_distance(poppy_hip_ctx* ctx, double* morph_distance);
+/* the same value from explicit point lists (host only, no ctx): points as Matcher::prepare leaves them */
+int poppy_printed_morph_distance(const float* points1, const float* points2, int n_points, int width, int height, double* morph_distance);
 
 /* ---- once-per-pair stage (outer boundary: poppy::morph, src/poppy.hpp:46-157) -------------------
  * ORB::create(nfeatures)->detect(gray, keypoints)  (src/extractor.cpp:45,77-78).  gray is an 8-bit single
@@ -147,6 +168,9 @@ int poppy_perspective_from4(const float* src4, const float* dst4, double* m3x3);
 /* Matcher::find (general branch) + Matcher::prepare on raw point lists (src/matcher.cpp:118-131,246-332):
  * drop out-of-image pairs, morph distance, greedy nearest-neighbour pairing, threshold filter, 4 corners.
  * Host only.  out1/out2 need room for n_points + 4 pairs.                                              */
+/* Self-check of the matcher's hypotf (point_match.cpp): compares its closed form with the libm hypotf the library is linked
+ * against on n pseudo-random float pairs; returns the number of mismatches (0 expected).  Host only.                    */
+long poppy_hypotf_selfcheck(long n, uint64_t seed);
 int poppy_match_points(const float* points1, const float* points2, int n_points, int width, int height,
                        double match_tolerance, float* out1, float* out2, int* n_out, double* initial_morph_distance);
 
@@ -154,7 +178,7 @@ int poppy_match_points(const float* points1, const float* points2, int n_points,
  * three times per pair: poppy.hpp:52,116 and matcher.cpp:17): grey -> 13 x MOG2 on progressively median-blurred copies
  * (k = 1, 9, ..., 89), accumulated and Gaussian-smoothed -> log mask -> x grey -> equalizeHist.  Returns the 8-bit
  * `goodFeatures` image (width*height bytes).  Bit-exact with the reference.  First part of the pre-ORB filter chain
- * (SURVEY 8f-1); the rest (dft_detail2, Gabor bank) is not on the GPU yet, so poppy_hip_pair_begin still fails.
+ * (SURVEY 8f-1); poppy_hip_orb_input / poppy_hip_gabor_field are the rest, poppy_hip_pair_begin runs all of it.
  * debug (optional, host pointers, each may be NULL): grey w*h; stages 50 planes of w*h in the order flow0, acc0, then
  * 12 x (med, flow, acc, blur); floats 3 planes of w*h: lin, logged, finalMask; masked w*h.                      */
 typedef struct poppy_foreground_debug {
@@ -201,6 +225,9 @@ int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail
 int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
 int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
 int poppy_radial_gradient(int width, int height, float* out);
+/* Host only: the plan of the length-n transform dft_detail2's kernels run (pass order, load permutation, float twiddles; see
+ * poppy_amd/csrc/dft_exact.cpp).  factors needs room for 34 ints, itab for n ints, wave for 2n floats.  For the test suite. */
+int poppy_dft_plan(int n, int* factors, int* n_factors, int* itab, float* wave);
 
 /* blur_margin (src/util.cpp:574-602), the CLI's padding step before poppy::morph (src/poppy.cpp:233-240,293-308): the image
  * centred in a union_width x union_height canvas, the four margin strips Gaussian-blurred (127x127, sigma 6).  Bit-exact.   */

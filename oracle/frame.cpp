@@ -60,4 +60,20 @@ int morph_images(const ImageU8& c1, const ImageU8& c2, const ImageF& gabor2,
     return 0;
 }
 
+// The no-match fallback  Mat blend = ((img2 * phase) + (img1 * (1.0 - phase)))  (src/poppy.hpp:129).  The MatExpr sum of two
+// scaled 8-bit images is one addWeighted(img2, phase, img1, 1 - phase, 0) (matrix_expressions.cpp MatOp_AddEx); for 8-bit
+// inputs the weights are narrowed to float and a pixel is  a*alpha + (b*beta + gamma)  in float with a rounding after every
+// operation (v_fma is unfused in the SSE3-baseline build), then cvRound + saturate (arithm.simd.hpp:1705-1755).
+void dissolve_u8(const ImageU8& img1, const ImageU8& img2, double phase, ImageU8& out) {
+    const float alpha = (float)phase, beta = (float)(1.0 - phase);
+    out = ImageU8(img1.w, img1.h, img1.c);
+    const size_t n = (size_t)img1.w * img1.h * img1.c;
+    for (size_t i = 0; i < n; ++i) {
+        const float t = (float)img1.d[i] * beta + 0.f;
+        const float v = (float)img2.d[i] * alpha + t;
+        const int r = cv_round_f(v);
+        out.d[i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+    }
+}
+
 }  // namespace oracle

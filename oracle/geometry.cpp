@@ -367,8 +367,11 @@ void draw_line8(ImageI& img, IPt p1, IPt p2, int32_t value) {
 
 }  // namespace
 
-void fill_triangle(ImageI& img, const IPt* v, int32_t value) {
-    const int npts = 3;
+void fill_triangle(ImageI& img, const IPt* v, int32_t value) { fill_convex(img, v, 3, value); }
+
+// FillConvexPoly for any convex polygon (drawing.cpp:1093-1255); Poppy only ever passes triangles, the general form exists so
+// that OpenCV's own known-answer test (imgproc/test/test_drawing.cpp:432-462: a 4-point polygon) can pin this routine.
+void fill_convex(ImageI& img, const IPt* v, int npts, int32_t value) {
     const int SHIFT = 16;
     const int64_t ONE = 1 << SHIFT;
     int W = img.w, H = img.h;

@@ -472,12 +472,26 @@ static void dump_astage() {
     if (!s1.empty()) {
         matcher.prepare(c1, c2, s1, s2);
         dump_pts("prepared1", s1); dump_pts("prepared2", s2);
+        // the value poppy::morph prints before --distance exits (src/poppy.hpp:142-159), from the same reference helpers
+        vector<Point2f> q1 = s1, q2 = s2, u1, u2;
+        clip_points(q1, a.cols, a.rows); make_uniq(q1, u1);
+        clip_points(q2, a.cols, a.rows); make_uniq(q2, u2);
+        if (u1.size() > u2.size()) u1.resize(u2.size()); else u2.resize(u1.size());
+        dump_f64("printedMorphDist", { morph_distance(u1, u2, a.cols, a.rows) });
     }
 
     // whole call
     Mat cc1, cc2; CollectWriter out;
     poppy::morph(a, b, cc1, cc2, phase, false, out);
     for (size_t i = 0; i < out.frames.size(); ++i) dump_mat("frame" + std::to_string(i), out.frames[i]);
+    // extra single-frame phase-mode calls: init(numberOfFrames = 1), morph(phase = t)  (what one frame of the sharded job is)
+    for (size_t k = 4; k < cfg.size(); ++k) {
+        poppy::init(false, 1, 1.0, autoAlign, false, false, false, false, 30, levels, "FFV1", false, 8);
+        Mat e1, e2; CollectWriter eo;
+        poppy::morph(a, b, e1, e2, cfg[k], false, eo);
+        if (eo.frames.size() != 1) { fprintf(stderr, "FATAL: phase call wrote %zu frames\n", eo.frames.size()); exit(2); }
+        dump_mat("phase" + std::to_string(k - 4) + "_frame", eo.frames[0]);
+    }
     fprintf(stderr, "astage: nfeatures=%d kps=%zu/%zu found=%zu frames=%zu\n", nfeatures, kps.first.size(), kps.second.size(), s1.size(), out.frames.size());
 }
 
@@ -698,6 +712,17 @@ static void dump_align() {
     }
 }
 
+// img2*phase + img1*(1.0-phase) exactly as poppy::morph's no-match fallback writes it (src/poppy.hpp:125-134)
+static void dump_dissolve() {
+    Mat img1 = read_mat("img1"), img2 = read_mat("img2");
+    vector<double> ph = read_f64("phases");
+    for (size_t k = 0; k < ph.size(); ++k) {
+        const double phase = ph[k];
+        Mat blend = ((img2 * phase) + (img1 * (1.0 - phase)));
+        dump_mat("blend" + std::to_string(k), blend);
+    }
+}
+
 static void dump_logcheck() {      // cv::log / cv::magnitude on given floats (debugging aid for the oracle)
     Mat x = read_mat("x"), y;
     log(x, y);
@@ -720,6 +745,7 @@ int main(int argc, char** argv) {
     else if (mode == "detail") dump_detail();
     else if (mode == "logcheck") dump_logcheck();
     else if (mode == "margin") dump_margin();
+    else if (mode == "dissolve") dump_dissolve();
     else { fprintf(stderr, "unknown mode\n"); return 1; }
     return 0;
 }

@@ -28,12 +28,28 @@ def write_in(case, name, arr):
 
 
 # ---- case tables (single source of truth for generator AND tests) --------------------------
+DISSOLVE = {
+    # name: (w, h, phases): img2*phase + img1*(1-phase), the no-match fallback expression (src/poppy.hpp:129); -1 is what the
+    # default CLI mode passes, 2.5 saturates both ways
+    "x_dissolve_200x150": (200, 150, [-1.0, 0.0, 0.3, 0.5, 1.0 / 3.0, 1.0, 2.5]),
+}
+
+
+def dissolve_inputs(name):
+    w, h, ph = DISSOLVE[name]
+    return dict(img1=synth.textured_bgr(w, h, 71), img2=synth.textured_bgr(w, h, 72), phases=np.array(ph, dtype=np.float64))
+
+
 BSTAGE = {
     # name: (w, h, npts, ratios[(shape, mask)], levels)
     "b_64x48": (64, 48, 12, [(0.0, 0.0), (1 / 60, 1 / 60), (0.25, 0.25), (0.5, 0.5), (1.0, 1.0)], 64),
     "b_256x256": (256, 256, 60, [(1 / 60, 1 / 60), (0.5, 0.5), (0.9, 0.7)], 64),
     "b_509x381": (509, 381, 150, [(0.5, 0.5), (0.3, 0.3)], 64),
     "b_1920x1080": (1920, 1080, 440, [(0.5, 0.5)], 64),
+    # shallow pyramids (--pyramid N): the coarsest level is far larger than one workgroup's LDS
+    "b_640x480_lv4": (640, 480, 100, [(0.5, 0.5), (0.2, 0.8)], 4),
+    "b_1920x1080_lv4": (1920, 1080, 440, [(0.4, 0.4)], 4),
+    "b_320x200_lv1": (320, 200, 40, [(0.5, 0.5)], 1),
 }
 ORB = {
     # name: (w, h, [nfeatures])
@@ -54,6 +70,14 @@ ASTAGE = {
     "a_512x384_chain": (512, 384, 4, -1.0, 64),
     "a_256x256_align": (256, 256, 3, -1.0, 64, 1),      # enable_auto_align (src/matcher.cpp:29-32)
     "a_384x288_align": (384, 288, 2, -1.0, 64, 1),
+    # round 2: (w, h, nframes, phase, levels, align, extra single-frame phases, input variant)
+    "a_512x512_chain30": (512, 512, 30, -1.0, 64, 0, ()),                 # BASELINE.json configs[0]: frames hash-only
+    "a_1920x1080_chain60": (1920, 1080, 60, -1.0, 64, 0, (0.25, 0.5)),    # configs[1] from the raw pair + two phase-mode frames
+    "a_3840x2160_phase": (3840, 2160, 1, 0.5, 64, 0, ()),                 # configs[2]: one 4K phase-mode frame
+    "a_256x256_phase01": (256, 256, 3, 0.0, 64, 0, (1.0,)),               # phase == 0 / == 1 short-circuits (src/poppy.hpp:54-70)
+    # (A featureless second image does NOT reach the linear-blend fallback of src/poppy.hpp:125-134: with empty point lists
+    #  Matcher::find -> morph_distance -> cv::convexHull throws "total >= 0 && (depth == CV_32F || depth == CV_32S)" first —
+    #  tried with the generator.  The fallback expression itself is pinned by x_dissolve_* below.)
 }
 
 
@@ -129,10 +153,16 @@ def match_inputs(name):
 
 
 def astage_inputs(name):
-    w, h, nframes, phase, levels = ASTAGE[name][:5]
-    align = ASTAGE[name][5] if len(ASTAGE[name]) > 5 else 0
+    t = ASTAGE[name]
+    w, h, nframes, phase, levels = t[:5]
+    align = t[5] if len(t) > 5 else 0
+    extra = list(t[6]) if len(t) > 6 else []
+    variant = t[7] if len(t) > 7 else ""
     a, b = synth.gen_pair(w, h)
-    return dict(img1=a, img2=b, cfg=np.array([nframes, phase, levels] + ([align] if align else []), dtype=np.float64))
+    if variant == "flat2":                          # a featureless second image: ORB finds nothing, the point lists come back empty
+        b = np.full_like(a, 77)                     # (the reference throws on it, see ASTAGE; kept for the library's own error test)
+    cfg = [nframes, phase, levels] + ([align] if (align or len(t) > 6) else []) + extra
+    return dict(img1=a, img2=b, cfg=np.array(cfg, dtype=np.float64))
 
 
 def prims_inputs():
@@ -187,6 +217,7 @@ def all_cases():
     out += [("detail", n, detail_inputs) for n in DETAIL]
     out += [("margin", n, margin_inputs) for n in MARGIN]
     out += [("align", n, align_inputs) for n in ALIGN]
+    out += [("dissolve", n, dissolve_inputs) for n in DISSOLVE]
     return out
 
 

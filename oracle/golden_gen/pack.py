@@ -32,7 +32,13 @@ def load_raw(path):
     return name, a.reshape(shape)
 
 
-def keep_full(name, arr):
+# long sequences: frames are pinned by their sha256 only (first and last kept in full for debugging)
+HASH_ONLY_FRAMES = {"a_512x512_chain30": ("frame0", "frame29"), "a_1920x1080_chain60": (), "a_3840x2160_phase": ()}
+
+
+def keep_full(name, arr, case=""):
+    if case in HASH_ONLY_FRAMES and "frame" in name:
+        return name in HASH_ONLY_FRAMES[case]
     if arr.nbytes <= FULL_LIMIT:
         return True
     big_ok = name.startswith("frame") or name.endswith("frame") or name in ("g1", "g2", "gabor2", "us1", "gb1", "radial", "padded") or "trImg" in name
@@ -67,7 +73,7 @@ def main():
         for path in sorted(glob.glob(os.path.join(cdir, "out", "*.bin"))):
             name, arr = load_raw(path)
             e = {"dtype": str(arr.dtype), "shape": list(arr.shape), "sha256": hashlib.sha256(arr.tobytes()).hexdigest()}
-            if keep_full(name, arr):
+            if keep_full(name, arr, case):
                 full[name] = arr
                 e["full"] = True
             else:

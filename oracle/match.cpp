@@ -241,6 +241,8 @@ double contour_area(const std::vector<Pt>& c) {
 
 }  // namespace
 
+void convex_hull_points(const std::vector<Pt>& pts, std::vector<Pt>& hull) { convex_hull(pts, hull); }
+
 double morph_distance(const std::vector<Pt>& p1, const std::vector<Pt>& p2, int w, int h) {
     const long double width = w, height = h;
     std::vector<DistPair> dm;

@@ -55,6 +55,7 @@ void triangle_int_points(const std::vector<int>& idx3, const std::vector<Pt>& po
 // fillConvexPoly(img, 3 pts, Scalar(value), LINE_8, shift 0) on a 32SC1 image
 void fill_triangle(ImageI& img, const IPt* v, int32_t value);
 void paint_triangles(ImageI& img, const std::vector<IPt>& tris);
+void fill_convex(ImageI& img, const IPt* v, int npts, int32_t value);        // cv::fillConvexPoly, LINE_8, shift 0
 
 bool invert33(const float* m, float* out);          // cv::invert 3x3 CV_32F (double cofactors)
 void solve_homography(const IPt* src1, const IPt* src2, float* H);
@@ -162,7 +163,14 @@ void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, st
 void gabor_filter_direct(const ImageF& src, int ks, const std::vector<float>& bank, ImageF& dst);   // tolerance comparator
 void orb_unsharp_gray(const ImageU8& gf, ImageF& us);
 
-void gaussian_blur_fx_u8(const ImageU8& src, int ksize, double sigma, ImageU8& dst);   // GaussianBlur on 8 bit, fixed-point path
+void gaussian_blur_fx_u8(const ImageU8& src, int ksize, double sigma, ImageU8& dst);
+// ---- detail.cpp ------------------------------------------------------------------------------
+double dft_detail2(const ImageU8& gray);                                     // src/experiments.hpp:305-318 (cv::dft restated bit for bit)
+void radial_gradient(int width, int height, ImageF& out);                    // draw_radial_gradiant2, src/draw.cpp:40-59
+void orb_input_image(const ImageU8& good_features, ImageU8& g);              // Extractor::keypoints up to the detector, src/extractor.cpp:50-76
+void gaussian_taps_fx(int n, double sigma, std::vector<int>& taps);          // 8.8 fixed-point taps of the 8-bit GaussianBlur (sigma <= 0: OpenCV's defaults)
+void convex_hull_points(const std::vector<Pt>& pts, std::vector<Pt>& hull);  // cv::convexHull(points, hull): counter-clockwise, points returned
+void dissolve_u8(const ImageU8& img1, const ImageU8& img2, double phase, ImageU8& out);   // img2*phase + img1*(1-phase), src/poppy.hpp:129   // GaussianBlur on 8 bit, fixed-point path
 void blur_margin(const ImageU8& src, int union_w, int union_h, ImageU8& dst);            // src/util.cpp:574-602
 
 }  // namespace oracle

@@ -170,6 +170,26 @@ void orc_gabor_filter_direct(const float* src, int w, int h, int c, int ks, cons
     gabor_filter_direct(wrap_f(src, w, h, c), ks, b, o); put_img(dst, o);
 }
 
+double orc_dft_detail2(const uint8_t* gray, int w, int h) { return dft_detail2(wrap_u8(gray, w, h, 1)); }
+void orc_radial_gradient(int w, int h, float* out) { ImageF o; radial_gradient(w, h, o); put_img(out, o); }
+void orc_orb_input(const uint8_t* gf, int w, int h, uint8_t* g) { ImageU8 o; orb_input_image(wrap_u8(gf, w, h, 1), o); put_img(g, o); }
+void orc_gaussian_taps_fx(int n, double sigma, int* out) { std::vector<int> t; gaussian_taps_fx(n, sigma, t); memcpy(out, t.data(), t.size() * sizeof(int)); }
+void orc_dissolve(const uint8_t* a, const uint8_t* b, int w, int h, int c, double phase, uint8_t* d) {
+    ImageU8 o; dissolve_u8(wrap_u8(a, w, h, c), wrap_u8(b, w, h, c), phase, o); put_img(d, o);
+}
+void orc_fill_convex(int w, int h, const int* xy, int npts, int32_t value, int32_t* map) {      // map is updated in place
+    ImageI img(w, h);
+    memcpy(img.d.data(), map, (size_t)w * h * 4);
+    std::vector<IPt> v(npts);
+    for (int i = 0; i < npts; ++i) v[i] = IPt{xy[2 * i], xy[2 * i + 1]};
+    fill_convex(img, v.data(), npts, value);
+    memcpy(map, img.d.data(), (size_t)w * h * 4);
+}
+int orc_convex_hull(const float* pts, int n, float* hull) {
+    std::vector<Pt> h; convex_hull_points(wrap_pts(pts, n), h);
+    memcpy(hull, h.data(), h.size() * sizeof(Pt));
+    return (int)h.size();
+}
 void orc_blur_margin(const uint8_t* src, int w, int h, int uw, int uh, uint8_t* dst) { ImageU8 o; blur_margin(wrap_u8(src, w, h, 3), uw, uh, o); put_img(dst, o); }
 
 // ---- auto-align ----------------------------------------------------------------------------------------------

@@ -329,13 +329,31 @@ void orb_unsharp_gray(const ImageU8& gf, ImageF& us) {
 // ---- blur_margin (src/util.cpp:574-602): pad into the union canvas, blur the four margin strips ------------------------------
 // 8-bit GaussianBlur, any odd ksize: taps in 8.8 fixed point with error diffusion (smooth.dispatch.cpp:224-258), exact integer
 // sums, (sum + 2^15) >> 16 at the end (smooth.simd.hpp:1136-1199,1780-1866); a dimension of size 1 is not filtered (:626-631).
-static void gaussian_taps_fx(int n, double sigma, std::vector<int>& taps) {
-    std::vector<double> v(n); double sum = 0;
-    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(-(x * x) / (2 * sigma * sigma)); sum += v[i]; }
+// getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (smooth.dispatch.cpp:81-258): for sigma <= 0 the fixed tables
+// for n = 1, 3, 5, 7, 9 (all multiples of 1/256, so their fixed-point form is exact), else sigma = n*0.15 + 0.35;
+// t_i = exp(x^2 * (-0.125 / sigma^2)) over the odd integers x = 2i - (n - 1), normalised by 1 / (2*sum + 1).  The reference
+// evaluates this in softfloat; libm's exp agrees to the last bit or differs by one ulp, which the rounding to 8 fractional
+// bits absorbs unless a tap sits within 2^-45 of a rounding boundary (pinned by OpenCV's own vectors,
+// imgproc/test/test_smooth_bitexact.cpp:14-27, tests/test_oracle_known_answers.py).
+void gaussian_taps_fx(int n, double sigma, std::vector<int>& taps) {
+    if (sigma <= 0 && (n == 1 || n == 3 || n == 5 || n == 7 || n == 9)) {
+        static const int t1[] = {256}, t3[] = {64, 128, 64}, t5[] = {16, 64, 96, 64, 16}, t7[] = {8, 28, 56, 72, 56, 28, 8},
+                         t9[] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
+        const int* t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : n == 7 ? t7 : t9;
+        taps.assign(t, t + n);
+        return;
+    }
+    const double sg = sigma > 0 ? sigma : n * 0.15 + 0.35;
+    const double scale = -0.125 / (sg * sg);
+    const int half = (n - 1) / 2;
+    std::vector<double> v(half); double sum = 0;
+    for (int i = 0, x = 1 - n; i < half; ++i, x += 2) { v[i] = std::exp((double)(x * x) * scale); sum += v[i]; }
+    sum = sum * 2 + 1;
+    const double mul = 1.0 / sum;
     taps.assign(n, 0);
     double err = 0; int tot = 0;
-    for (int i = 0; i < n / 2; ++i) {
-        const double adj = v[i] / sum * 256 + err;
+    for (int i = 0; i < half; ++i) {
+        const double adj = (v[i] * mul) * 256 + err;
         const int v0 = cv_round(adj);
         err = adj - v0;
         taps[i] = taps[n - 1 - i] = v0; tot += v0;

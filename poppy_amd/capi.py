@@ -30,6 +30,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
+    "poppy_dft_plan", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
@@ -94,6 +95,12 @@ def lib():
         L.poppy_hip_pair_begin_prefiltered.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, i, i, i]
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_points.argtypes = [vp, vp, vp, i, vp]
+        L.poppy_dft_plan.argtypes = [i, vp, vp, vp, vp]
+        L.poppy_hip_morph.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, vp, vp, vp]
+        L.poppy_hip_pair_distance.argtypes = [vp, vp]
+        L.poppy_printed_morph_distance.argtypes = [vp, vp, i, i, i, vp]
+        L.poppy_hypotf_selfcheck.restype = C.c_long
+        L.poppy_hypotf_selfcheck.argtypes = [C.c_long, C.c_uint64]
         _lib = L
     return _lib
 
@@ -173,6 +180,25 @@ def radial_gradient(w, h):
     if rc:
         raise PoppyError(f"poppy_radial_gradient: {rc}")
     return out
+
+
+def dft_plan(n):
+    """Host-only: (factors, itab, wave) of the length-n transform plan."""
+    f = np.zeros(34, np.int32); nf = C.c_int(0); itab = np.zeros(n, np.int32); wave = np.zeros((n, 2), np.float32)
+    rc = lib().poppy_dft_plan(n, _p(f), C.byref(nf), _p(itab), _p(wave))
+    if rc:
+        raise PoppyError(f"poppy_dft_plan: {rc}")
+    return f[:nf.value].copy(), itab, wave
+
+
+def printed_morph_distance(p1, p2, w, h):
+    """Host-only: the "morph distance" poppy::morph prints for prepared point lists (src/poppy.hpp:142-159)."""
+    p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+    d = C.c_double(0)
+    rc = lib().poppy_printed_morph_distance(_p(p1), _p(p2), len(p1), w, h, C.byref(d))
+    if rc:
+        raise PoppyError(f"poppy_printed_morph_distance: {rc}")
+    return d.value
 
 
 def match_points(p1, p2, w, h, tolerance=1.0):
@@ -374,6 +400,29 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_pair_points(self.h, _p(p1), _p(p2), max_points, C.byref(n)), "pair_points")
         return p1[:n.value].copy(), p2[:n.value].copy()
+
+    def morph(self, bgr1, bgr2, phase=-1.0, distance=False, collect=True):
+        """poppy::morph end to end: returns (status, frames, printed morph distance or None).  status is POPPY_OK (0) or
+        POPPY_E_NOMATCH (-5, fallback frames written); anything else raises."""
+        a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
+        h, w = a.shape[:2]
+        frames = []
+
+        def cb(user, ptr, ww, hh, stride):
+            frames.append(np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy())
+        fn = WRITE_CB(cb) if collect else None
+        d = C.c_double(float("nan"))
+        rc = lib().poppy_hip_morph(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, int(distance),
+                                   C.cast(fn, C.c_void_p) if fn else None, None, C.byref(d))
+        if rc not in (0, -5):
+            self._chk(rc, "morph")
+        self.w, self.h_ = w, h
+        return rc, frames, (None if d.value != d.value else d.value)
+
+    def pair_distance(self):
+        d = C.c_double(0)
+        self._chk(lib().poppy_hip_pair_distance(self.h, C.byref(d)), "pair_distance")
+        return d.value
 
     def reset(self):
         self._chk(lib().poppy_hip_pair_reset(self.h), "pair_reset")

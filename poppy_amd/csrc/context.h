@@ -39,6 +39,7 @@ struct FrameSlot {
     void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
+    hipEvent_t dl_pending = nullptr;                // download of this slot's `out` towards the writer still in flight (one of ctx.dl_done), or null
 };
 constexpr size_t kBlobHeader = 64;
 
@@ -52,6 +53,8 @@ struct poppy_hip_ctx {
     bool pair_ready = false;
     // resident buffers
     uint8_t *c1 = nullptr, *c2 = nullptr;
+    uint8_t* c2_raw = nullptr;           // image 2 before auto-align (only allocated when auto-align ran): what phase == 1 writes
+    bool c2_raw_valid = false;           // ... and whether it belongs to the resident pair
     float *gabor2 = nullptr, *m2 = nullptr;
     std::vector<FrameSlot> slots;        // per-frame working sets, used round-robin
     hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
@@ -66,6 +69,7 @@ struct poppy_hip_ctx {
     std::vector<PyrLevel> levels;        // 0..pyramid_levels
     PyrLevel* d_levels = nullptr;
     int first_tail = 1;
+    bool use_tail = true;                // false: the coarsest level is too large for one workgroup's LDS (shallow --pyramid): per-level kernels all the way
     // points
     std::vector<P2f> pts1_0, pts1, pts2;
     // per-frame plan blobs (pinned host + device) live in the frame slots, so the host can plan ahead of the GPU

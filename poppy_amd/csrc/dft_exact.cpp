@@ -1,132 +1,105 @@
 // dft_exact.cpp — see dft_exact.h.  Host only.
+//
+// Written from the definition of the transform the kernels run — a decimation-in-time mixed-radix FFT whose passes go
+// "whole power of two (radix 4, then at most one radix 2), then the odd primes from the largest to the smallest" — not from
+// the reference's table-building code.  What has to coincide with cv::dft (OCV/core/src/dxt.cpp) for dft_detail2's bytes
+// to coincide is the RESULT of the plan, and tests/test_host_plan.py::test_dft_plan_tables pins exactly that:
+//   * the pass order: the output index i is read as digits d_0, d_1, ... (least significant first) over the factors in pass
+//     order f_0, f_1, ...;
+//   * the load permutation that makes every pass work in place: the element that ends up in slot i comes from
+//     sum_k d_k * (n / (f_0 ... f_k)) — digit reversal — with the power-of-two digit additionally bit-reversed inside its
+//     own range (that factor is itself carried out as radix-4 / radix-2 sub-passes);
+//   * the twiddles exp(-2 pi i k / n) as FLOATS obtained by the recurrence w_{k+1} = w_k * w_1 in double, where w_1 comes from
+//     a constant table for powers of two (dft_pow2_roots.inc, published constants) and from libm otherwise
+//     (sin(2 pi / n), cos = sqrt(1 - sin^2)): the float roundings of this particular recurrence are what the reference
+//     multiplies by, so a mathematically better table would give different low bits.
 #include "dft_exact.h"
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <stdexcept>
 
 namespace poppy_hip {
 
+namespace {
+
+const double kPow2Roots[32][2] = {
+#include "dft_pow2_roots.inc"
+};
+
+bool is_pow2(int n) { return (n & (n - 1)) == 0; }
+
+int log2_exact(int n) { int m = 0; while ((1 << m) < n) ++m; return m; }
+
+int bit_reverse(int v, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+    return r;
+}
+
+}  // namespace
+
 int dft_optimal_size(int n) {
     for (int m = n;; ++m) {
         int t = m;
-        while (t % 2 == 0) t /= 2;
-        while (t % 3 == 0) t /= 3;
-        while (t % 5 == 0) t /= 5;
+        for (int f : {2, 3, 5}) while (t % f == 0) t /= f;
         if (t == 1) return m;
     }
 }
 
-static unsigned char bitrev8(unsigned v) {
-    unsigned r = 0;
-    for (int b = 0; b < 8; ++b) r |= ((v >> b) & 1u) << (7 - b);
-    return (unsigned char)r;
-}
-
-// DFTFactorize (dxt.cpp:158-200): the power of two first, then odd factors ascending, then the odd part reversed
-static int factorize(int n, int* factors) {
-    int nf = 0, f;
-    if (n <= 5) { factors[0] = n; return 1; }
-    f = (((n - 1) ^ n) + 1) >> 1;
-    if (f > 1) { factors[nf++] = f; n = f == n ? 1 : n / f; }
-    for (f = 3; n > 1;) {
-        const int d = n / f;
-        if (d * f == n) { factors[nf++] = f; n = d; }
-        else { f += 2; if (f * f > n) break; }
+void dft_make_plan(int n, DftPlanHost& p) {
+    if (n < 1) throw std::runtime_error("dft_make_plan: length must be positive");
+    p.n = n;
+    // ---- pass order ---------------------------------------------------------------------------------------------------
+    std::vector<int> order;
+    const int two = n & -n;                                       // the whole power of two is one entry
+    if (two > 1) order.push_back(two);
+    {
+        std::vector<int> primes;
+        int rest = n / two;
+        for (int f = 3; rest > 1; f += 2)
+            while (rest % f == 0) { primes.push_back(f); rest /= f; }
+        order.insert(order.end(), primes.rbegin(), primes.rend());   // largest odd prime first
     }
-    if (n > 1) factors[nf++] = n;
-    f = (factors[0] & 1) == 0;
-    for (int i = f; i < (nf + f) / 2; i++) { const int t = factors[i]; factors[i] = factors[nf - i - 1 + f]; factors[nf - i - 1 + f] = t; }
-    return nf;
-}
+    if (order.empty()) order.push_back(1);                        // n == 1: a single trivial pass
+    if (order.size() >= 34) throw std::runtime_error("dft_make_plan: too many factors");
+    p.nf = (int)order.size();
+    for (int k = 0; k < 34; ++k) p.factors[k] = k < p.nf ? order[k] : 0;
 
-// DFTInit (dxt.cpp:202-400) for the forward, non-inverted permutation table and float twiddles
-void dft_make_plan(int n0, DftPlanHost& p) {
-    p.n = n0;
-    p.nf = factorize(n0, p.factors);
-    p.itab.assign(n0, 0);
-    p.wave.assign((size_t)n0 * 2, 0.f);
-    int* itab = p.itab.data();
-    const int* factors = p.factors;
-    const int nf = p.nf;
-    int digits[34], radix[34];
-    int n = factors[0], m = 0;
-    int i, j, k;
-    if (n0 <= 5) {
-        itab[0] = 0; itab[n0 - 1] = n0 - 1;
-        if (n0 != 4) { for (i = 1; i < n0 - 1; i++) itab[i] = i; }
-        else { itab[1] = 2; itab[2] = 1; }
-        if (n0 == 5) { p.wave[0] = 1.f; p.wave[1] = 0.f; }
-        if (n0 != 4) return;
-        m = 2;
-    } else {
-        if (nf >= 34) throw std::runtime_error("dft_make_plan: too many factors");
-        radix[nf] = 1; digits[nf] = 0;
-        for (i = 0; i < nf; i++) { digits[i] = 0; radix[nf - i - 1] = radix[nf - i] * factors[nf - i - 1]; }
-        if ((n & 1) == 0) {
-            const int a = radix[1], na2 = n * a >> 1, na4 = na2 >> 1;
-            for (m = 0; (unsigned)(1 << m) < (unsigned)n; m++) {}
-            if (n <= 2) { itab[0] = 0; itab[1] = na2; }
-            else if (n <= 256) {
-                const int shift = 10 - m;
-                for (i = 0; i <= n - 4; i += 4) {
-                    j = (bitrev8(i >> 2) >> shift) * a;
-                    itab[i] = j; itab[i + 1] = j + na2; itab[i + 2] = j + na4; itab[i + 3] = j + na2 + na4;
-                }
-            } else {
-                const int shift = 34 - m;
-                for (i = 0; i < n; i += 4) {
-                    const unsigned i4 = (unsigned)(i >> 2);
-                    const unsigned rev = ((unsigned)bitrev8(i4 & 255) << 24) + ((unsigned)bitrev8((i4 >> 8) & 255) << 16) +
-                                         ((unsigned)bitrev8((i4 >> 16) & 255) << 8) + (unsigned)bitrev8(i4 >> 24);
-                    j = (int)(rev >> shift) * a;
-                    itab[i] = j; itab[i + 1] = j + na2; itab[i + 2] = j + na4; itab[i + 3] = j + na2 + na4;
-                }
-            }
-            digits[1]++;
-            if (nf >= 2) {
-                for (i = n, j = radix[2]; i < n0;) {
-                    for (k = 0; k < n; k++) itab[i + k] = itab[k] + j;
-                    if ((i += n) >= n0) break;
-                    j += radix[2];
-                    for (k = 1; ++digits[k] >= factors[k]; k++) { digits[k] = 0; j += radix[k + 2] - radix[k]; }
-                }
-            }
-        } else {
-            for (i = 0, j = 0;;) {
-                itab[i] = j;
-                if (++i >= n0) break;
-                j += radix[1];
-                for (k = 0; ++digits[k] >= factors[k]; k++) { digits[k] = 0; j += radix[k + 2] - radix[k]; }
-            }
+    // ---- load permutation: digit reversal over `order`, bit reversal inside the power of two --------------------------
+    const int two_bits = two > 1 ? log2_exact(two) : 0;
+    p.itab.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+        int rem = i, place = n, from = 0;
+        for (size_t k = 0; k < order.size(); ++k) {
+            int digit = rem % order[k];
+            rem /= order[k];
+            place /= order[k];
+            if (k == 0 && two > 1) digit = bit_reverse(digit, two_bits);
+            from += digit * place;
         }
+        p.itab[i] = from;
     }
-    double wre, wim, w1re, w1im, t;
-    if ((n0 & (n0 - 1)) == 0) {
-        // DFTTab[m] (dxt.cpp:89-124) holds (cos, sin)(2 pi / 2^m) as decimal literals with 17 digits after the point, i.e. the
-        // doubles one gets by printing the C library's values with "%.17f" and reading them back (checked against all 32
-        // entries of the reference table in the container)
-        const double ang = 2 * M_PI / (double)(1u << m);
-        auto lit = [](double v) { char b[64]; snprintf(b, sizeof b, "%.17f", v); return strtod(b, nullptr); };
-        const double c = m == 0 ? 1.0 : m == 1 ? -1.0 : m == 2 ? 0.0 : lit(std::cos(ang));
-        // (one entry does not follow the rule: the table's sine for m = 7 ends in ...802 where the rule gives ...801)
-        const double s = m <= 1 ? 0.0 : m == 2 ? 1.0 : m == 7 ? 0.04906767432741802 : lit(std::sin(ang));
-        wre = w1re = c; wim = w1im = -s;
+
+    // ---- twiddles ---------------------------------------------------------------------------------------------------------
+    double c1, s1;                                                // w_1 = c1 + i s1 = exp(-2 pi i / n)
+    if (is_pow2(n)) {
+        const int m = log2_exact(n);
+        c1 = kPow2Roots[m][0]; s1 = -kPow2Roots[m][1];
     } else {
-        t = -M_PI * 2 / n0;
-        wim = w1im = std::sin(t);
-        wre = w1re = std::sqrt(1. - w1im * w1im);
+        s1 = std::sin(-M_PI * 2 / n);
+        c1 = std::sqrt(1. - s1 * s1);
     }
-    n = (n0 + 1) / 2;
-    float* wave = p.wave.data();
-    wave[0] = 1.f; wave[1] = 0.f;
-    if ((n0 & 1) == 0) { wave[2 * n] = -1.f; wave[2 * n + 1] = 0.f; }
-    for (i = 1; i < n; i++) {
-        wave[2 * i] = (float)wre; wave[2 * i + 1] = (float)wim;
-        wave[2 * (n0 - i)] = (float)wre; wave[2 * (n0 - i) + 1] = (float)-wim;
-        t = wre * w1re - wim * w1im;
-        wim = wre * w1im + wim * w1re;
-        wre = t;
+    p.wave.assign((size_t)n * 2, 0.f);
+    auto put = [&](int k, double re, double im) { p.wave[2 * (size_t)k] = (float)re; p.wave[2 * (size_t)k + 1] = (float)im; };
+    put(0, 1.0, 0.0);
+    const int half = (n + 1) / 2;
+    if (n % 2 == 0) put(half, -1.0, 0.0);
+    double re = c1, im = s1;
+    for (int k = 1; k < half; ++k) {
+        put(k, re, im);
+        put(n - k, re, -im);                                      // the upper half mirrors the lower one
+        const double nre = re * c1 - im * s1;
+        im = re * s1 + im * c1;
+        re = nre;
     }
 }
 

@@ -308,6 +308,13 @@ static void build_raster(FramePlan& plan, int w, int h) {
     }
 }
 
+void unique_points_ref(const std::vector<P2f>& pts, std::vector<P2f>& out) {
+    std::set<P2f, P2fLess> seen;
+    out.clear();
+    for (const P2f& p : pts)
+        if (seen.insert(p).second) out.push_back(p);
+}
+
 int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f>& src2, double shape_ratio, FramePlan& plan) {
     const size_t n = src1.size();
     std::vector<P2f> a = src1, b = src2;

@@ -48,6 +48,7 @@ constexpr int kWarpRecordFloats = 20;
 bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* records);
 
 void clip_points_ref(std::vector<P2f>& pts, int cols, int rows);   // src/util.cpp:453-460
+void unique_points_ref(const std::vector<P2f>& pts, std::vector<P2f>& out);   // make_uniq, src/util.cpp:541-548: first occurrences, input order
 bool invert3x3(const float* m, float* out);                        // OCV/core/src/lapack.cpp:965-993
 
 }  // namespace poppy_hip

@@ -84,6 +84,8 @@ void launch_collapse2(const float* gL, const float* gR, const float* gM, const f
                       const float* nL, const float* nR, const float* nB, float* outB,
                       int w, int h, int w1, int h1, int w2, int h2, hipStream_t s);
 
+// blended smallest level = L*m + R*(1-m), for pyramids whose coarsest level does not fit the tail kernel's LDS
+void launch_mix_top(const float* l, const float* r, const float* m, float* out, int n_px, hipStream_t s);
 size_t pyr_tail_lds_bytes(int levels, int n3, int n1);      // dynamic LDS the tail kernel needs
 bool prepare_pyr_tail(size_t lds_bytes);                    // raises the kernel's LDS limit; call outside stream capture
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels,

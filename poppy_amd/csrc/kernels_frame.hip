@@ -14,6 +14,7 @@
 #include <hip/hip_ext.h>
 #include <climits>
 #include <cmath>
+#include <mutex>
 
 namespace poppy_hip {
 
@@ -585,8 +586,29 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
         for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
     }
 }
-bool prepare_pyr_tail(size_t lds_bytes) {     // once per pair geometry, outside any stream capture
-    return hipFuncSetAttribute((const void*)k_pyr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+// The dynamic-LDS limit of a kernel is process state per device, not per context: it is only ever RAISED here, so a context
+// with a smaller geometry cannot lower it under a live one.  Call outside any stream capture.
+bool prepare_pyr_tail(size_t lds_bytes) {
+    static std::mutex mu;
+    static size_t granted[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds_bytes <= granted[dev]) return true;
+    if (hipFuncSetAttribute((const void*)k_pyr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
+    granted[dev] = lds_bytes;
+    return true;
+}
+
+// Smallest-level mix of a pyramid too shallow for the LDS tail (blend.hpp:72-76: resultHighestLevel = left * mask + right * (1 - mask)
+// with the mask replicated to three channels), straight from and to global memory.
+__global__ void __launch_bounds__(256) k_mix_top(const float* __restrict__ l, const float* __restrict__ r, const float* __restrict__ m,
+                                                 float* __restrict__ out, int n3) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n3) out[e] = mix_lr(l[e], r[e], m[e / 3]);
+}
+void launch_mix_top(const float* l, const float* r, const float* m, float* out, int n_px, hipStream_t s) {
+    hipLaunchKernelGGL(k_mix_top, dim3((n_px * 3 + 255) / 256), dim3(256), 0, s, l, r, m, out, n_px * 3);
 }
 size_t pyr_tail_lds_bytes(int levels, int n3, int n1) {
     return ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;

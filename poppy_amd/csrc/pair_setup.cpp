@@ -3,6 +3,7 @@
 // (poppy::morph up to its frame loop, src/poppy.hpp:46-160, incl. Matcher::find / prepare and the auto-align), blur_margin.
 // The per-frame path and the context itself live in poppy_hip.cpp; both share context.h.
 #include "context.h"
+#include "dft_exact.h"
 
 extern "C" {
 
@@ -173,6 +174,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     HIPCHK(c, hipSetDevice(c->device));
     int rc = alloc_pair(c, W, H); if (rc) return rc;
     c->pair_ready = false;
+    c->c2_raw_valid = false;
     rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
     rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
     const size_t P = (size_t)W * H;
@@ -270,6 +272,9 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
             if (n < 4) return fail(c, POPPY_E_UNSUPPORTED, "auto-align needs at least 4 keypoint pairs (the reference reads 4 unconditionally)");
             std::vector<P2f> a(n), b(n);
             memcpy(a.data(), p1.data(), n * 8); memcpy(b.data(), p2.data(), n * 8);
+            if (!c->c2_raw) HIPCHK(c, hipMalloc((void**)&c->c2_raw, P * 3 + 16));       // phase == 1 writes the image as it came in
+            HIPCHK(c, hipMemcpyAsync(c->c2_raw, c->c2, P * 3, hipMemcpyDeviceToDevice, c->stream));
+            c->c2_raw_valid = true;
             if (c->aligner.run(c->c2, W, H, a, b, c->stream, nullptr)) return fail(c, POPPY_E_DEVICE, c->aligner.err.c_str());
             memcpy(p2.data(), b.data(), n * 8);
             const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->stream);
@@ -379,6 +384,17 @@ int poppy_hip_blur_margin(poppy_hip_ctx* c, const uint8_t* src, size_t stride, i
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) { c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
+int poppy_dft_plan(int n, int* factors, int* n_factors, int* itab, float* wave) {
+    if (n < 1 || !factors || !n_factors || !itab || !wave) return POPPY_E_ARG;
+    DftPlanHost p;
+    try { dft_make_plan(n, p); } catch (...) { return POPPY_E_UNSUPPORTED; }
+    *n_factors = p.nf;
+    memcpy(factors, p.factors, sizeof(int) * 34);
+    memcpy(itab, p.itab.data(), sizeof(int) * (size_t)n);
+    memcpy(wave, p.wave.data(), sizeof(float) * 2 * (size_t)n);
     return POPPY_OK;
 }
 

@@ -14,11 +14,33 @@
 
 namespace poppy_hip {
 
-// glibc's hypotf for finite floats is (float)sqrt((double)x*x + (double)y*y): the squares are exact in double, their sum and
-// the root are each rounded once, and the final rounding to float never meets a double-rounding case (checked against
-// hypotf on 4*10^8 inputs, tools/micro/hypotf_check.c; the candidate-scoring kernel relies on the same identity).  The
-// libm call costs several times this, and the matcher evaluates it ~10^6 times per pair.
+// hypotf for finite, non-zero floats IS this expression in glibc — sysdeps/ieee754/flt-32/e_hypotf.c returns
+// (float) sqrt((double) x * x + (double) y * y) after peeling off infinities, NaNs and zeros (2.17-2.34), and the 2.35
+// rewrite keeps the same double-precision square root with an added overflow check — so this is the library's own
+// definition, not an approximation of it: the squares are exact in double, sum and root are each rounded once, one final
+// rounding to float.  tools/micro/hypotf_check.c compares it with the installed libm on 4*10^8 inputs (0 differ on glibc
+// 2.35; tests/test_host_plan.py repeats a 2*10^6-input sample on whatever libm the test box has).  The zero / infinity /
+// NaN special cases give the same values through the formula (x = 0 -> sqrt(y*y) = |y| exactly; inf -> inf; NaN -> NaN) and
+// image coordinates are finite.  The libm call costs several times this, and the matcher evaluates it ~10^6 times per pair;
+// the candidate-scoring kernel (kernels_align.hip) uses the same expression with the device's correctly rounded f64 sqrt.
 static inline float hyp(float x, float y) { return (float)std::sqrt((double)x * (double)x + (double)y * (double)y); }
+
+long hypotf_selfcheck(long n, unsigned long long seed) {
+    unsigned long long s = seed ? seed : 88172645463325252ull;
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        float x, y;
+        switch (i & 3) {
+        case 0: x = (float)((int)(s & 0xFFFFF) - 524288) / 256.f; y = (float)((int)((s >> 20) & 0xFFFFF) - 524288) / 256.f; break;   // image-scale coordinates
+        case 1: x = (float)((int)(s & 0xFFFF) - 32768) / 8.f; y = (float)((int)((s >> 16) & 0xFFFF) - 32768) / 8.f; break;
+        case 2: x = std::ldexp((float)(s & 0xFFFFFF), -(int)((s >> 24) & 31)); y = std::ldexp((float)((s >> 32) & 0xFFFFFF), -(int)((s >> 56) & 31)); break;
+        default: x = (float)((int)(s & 0x3FFF) - 8192) / 4.f; y = (s >> 40) & 1 ? 0.f : (float)((int)((s >> 14) & 0x3FFF) - 8192) / 4.f; break;
+        }
+        if (::hypotf(x, y) != hyp(x, y)) ++bad;
+    }
+    return bad;
+}
 
 void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs) {
     std::vector<P2f> pool = src2;

@@ -12,6 +12,7 @@ namespace poppy_hip {
 
 struct PointPair { double dist; P2f a, b; };
 
+long hypotf_selfcheck(long n, unsigned long long seed);                         // mismatches between hyp() and libm hypotf
 void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs);   // make_distance_map
 void drop_out_of_image(std::vector<P2f>& p1, std::vector<P2f>& p2, int cols, int rows);                         // filter_invalid_points + resize
 double morph_distance_ref(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h);               // morph_distance

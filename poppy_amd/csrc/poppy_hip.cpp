@@ -64,9 +64,9 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
 }
 
 static void free_pair(poppy_hip_ctx* c) {
-    void* bufs[] = {c->c1, c->c2, c->gabor2, c->m2, c->d_levels};
+    void* bufs[] = {c->c1, c->c2, c->c2_raw, c->gabor2, c->m2, c->d_levels};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    c->c1 = c->c2 = nullptr; c->gabor2 = c->m2 = nullptr; c->d_levels = nullptr;
+    c->c1 = c->c2 = c->c2_raw = nullptr; c->gabor2 = c->m2 = nullptr; c->d_levels = nullptr;
     for (FrameSlot& f : c->slots) {
         void* fb[] = {f.tr1, f.tr2, f.out, f.pyrL, f.pyrR, f.pyrM, f.pyrB, f.tmp, f.diff, f.unsharpF, f.triMap};
         for (void* b : fb) if (b) (void)hipFree(b);
@@ -170,8 +170,14 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         if (c->levels[i].w == 1 && c->levels[i].h == 1) { c->tail_k1 = i; break; }
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
     const size_t tail_lds = pyr_tail_lds_bytes(L, c->tail_n3, c->tail_n1);
-    if (tail_lds > 160 * 1024 || !prepare_pyr_tail(tail_lds))
-        return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels too small for this image size: the coarsest level must fit the LDS-resident tail kernel");
+    c->use_tail = tail_lds <= 160 * 1024;
+    if (c->use_tail) {
+        if (!prepare_pyr_tail(tail_lds)) return fail(c, POPPY_E_DEVICE, "could not raise the tail kernel's LDS limit");
+    } else {
+        // A shallow pyramid (--pyramid 4 at 1080p ends at 120 x 68): every level goes through the per-level kernels and the
+        // coarsest-level mix runs from global memory (blend.hpp simply loops `levels` times, any depth is legal).
+        c->first_tail = L;
+    }
     // +16: k_warp4 fetches footprints with 8-byte loads (6 bytes used), the last one may run 2 bytes past the image
     HIPCHK(c, hipMalloc((void**)&c->c1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3 + 16));
     HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12)); HIPCHK(c, hipMalloc((void**)&c->m2, P * 4));
@@ -309,6 +315,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
             hipError_t e = hipStreamWaitEvent(c->dl_stream, f.done, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * frame_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
             if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
+            f.dl_pending = c->dl_done[r];
             if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; break; }
             if (j >= R - 1) {
                 const int jr = j - (R - 1), rr = jr % R;
@@ -352,7 +359,9 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         ++i;
     }
     if (tm) tm->mark("pyrdown");
-    launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
+    if (c->use_tail) launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
+    else launch_mix_top(f.pyrL + c->levels[L].off3, f.pyrR + c->levels[L].off3, f.pyrM + c->levels[L].off1, f.pyrB + c->levels[L].off3,
+                        c->levels[L].w * c->levels[L].h, s);
     if (tm) tm->mark("pyr_tail");
     for (int j = ft; j > 0;) {                     // blended level j is known; produce level j-2 or j-1
         if (fuse && j - 2 >= 1) {
@@ -392,12 +401,17 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const int W = c->W, H = c->H;
     const int T = c->plan.n_tris;
     if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
+    static_assert(((long long)kIdTagMax << kIdTagShift) + (1ll << kIdTagShift) - 1 <= 0x7fffffffll, "tagged ids must stay positive int32 values");
+    if (T + 1 >= (1 << kIdTagShift)) return fail(c, POPPY_E_UNSUPPORTED, "more triangles than the id map's tag scheme can number (2^20 - 2)");
 
     // frame slot: the next one in the ring that does not hold the image this frame reads as corrected1
     int fi = c->next_slot;
     if (c->slots[fi].out == c->cur1) fi = (fi + 1) % (int)c->slots.size();
     c->next_slot = (fi + 1) % (int)c->slots.size();
     FrameSlot& f = c->slots[fi];
+    // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
+    // `out` before that copy has read it
+    if (f.dl_pending) { HIPCHK(c, hipEventSynchronize(f.dl_pending)); f.dl_pending = nullptr; }
 
     HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
@@ -528,6 +542,7 @@ int poppy_hip_pair_load(poppy_hip_ctx* c, const uint8_t* c1, size_t s1, const ui
     if (!c1 || !c2 || !gabor2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = alloc_pair(c, W, H); if (rc) return rc;
+    c->c2_raw_valid = false;
     rc = set_points(c, p1, p2, n); if (rc) return rc;
     rc = upload_image(c, c->c1, c1, s1, W, H); if (rc) return rc;
     rc = upload_image(c, c->c2, c2, s2, W, H); if (rc) return rc;
@@ -543,6 +558,7 @@ int poppy_hip_pair_load_device(poppy_hip_ctx* c, const void* d1, const void* d2,
     if (!d1 || !d2 || !dg || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = alloc_pair(c, W, H); if (rc) return rc;
+    c->c2_raw_valid = false;
     rc = set_points(c, p1, p2, n); if (rc) return rc;
     const size_t P = (size_t)W * H;
     HIPCHK(c, hipMemcpyAsync(c->c1, d1, P * 3, hipMemcpyDeviceToDevice, c->stream));
@@ -604,10 +620,66 @@ int poppy_hip_morph_frames(poppy_hip_ctx* c, double phase, poppy_write_cb write,
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->cfg.number_of_frames;
     if (write) { int rc = stage_host(c, (size_t)c->W * 3 * c->H); if (rc) return rc; }
+    if (phase == 0 || phase == 1) {                            // src/poppy.hpp:54-70: N copies of image 1 / image 2, nothing rendered
+        if (!write) return POPPY_OK;
+        const uint8_t* img = phase == 0 ? c->c1 : (c->c2_raw_valid ? c->c2_raw : c->c2);
+        const size_t row = (size_t)c->W * 3;
+        HIPCHK(c, hipMemcpyAsync(c->h_stage, img, row * c->H, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int j = 0; j < N; ++j) write(user, c->h_stage, c->W, c->H, row);
+        return POPPY_OK;
+    }
     const int n = phase >= 0 ? 1 : N;                          // phase mode: exactly one frame (src/poppy.hpp:234-235)
     std::vector<double> ratio(n);
     for (int j = 0; j < n; ++j) ratio[j] = poppy_frame_ratio(j, N, phase);
     return render_sequence(c, ratio.data(), ratio.data(), n, true, write, user);
+}
+
+int poppy_printed_morph_distance(const float* p1, const float* p2, int n, int W, int H, double* out) {
+    if (n < 1 || !p1 || !p2 || !out || W <= 0 || H <= 0) return POPPY_E_ARG;
+    std::vector<P2f> a(n), b(n), u1, u2;
+    memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8);
+    clip_points_ref(a, W, H); unique_points_ref(a, u1);           // src/poppy.hpp:142-157
+    clip_points_ref(b, W, H); unique_points_ref(b, u2);
+    if (u1.size() > u2.size()) u1.resize(u2.size()); else u2.resize(u1.size());
+    *out = morph_distance_ref(u1, u2, W, H);
+    return POPPY_OK;
+}
+
+int poppy_hip_pair_distance(poppy_hip_ctx* c, double* out) {
+    if (!c || !out) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    if (c->pts1_0.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs");
+    return poppy_printed_morph_distance((const float*)c->pts1_0.data(), (const float*)c->pts2.data(), (int)c->pts1_0.size(), c->W, c->H, out);
+}
+
+long poppy_hypotf_selfcheck(long n, uint64_t seed) { return hypotf_selfcheck(n, seed); }
+
+int poppy_hip_morph(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, double phase,
+                    int distance, poppy_write_cb write, void* user, double* morph_distance) {
+    if (!c) return POPPY_E_ARG;
+    if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
+    const int N = c->cfg.number_of_frames;
+    if (phase == 0 || phase == 1) {                            // src/poppy.hpp:54-70, before any feature work
+        for (int j = 0; j < N && write; ++j) write(user, phase == 0 ? bgr1 : bgr2, W, H, phase == 0 ? s1 : s2);
+        return POPPY_OK;
+    }
+    int rc = poppy_hip_pair_begin(c, bgr1, s1, bgr2, s2, W, H); if (rc) return rc;
+    if (c->pts1_0.empty()) {                                   // :125-134 (see the header: the reference throws before reaching it)
+        if (!distance && write) {
+            std::vector<uint8_t> blend((size_t)W * 3 * H);
+            rc = poppy_hip_dissolve(c, bgr1, s1, bgr2, s2, W, H, phase, blend.data(), (size_t)W * 3); if (rc) return rc;
+            for (int j = 0; j < N; ++j) write(user, blend.data(), W, H, (size_t)W * 3);
+        }
+        return fail(c, POPPY_E_NOMATCH, "no point pairs: linear-blend fallback frames written (src/poppy.hpp:125-134)");
+    }
+    if (morph_distance || distance) {
+        double d = 0;
+        rc = poppy_hip_pair_distance(c, &d); if (rc) return rc;
+        if (morph_distance) *morph_distance = d;
+    }
+    if (distance) return POPPY_OK;                             // :159-163 (the reference exits here)
+    return poppy_hip_morph_frames(c, phase, write, user);
 }
 
 int poppy_hip_dissolve(poppy_hip_ctx* c, const uint8_t* img1, size_t s1, const uint8_t* img2, size_t s2, int W, int H, double phase,

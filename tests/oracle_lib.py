@@ -415,3 +415,115 @@ def align_step(which, img, p1, p2):
     lib().orc_align_step.restype = C.c_double
     d = lib().orc_align_step(code, _vp(im), w, h, _vp(p1), _vp(q), len(p1))
     return im, q, d
+
+
+# ---- round 2: the rest of the pre-ORB chain, the whole pair set-up and poppy::morph in the oracle ---------------------
+def dft_detail2(gray):
+    g = np.ascontiguousarray(gray, np.uint8)
+    L = lib(); L.orc_dft_detail2.restype = C.c_double
+    return L.orc_dft_detail2(_vp(g), g.shape[1], g.shape[0])
+
+
+def radial_gradient(w, h):
+    o = np.zeros((h, w), np.float32)
+    lib().orc_radial_gradient(w, h, _vp(o))
+    return o
+
+
+def orb_input(good_features):
+    gf = np.ascontiguousarray(good_features, np.uint8); o = np.zeros_like(gf)
+    lib().orc_orb_input(_vp(gf), gf.shape[1], gf.shape[0], _vp(o))
+    return o
+
+
+def gaussian_taps_fx(n, sigma):
+    o = np.zeros(n, np.int32)
+    L = lib(); L.orc_gaussian_taps_fx.argtypes = [C.c_int, C.c_double, C.c_void_p]
+    L.orc_gaussian_taps_fx(n, sigma, _vp(o))
+    return o
+
+
+def dissolve(img1, img2, phase):
+    a = np.ascontiguousarray(img1, np.uint8); b = np.ascontiguousarray(img2, np.uint8); o = np.zeros_like(a)
+    L = lib(); L.orc_dissolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    L.orc_dissolve(_vp(a), _vp(b), a.shape[1], a.shape[0], a.shape[2] if a.ndim == 3 else 1, phase, _vp(o))
+    return o
+
+
+def fill_convex(img, pts, value):
+    m = np.ascontiguousarray(img, np.int32).copy()
+    xy = np.ascontiguousarray(pts, np.int32).reshape(-1, 2)
+    lib().orc_fill_convex(m.shape[1], m.shape[0], _vp(xy), len(xy), int(value), _vp(m))
+    return m
+
+
+def convex_hull(pts):
+    p = _f(pts).reshape(-1, 2); o = np.zeros_like(p)
+    n = lib().orc_convex_hull(_vp(p), len(p), _vp(o))
+    return o[:n].copy()
+
+
+def gabor_field(bgr):
+    """gabor_filter(bgr / 255) with the default arguments (src/poppy.hpp:119-122): the direct double sum rounded once."""
+    return gabor_filter_direct(u8_to_f32(np.ascontiguousarray(bgr, np.uint8)), 13, gabor_bank(13, 5, 10))
+
+
+def frame_ratio(j, n, phase):
+    """The scheduler of poppy::morph (src/poppy.hpp:181-210): shape (= colour) ratio of frame j."""
+    linear = j / float(n)
+    progress = 0.0
+    if phase >= 1.0:
+        progress = 1.0
+    if 0 <= phase < 1.0:
+        progress = 1.0 / n
+    elif linear == 0:
+        progress = 0.0
+    elif linear == 1:
+        progress = 1.0
+    else:
+        progress = (1.0 / (1.0 - linear)) / n
+    shape = progress * phase if 0 <= phase < 1.0 else progress
+    return min(shape, 1.0)
+
+
+def pair_setup(img1, img2, max_keypoints=300, tolerance=1.0):
+    """poppy::morph up to its frame loop (src/poppy.hpp:46-160, no face detection, no auto-align) from the raw BGR pair:
+    dict(nfeatures, detail, g1, g2, kp1, kp2, points1, points2, gabor2, distance)."""
+    img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
+    h, w = img1.shape[:2]
+    gf1, gf2 = foreground(img1)["foreground"], foreground(img2)["foreground"]
+    d1, d2 = dft_detail2(gf1), dft_detail2(gf2)
+    nfeatures = int(max_keypoints * (255.0 / max(d1, d2)))
+    g1, g2 = orb_input(gf1), orb_input(gf2)
+    kp1, kp2 = orb_detect(g1, nfeatures), orb_detect(g2, nfeatures)
+    n = min(len(kp1), len(kp2))
+    f1, f2 = filter_invalid(kp1[:n, :2].copy(), kp2[:n, :2].copy(), w, h)
+    out = dict(nfeatures=nfeatures, detail=(d1, d2), g1=g1, g2=g2, kp1=kp1, kp2=kp2, gabor2=gabor_field(img2),
+               points1=f1[:0], points2=f2[:0], distance=None)
+    if len(f1):
+        md = morph_distance(f1, f2, w, h)
+        a, b = match_prepare(f1, f2, w, h, tolerance, md)
+        u1 = make_uniq(clip_points(a, w, h)); u2 = make_uniq(clip_points(b, w, h))
+        k = min(len(u1), len(u2))
+        out.update(points1=a, points2=b, distance=morph_distance(u1[:k], u2[:k], w, h))
+    return out
+
+
+def morph(img1, img2, number_of_frames, phase=-1.0, levels=64, setup=None):
+    """poppy::morph end to end: the list of frames it hands to the writer."""
+    img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
+    if phase == 0:
+        return [img1.copy() for _ in range(number_of_frames)]
+    if phase == 1:
+        return [img2.copy() for _ in range(number_of_frames)]
+    s = setup or pair_setup(img1, img2)
+    if not len(s["points1"]):
+        return [dissolve(img1, img2, phase) for _ in range(number_of_frames)]
+    frames, cur, pts = [], img1, s["points1"]
+    for j in range(number_of_frames):
+        r = frame_ratio(j, number_of_frames, phase)
+        cur, pts = morph_images(cur, img2, s["gabor2"], pts, s["points2"], r, r, levels)
+        frames.append(cur)
+        if phase >= 0:
+            break
+    return frames

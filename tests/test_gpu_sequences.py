@@ -1,0 +1,180 @@
+"""GPU parity on whole calls of poppy::morph through the C ABI (poppy_hip_morph), against frames of the REAL reference
+(tests/golden, captured from the compiled poppy::morph): every BASELINE.json single-GPU configuration end to end from the raw
+image pair, the phase == 0 / 1 short-circuits, --distance, the no-match fallback expression and shallow pyramids."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(**kw):
+    from poppy_amd import capi
+    return capi.Context(0, **kw)
+
+
+def test_phase_mode_frame_fixture():
+    """a_256x256_phase: init(numberOfFrames = 1); morph(phase = 0.5) of the real reference."""
+    case = "a_256x256_phase"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=int(inp["cfg"][0]))
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"], phase=float(inp["cfg"][1]))
+    assert rc == 0 and len(frames) == 1
+    G.check(case, "frame0", frames[0])
+    c.close()
+
+
+def test_phase_zero_and_one_short_circuit():
+    case = "a_256x256_phase01"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=3)
+    rc, frames, _ = c.morph(inp["img1"], inp["img2"], phase=0.0)
+    assert rc == 0 and len(frames) == 3
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
+    c.close()
+    c = _ctx(number_of_frames=1)
+    rc, frames, _ = c.morph(inp["img1"], inp["img2"], phase=1.0)
+    assert rc == 0 and len(frames) == 1
+    G.check(case, "phase0_frame", frames[0])
+    # the same two shortcuts on a resident pair (what a rank of the sharded job calls for t_0 = 0)
+    c.pair_begin(inp["img1"], inp["img2"])
+    f0 = c.morph_frames(0.0)
+    f1 = c.morph_frames(1.0)
+    assert len(f0) == 1 and np.array_equal(f0[0], inp["img1"]) and np.array_equal(f1[0], inp["img2"])
+    c.close()
+
+
+def test_cfg1_512x512_30_chained_frames():
+    """BASELINE.json configs[0] end to end from the raw pair: all 30 frames of the real poppy::morph (sha256)."""
+    case = "a_512x512_chain30"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=30)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"])
+    assert rc == 0 and len(frames) == 30
+    assert dist == float(G.full(case, "printedMorphDist")[0])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1); G.check(case, "prepared2", p2)
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
+    c.close()
+
+
+def test_cfg2_1080p_60_chained_frames_and_phase_frames():
+    """BASELINE.json configs[1] end to end from the raw 1080p pair: nfeatures, point pairs, the printed morph distance, all 60
+    chained frames, and two phase-mode frames (t = 0.25, 0.5 with number_of_frames = 1: what a rank of configs[3] renders)."""
+    case = "a_1920x1080_chain60"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=60)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"])
+    assert rc == 0 and len(frames) == 60
+    ref = G.full(case, "detail")
+    nf = __import__("ctypes").c_int(0)
+    from poppy_amd import capi
+    capi.lib().poppy_hip_pair_begin_info(c.h, __import__("ctypes").byref(nf), None)
+    assert nf.value == int(ref[3])
+    assert dist == float(G.full(case, "printedMorphDist")[0])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1); G.check(case, "prepared2", p2)
+    bad = [j for j, f in enumerate(frames) if G.sha(f) != G.entries(case)[f"frame{j}"]["sha256"]]
+    assert not bad, f"frames {bad} differ from the reference"
+    c.close()
+    c1 = _ctx(number_of_frames=1)
+    for k, t in enumerate(inp["cfg"][4:]):
+        rc, fr, _ = c1.morph(inp["img1"], inp["img2"], phase=float(t))
+        assert rc == 0 and len(fr) == 1
+        G.check(case, f"phase{k}_frame", fr[0], what=f"phase {t}")
+    # the sharded job renders the same frames from ONE resident pair with explicit ratios (poppy_hip_render_many)
+    got = []
+    c1.reset()
+    c1.render_many(np.array(inp["cfg"][4:], np.float64), chain=False, write=lambda f: got.append(f.copy()))
+    for k in range(len(got)):
+        G.check(case, f"phase{k}_frame", got[k])
+    c1.close()
+
+
+def test_cfg3_4k_phase_mode_frame():
+    """BASELINE.json configs[2] geometry: one 3840x2160 phase-mode frame of the real reference, from the raw pair."""
+    case = "a_3840x2160_phase"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=1)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"], phase=0.5)
+    assert rc == 0 and len(frames) == 1
+    assert dist == float(G.full(case, "printedMorphDist")[0])
+    G.check(case, "frame0", frames[0])
+    c.close()
+
+
+def test_distance_flag_writes_nothing():
+    case = "a_512x512_chain30"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=30)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"], distance=True)
+    assert rc == 0 and frames == [] and dist == float(G.full(case, "printedMorphDist")[0])
+    assert c.pair_distance() == dist
+    c.close()
+
+
+def test_dissolve_fixture():
+    case = "x_dissolve_200x150"
+    inp = G.make_inputs.dissolve_inputs(case)
+    c = _ctx()
+    for k, ph in enumerate(inp["phases"]):
+        G.check(case, f"blend{k}", c.dissolve(inp["img1"], inp["img2"], float(ph)), what=f"phase {ph}")
+    c.close()
+
+
+def test_no_match_fallback():
+    """A featureless second image leaves no keypoints: poppy_hip_morph writes the frames the reference's fallback branch means
+    to write (src/poppy.hpp:125-134, with the phase ARGUMENT, -1 in the default mode) and reports POPPY_E_NOMATCH."""
+    import oracle_lib as O
+    from poppy_amd import synth
+    a, _ = synth.gen_pair(256, 256)
+    b = np.full_like(a, 77)
+    c = _ctx(number_of_frames=2)
+    rc, frames, dist = c.morph(a, b, phase=-1.0)
+    assert rc == -5 and len(frames) == 2 and dist is None
+    want = O.dissolve(a, b, -1.0)
+    assert np.array_equal(frames[0], want) and np.array_equal(frames[1], want)
+    c.close()
+
+
+@pytest.mark.parametrize("case", ["b_640x480_lv4", "b_1920x1080_lv4", "b_320x200_lv1"])
+def test_shallow_pyramids(case):
+    """--pyramid 4 / 1: the coarsest level is far larger than one workgroup's LDS (was POPPY_E_UNSUPPORTED in round 1)."""
+    inp = G.bstage_inputs(case)
+    w, h, n, ratios, levels = G.make_inputs.BSTAGE[case]
+    c = _ctx(pyramid_levels=levels)
+    c.set_debug(True)
+    for k, (sr, mr) in enumerate(ratios):
+        out, mp = c.morph_images(inp["c1"], inp["c2"], inp["gabor2"], inp["pts1"], inp["pts2"], sr, mr)
+        G.check(case, f"f{k}_lbmask", c.fetch("lbmask"))
+        G.check(case, f"f{k}_lapBlend", c.fetch("lapBlend"))
+        G.check(case, f"f{k}_frame", out)
+    c.close()
+
+
+def test_download_ring_with_two_slots(monkeypatch):
+    """POPPY_HIP_SLOTS=2: chained frames, then independent frames with a writer and no reset in between — every delivered frame
+    must equal the one rendered with the default slot count."""
+    from poppy_amd import capi, synth
+    w, h = 320, 192
+    c1 = synth.textured_bgr(w, h, 21); c2 = synth.textured_bgr(w, h, 22); g = synth.unit_field(w, h, 11)
+    p1, p2 = synth.point_pairs(w, h, 40, seed=5)
+    ts = np.linspace(0.1, 0.9, 9)
+
+    def run():
+        c = capi.Context(0, number_of_frames=6)
+        c.pair_load(c1, c2, g, p1, p2)
+        a = []
+        c.render_many(np.array([capi.lib().poppy_frame_ratio(j, 6, -1.0) for j in range(6)]), chain=True, write=lambda f: a.append(f.copy()))
+        b = []
+        c.render_many(ts, chain=False, write=lambda f: b.append(f.copy()))
+        c.close()
+        return a, b
+    ref_a, ref_b = run()
+    monkeypatch.setenv("POPPY_HIP_SLOTS", "2")
+    got_a, got_b = run()
+    assert all(np.array_equal(x, y) for x, y in zip(ref_a, got_a)) and len(got_a) == 6
+    assert all(np.array_equal(x, y) for x, y in zip(ref_b, got_b)) and len(got_b) == 9

@@ -142,3 +142,37 @@ def test_procrustes_and_perspective_fit_host(case):
     assert np.float32(sc[0]) == r["scale"] and np.float32(sc[1]) == r["error"]
     G.check(case, "pc_yprime", r["yprime"])
     G.check(case, "prim_persp", capi.perspective_from4(inp["pts1"][:4], inp["pts2"][:4]))
+
+
+def test_dft_plan_tables():
+    """The transform plan of dft_detail2's kernels (pass order, load permutation, float twiddles): same tables as the
+    implementation that reproduced cv::dft bit for bit (tests/golden/dft_plan_fnv.json), and the same permutation /
+    twiddles as the oracle's independent planner implies through dft_detail2 (tests/test_oracle_sequences.py)."""
+    import json, os
+    ref = json.load(open(os.path.join(G.GOLD, "dft_plan_fnv.json")))["fnv1a64"]
+
+    def fnv(chunks):
+        h = 1469598103934665603
+        for c in chunks:
+            for b in c.tobytes():
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+    for n_s, want in ref.items():
+        n = int(n_s)
+        f, itab, wave = capi.dft_plan(n)
+        parts = [np.array([len(f)], np.int32), f, itab] + ([wave] if (n > 5 or n == 4) else [])
+        assert fnv(parts) == want, n
+        assert sorted(itab.tolist()) == list(range(n))                     # a permutation
+        assert int(np.prod(f.astype(np.int64))) == max(n, 1)
+    f, itab, wave = capi.dft_plan(1080)
+    assert f.tolist() == [8, 5, 3, 3, 3]                                    # power of two, then the odd primes descending
+    assert capi.dft_plan(1920)[0].tolist() == [128, 5, 3]
+    k = np.arange(1080)
+    assert np.abs(wave[:, 0] - np.cos(2 * np.pi * k / 1080)).max() < 1e-6 and np.abs(wave[:, 1] + np.sin(2 * np.pi * k / 1080)).max() < 1e-6
+
+
+def test_matcher_hypot_is_libm_hypotf():
+    """point_match.cpp evaluates hypotf by glibc's own closed form; compare with the linked libm on 2e6 inputs."""
+    L = capi.lib()
+    assert L.poppy_hypotf_selfcheck(2000000, 12345) == 0
+    assert L.poppy_hypotf_selfcheck(500000, 999) == 0
