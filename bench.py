@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — morph frames/sec at 1080p (BASELINE.json metric) on N MI355X GPUs of one node.
+"""bench.py — morph frames/sec at 1080p for 60-frame sequences (BASELINE.json metric) on N MI355X GPUs of one node.
 
-A "step" is one 60-frame morph of a synthetic 1080p pair on every rank:
-  N = 1 : the reference's default CLI mode (chained: frame j warps frame j-1; src/poppy.hpp:177-219);
-  N > 1 : frame-range sharding.  The job is ONE 60*N-frame phase-mode morph (N = 8 -> the 480-frame morph of
-          BASELINE.json configs[3]); rank r renders frames [60r, 60r+60) with phase t_j = j / (60 N), each
-          equal to the reference call morph(img1, img2, ..., phase = t_j) with number_of_frames = 1.  The source
-          pair and the mask field are broadcast once from rank 0 over RCCL (torch.distributed "nccl"); there
-          is no data-path collective afterwards.  Per-GPU work is fixed => "scaling": "weak".
-Frames stay in HBM (inputs are resident before the timed region, outputs are not copied back); the PCIe-inclusive
-rate is printed as an extra key, never as `value`.
+N = 1 (BASELINE.json configs[1]).  A step = PAIRS (4) independent synthetic 1080p pairs (seeds 1234 + k), each
+taken through the WHOLE of poppy::morph (src/poppy.hpp:46-248) by the library:
+    poppy_hip_pair_begin_device   raw BGR pair (resident in HBM before the timed region) -> foreground x2, dft_detail2 x2, ORB
+                                  input x2, ORB x2, matcher, gabor2: the real point sets and mask field, nothing synthetic
+    poppy_hip_morph_frames(-1)    the reference's default mode: 60 chained frames, every frame downloaded into pinned host
+                                  memory and handed to a writer callback (poppy_count_frames_cb)
+`value` = frames written / wall time of the timed region: set-up, rendering and the writer hand-off are all inside.  The
+per-frame operator alone on a resident pair with the frames left in HBM (what round 1 reported as `value`) is the extra key
+`resident_pair_fps`.
 
-Output: ONE JSON line on rank 0 (see the driver contract), extended with
-  roofline     : the fused map+remap kernel (k_warp_tile; k_warp4 for odd geometries): 16 B/px (faithful path) + 8 B/px for the lbmask it
-                 computes on the way (m2 in, mask out); the id map is frame-tagged and never cleared,
-                 average launch duration measured live with HIP events on the library's stream (one launch in seven of
-                 the timed region carries the stamps: `launches_timed`);
-  kernels      : the same for every kernel group of the frame (one extra untimed step; "warp" is the timed region's);
-  cpu_baseline : oracle/ (CPU restatement, "port") timed on this box's host cores on a bounded sample.
+N > 1 (configs[3]): ONE 60*N-frame phase-mode morph of one pair (N = 8 -> the 480-frame morph): rank 0 runs the pair set-up,
+the pair state (both images, the mask field's grey complement, the point sets) goes to every rank in one broadcast over
+RCCL/xGMI, rank r renders frames [60r, 60r + 60) with t_j = j / (60 N) — each equal to morph(img1, img2, ..., phase = t_j) with
+number_of_frames = 1 — and hands them to its writer.  No data-path collective afterwards; per-GPU work is fixed => "weak".
+The N = 1 point of THAT workload is the extra key `scaling_baseline` of the N = 1 line (a 60-frame phase-mode morph incl.
+set-up), so an N-sweep is read against it and not against the chained headline.
+
+One JSON line on rank 0 (driver contract) with
+  roofline      the dominant kernel (fused create_map + remap of both sources): algorithmic bytes per launch = 16 B/px (SURVEY.md
+                8d, faithful path: id 4 + src 3 + 3 in, warped 3 + 3 out) x pixels, / the kernel's average launch duration
+                measured live with HIP events attached to the dispatch on the library's stream (one launch in seven of the timed
+                region); `frac_with_rider` adds the 8 B/px of the lbmask the kernel also produces (m2 in, mask out);
+  cpu_baseline  oracle/ (CPU restatement, "port", 1 thread) on 20 chained frames of pair 0 from the GPU's own pair state;
+  parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected);
+  cfg3_4k       configs[2]: one 3840x2160 pair, 120 phase-mode frames, set-up and writer hand-off included, with its own roofline.
 """
 import argparse
 import ctypes
@@ -32,89 +40,123 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H, FRAMES, NPTS = 1920, 1080, 60, 436
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+W, H, FRAMES = 1920, 1080, 60
+PAIRS = 4                      # pairs per step at N = 1
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+WARP_CONTRACT_B_PER_PX = 16.0  # the faithful fused map+remap kernel
+WARP_RIDER_B_PER_PX = 8.0      # m2 in, lbmask out (the kernel computes the blend mask on the way)
 
-# algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel P
+# algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel
 ALGO_BYTES_PER_PX = {
-    "upload+clear": 0.0,                       # wait for the plan upload (the id map is frame-tagged: no clear)
-    "raster": 4.0,                             # every pixel's id written once
-    "warp": 24.0,                              # triMap 4 + c1 3 + c2 3 in, trImg1 3 + trImg2 3 out; lbmask rider: m2 4 in, mask 4 out
-    "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3),      # level 0: u8 L,R + mask in; quarter-size f32 L,R,M out; geometric tail
-    "pyr_tail": 0.0,
-    "collapse": (6 + 4 + 12) + (36 / 4) * (4 / 3) + 12 * (1 / 3),   # G_i (u8 at level 0), mask, lower level L,R,B in; B_i out
-    "unsharp": 12 + 3,                         # fused tile kernel: lapBlend f32x3 in, frame u8x3 out
+    "upload+clear": 0.0, "raster": 4.0, "warp": WARP_CONTRACT_B_PER_PX + WARP_RIDER_B_PER_PX,
+    "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3), "pyr_tail": 0.0,
+    "collapse": (6 + 4 + 12) + (36 / 4) * (4 / 3) + 12 * (1 / 3), "unsharp": 12 + 3,
 }
 
 
-def synth_inputs():
+def synth_pair(w, h, k):
     from poppy_amd import synth
-    a, b = synth.gen_pair(W, H)
-    g = synth.unit_field(W, H, 11)
-    p1, p2 = synth.point_pairs(W, H, NPTS, seed=5, dup=0, oob=0)       # 436 matches + 4 corners
-    return a, b, g, p1, p2
+    return synth.gen_pair(w, h, seed=1234 + k)
 
 
-def cpu_baseline(a, b, g, p1, p2, frames=20):
-    """oracle/ timed on the host: `frames` chained 1080p frames of the same workload, one thread."""
+def roofline_of(ctx, warp_ms, warp_n, w, h):
+    per_launch_ms = warp_ms / max(warp_n, 1)
+    P = w * h
+    contract = WARP_CONTRACT_B_PER_PX * P
+    ach = contract / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    ach_r = (WARP_CONTRACT_B_PER_PX + WARP_RIDER_B_PER_PX) * P / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": ctx.warp_kernel_name() + " (fused create_map + remap of both sources; also emits lbmask)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "algo_bytes_per_launch": int(contract), "algo_bytes_note": "16 B/px x pixels (SURVEY.md 8d faithful path)",
+            "achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4),
+            "avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
+            "traffic": None, "traffic_note": "PMC passes cannot run inside the bench; see profiles/ for the counter passes of this command"}
+
+
+def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):
+    """oracle/ on `frames` chained frames of pair 0, fed with the pair state the GPU set-up produced (points, gabor2), one thread;
+    its last frame is compared with the same frame of the GPU run."""
     import oracle_lib as O
-    from poppy_amd import capi
     O.lib()
-    L = capi.lib()
+    p1, p2 = ctx.pair_points()
+    g = ctx.fetch("gabor2")
     cur, pts = a, p1
     t0 = time.perf_counter()
-    for j in range(1, frames + 1):
-        s = L.poppy_frame_ratio(j, FRAMES, -1.0)
+    for j in range(frames):
+        s = O.frame_ratio(j, FRAMES, -1.0)
         cur, pts = O.morph_images(cur, b, g, pts, p2, s, s, 64)
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} chained 1080p frames (j=1..{frames} of the 60-frame sequence) through oracle/liboracle.so, "
-                      f"{dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+    diff = int((cur != gpu_frames[frames - 1]).sum())
+    base = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} chained {a.shape[1]}x{a.shape[0]} frames (j = 0..{frames - 1} of the 60-frame sequence of pair 0, the per-frame operator "
+                      f"only: the oracle's pair set-up at this size takes minutes) through oracle/liboracle.so, {dt:.1f} s on 1 of {os.cpu_count()} host threads; "
+                      "BASELINE.md: the real reference ran 0.87 frames/s incl. set-up on the build container"}
+    par = {"frame": frames - 1, "equal": diff == 0, "differing_bytes": diff,
+           "what": "frame 19 of pair 0 as written by the GPU run vs the oracle's 20th chained frame from the same pair state"}
+    return base, par
 
 
-def cpu_baseline_threads(a, b, g, p1, p2, threads, per_thread=2):
-    """The same oracle on independent phase-mode frames (t_j = j / 60), one host thread each: what the CPU path does with all
-    the cores it is given (ctypes releases the GIL for the duration of a frame)."""
-    import threading
-    import oracle_lib as O
-    O.lib()
+def run_cfg3_4k(capi, torch, dev, steps):
+    """BASELINE.json configs[2]: 3840x2160 pair, 120 phase-mode frames (t_j = j / 120), set-up and writer hand-off inside."""
+    w, h, n = 3840, 2160, 120
+    a, b = synth_pair(w, h, 0)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    ctx = capi.Context(dev.index or 0, number_of_frames=1)
+    ts = np.arange(1, n + 1) / float(n + 1)            # 120 in-between frames: 0 < t < 1 (t = 0 and 1 are plain copies, src/poppy.hpp:54-70)
 
-    def work(k):
-        for i in range(per_thread):
-            t = ((k * per_thread + i) % (FRAMES - 1) + 1) / float(FRAMES)
-            O.morph_images(a, b, g, p1, p2, t, t, 64)
-    th = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    def step():
+        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), w, h)
+        return ctx.render_many_counted(ts, chain=False)
+    step()
+    ctx.set_timing(2)
+    ctx.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    got = 0
+    for _ in range(steps):
+        got += step()
+    ctx.sync()
     dt = time.perf_counter() - t0
-    return {"value": threads * per_thread / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{threads * per_thread} independent phase-mode 1080p frames, {per_thread} per thread on {threads} of "
-                      f"{os.cpu_count()} host threads, {dt:.1f} s"}
+    warp_ms, warp_n = next(((ms, c) for nm, ms, c in ctx.timing_summary() if nm == "warp"), (0.0, 0))
+    ctx.set_timing(0)
+    # the same frames left in HBM, pair resident (frame loop only)
+    ctx.render_many(ts, chain=False); ctx.sync()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        ctx.render_many(ts, chain=False)
+    ctx.sync()
+    dt_res = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), w, h)
+    setup_ms = (time.perf_counter() - t2) * 1e3
+    out = {"workload": f"{w}x{h} pair, {n} phase-mode frames per step, pair set-up from the raw images and the writer hand-off included",
+           "value": round(got / dt, 2), "unit": "frames/s", "mpix_per_s": round(got / dt * w * h / 1e6, 1), "steps": steps,
+           "ms_per_step": round(dt / steps * 1e3, 3), "resident_pair_fps": round(steps * n / dt_res, 1), "pair_setup_ms": round(setup_ms, 2),
+           "roofline": roofline_of(ctx, warp_ms, warp_n, w, h)}
+    ctx.close()
+    del ta, tb
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["chain", "phase"], default=None, help="default: chain at N=1, phase at N>1")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-setup", action="store_true", help="skip the pair set-up timing (poppy_hip_pair_begin)")
-    ap.add_argument("--headline-only", action="store_true",
-                    help="only the timed region and the per-kernel step (no phase-mode / batched / download / set-up extras): "
-                         "the command the rocprofv3 summaries under profiles/ are taken from")
-    ap.add_argument("--width", type=int, default=None, help="override the 1080p headline size (e.g. 3840 for BASELINE configs[2])")
+    ap.add_argument("--no-4k", action="store_true", help="skip the configs[2] (3840x2160 x 120) object")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed region (the command the rocprofv3 summaries under profiles/ are taken from)")
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 60)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
     args = ap.parse_args()
-    global W, H, FRAMES
+    global W, H, FRAMES, PAIRS
     if args.width and args.height:
         W, H = args.width, args.height
     if args.frames:
         FRAMES = args.frames
+    if args.pairs:
+        PAIRS = args.pairs
 
     import torch
     import torch.distributed as dist
@@ -128,9 +170,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    # POPPY_BENCH_ONE_GPU=1 is a rehearsal of the N > 1 path on a single-GPU box (every rank on GPU 0, gloo as the
-    # backend, the pair staged through host memory for the broadcast); its numbers mean nothing
-    rehearsal = os.environ.get("POPPY_BENCH_ONE_GPU") == "1" and world > 1
+    rehearsal = os.environ.get("POPPY_BENCH_ONE_GPU") == "1" and world > 1      # every rank on GPU 0 over gloo: numbers mean nothing
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
@@ -142,221 +182,208 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    mode = args.mode or ("chain" if world == 1 else "phase")
-    if mode == "chain" and world > 1:
-        raise SystemExit("chained mode is sequential by construction (SURVEY.md F5); use --mode phase for N>1")
-
-    # ---- inputs: generated on rank 0, broadcast once over RCCL, resident in HBM before timing --------------
-    if rehearsal:
-        cpu = torch.device("cpu")
-        host = sharding.pair_tensors(torch, cpu, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
-        sharding.broadcast_pair(dist, host, src=0)
-        ta, tb, tg, tp = [t.to(dev) for t in host]
+    P = W * H
+    if world == 1:
+        out = bench_single(args, torch, capi, dev, local)
     else:
-        ta, tb, tg, tp = sharding.pair_tensors(torch, dev, W, H, NPTS + 4, synth_inputs() if rank == 0 else None)
-        if world > 1:
-            sharding.broadcast_pair(dist, (ta, tb, tg, tp), src=0)
+        out = bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, rehearsal)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_single(args, torch, capi, dev, local):
+    P = W * H
+    pairs_host = [synth_pair(W, H, k) for k in range(PAIRS)]
+    pairs_dev = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in pairs_host]
     torch.cuda.synchronize()
-    pts = tp.cpu().numpy()
-    p1r, p2r = np.ascontiguousarray(pts[0]), np.ascontiguousarray(pts[1])
-
     ctx = capi.Context(local, number_of_frames=FRAMES)
-    ctx.pair_load_device(ta.data_ptr(), tb.data_ptr(), tg.data_ptr(), W, H, p1r, p2r)
-
-    total_frames = FRAMES * world
-    if mode == "chain":
-        shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
-    else:
-        shapes = sharding.phase_schedule(rank, world, FRAMES)
 
     def step():
-        ctx.reset()
-        ctx.render_many(shapes, chain=(mode == "chain"))
+        n = 0
+        for ta, tb in pairs_dev:
+            ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+            n += ctx.morph_frames_counted(-1.0)
+        return n
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch, one launch in seven, on the stream it is launched on
+    ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    written = 0
+    for _ in range(args.steps):
+        written += step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    warp_ms, warp_n = next(((ms, c) for nm, ms, c in ctx.timing_summary() if nm == "warp"), (0.0, 0))
+    ctx.set_timing(0)
+    assert written == args.steps * PAIRS * FRAMES, (written, args.steps * PAIRS * FRAMES)
+    fps = written / dt
+
+    out = {
+        "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H, FRAMES) == (1920, 1080, 60) else f"morph frames/sec at {W}x{H}, {FRAMES}-frame sequence; Mpix/s warped",
+        "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "timed_region_s": round(dt, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8+f32",
+        "dtype_note": "u8 pixels and fixed-point remap, f32 pyramid and unsharp, f64 Gabor sums; bit-compatible with the reference (no FMA contraction)",
+        "data": "synthetic (integer-defined shapes pairs, seeds 1234+k: poppy_amd/synth.py); point sets and mask field come from the real pair set-up",
+        "config": {"workload": f"{W}x{H} pairs, {FRAMES}-frame morph each, default chained mode (BASELINE.json configs[1]): per step {PAIRS} pairs x "
+                               "(pair set-up from the raw images + 60 chained frames handed to a writer through pinned host memory), pyramid_levels 64",
+                   "pairs_per_step": PAIRS, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
+                   "parallelism": "1 GPU"},
+        "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
+    }
+    if args.headline_only:
+        ctx.close()
+        return out
+
+    # ---- extras, all outside the timed region -------------------------------------------------------------------------
+    ta, tb = pairs_dev[0]
+    a_h, b_h = pairs_host[0]
+    ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+    p1, p2 = ctx.pair_points()
+    out["config"]["point_pairs_pair0"] = int(len(p1))
+    shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
+    reps = max(args.steps, 10)
+    # per-frame operator on the resident pair, frames left in HBM (round 1's `value`)
+    ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ctx.reset(); ctx.render_many(shapes, chain=True)
+    ctx.sync()
+    out["resident_pair_fps"] = round(reps * FRAMES / (time.perf_counter() - t1), 1)
+    # the same with the writer hand-off
+    ctx.reset(); ctx.render_many_counted(shapes, chain=True)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ctx.reset(); ctx.render_many_counted(shapes, chain=True)
+    ctx.sync()
+    out["resident_pair_fps_with_writer"] = round(reps * FRAMES / (time.perf_counter() - t1), 1)
+    # pair set-up alone
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+    out["pair_setup_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 2)
+    # N = 1 point of the sharded workload (configs[3]): a 60-frame phase-mode morph incl. set-up and writer
+    ph = np.arange(FRAMES) / float(FRAMES)
+
+    def phase_step():
+        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+        return ctx.morph_frames_counted(0.0) + ctx.render_many_counted(ph[1:], chain=False)   # frame 0 (t = 0) is a copy of image 1 (src/poppy.hpp:54-62)
+    phase_step()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        phase_step()
+    ctx.sync()
+    dtp = time.perf_counter() - t1
+    ctx.render_many(ph[1:], chain=False); ctx.sync()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ctx.render_many(ph[1:], chain=False)
+    ctx.sync()
+    out["scaling_baseline"] = {"workload": f"one {FRAMES}-frame phase-mode morph per step (what every rank of --gpus N does), set-up and writer included",
+                               "fps": round(reps * FRAMES / dtp, 1), "frames_only_fps": round(reps * (FRAMES - 1) / (time.perf_counter() - t1), 1)}
+    # per-kernel breakdown: one untimed sequence with events around every kernel group
+    ctx.set_timing(1)
+    ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
+    kernels = {}
+    tot = 0.0
+    for name, ms, cnt in ctx.timing_summary():
+        per = ms / max(cnt, 1)
+        tot += ms
+        ab = ALGO_BYTES_PER_PX.get(name, 0.0) * P
+        kernels[name] = {"avg_ms": round(per, 5), "launch_groups": cnt, "algo_MB": round(ab / 1e6, 3),
+                         "GBps": round(ab / (per * 1e-3) / 1e9, 1) if per > 0 else None}
+    ctx.set_timing(0)
+    out["kernels"] = kernels
+    out["kernel_groups_ms_per_frame"] = round(tot / FRAMES, 4)
+
+    if not args.no_cpu_baseline:
+        try:
+            ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+            got = []
+            ctx.reset()
+            ctx.render_many(shapes[:20], chain=True, write=lambda f: got.append(f.copy()))
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline_and_parity(ctx, a_h, b_h, got, 20)
+        except Exception as e:   # the checker is optional for the measurement, never for parity
+            out["cpu_baseline"] = {"value": None, "error": str(e)}
+    ctx.close()
+    if not args.no_4k and (W, H) == (1920, 1080):
+        try:
+            out["cfg3_4k"] = run_cfg3_4k(capi, torch, dev, max(3, min(args.steps, 10)))
+        except Exception as e:
+            out["cfg3_4k"] = {"error": str(e)}
+    return out
+
+
+def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, rehearsal):
+    """configs[3]: one 60*world-frame phase-mode morph; set-up on rank 0, one broadcast of the pair state, frame ranges per rank."""
+    P = W * H
+    total = FRAMES * world
+    cdev = torch.device("cpu") if rehearsal else dev
+    ctx = capi.Context(local, number_of_frames=1)
+    if rank == 0:
+        a, b = synth_pair(W, H, 0)
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    ts = sharding.phase_schedule(rank, world, FRAMES)
+    link = sharding.PairLink(torch, dist, capi, ctx, rank, world, W, H, cdev, use_library=not rehearsal)
+
+    def step():
+        if rank == 0:
+            ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+        link.broadcast(root=0)
+        n = 0
+        for t in ts[:1]:
+            if t == 0.0:                      # global frame 0: the reference's phase == 0 short-circuit, a copy of image 1
+                n += ctx.morph_frames_counted(0.0)
+        return n + ctx.render_many_counted(ts[1:] if ts[0] == 0.0 else ts, chain=False)
 
     def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ctx.sync(); torch.cuda.synchronize()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch (k_warp_tile), one launch in seven, on the stream it is launched on
     fence()
     t0 = time.perf_counter()
+    n = 0
     for _ in range(args.steps):
-        step()
+        n += step()
     fence()
     dt = time.perf_counter() - t0
-    warp_ms, warp_n = next(((ms, cnt) for name, ms, cnt in ctx.timing_summary() if name == "warp"), (0.0, 0))
-    # per-kernel breakdown: one extra, untimed step with events around every kernel group (frames are then issued
-    # launch by launch instead of through the captured graph)
-    ctx.set_timing(1)
-    step()
-    ctx.sync()
-    summary = ctx.timing_summary()
-    ctx.set_timing(0)
-
-    dt_max = sharding.max_over_ranks(torch, dist, dt, torch.device("cpu") if rehearsal else dev) if world > 1 else dt
-
-    # N = 1 only: the same 60 frames as independent phase-mode frames t_j = j/60 (what every rank of an N > 1 run
-    # does), so the driver's N-sweep has a like-for-like single-GPU point beside the chained headline
-    phase_fps = None
-    if world == 1 and mode == "chain" and not args.headline_only:
-        ph = sharding.phase_schedule(0, 1, FRAMES)
-        ctx.reset(); ctx.render_many(ph, chain=False); ctx.sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.reset(); ctx.render_many(ph, chain=False)
-        ctx.sync()
-        phase_fps = args.steps * FRAMES / (time.perf_counter() - t1)
-
-    # N = 1 only: BASELINE.json configs[4] in miniature — several independent pairs on this GPU at once, each a chained
-    # 60-frame morph driven by its own host thread and context (pairs never depend on each other)
-    batched_fps, batched_pairs = None, 3
-    if world == 1 and mode == "chain" and not args.no_setup and not args.headline_only:
-        import threading
-        extra = []
-        for _ in range(batched_pairs - 1):
-            cx = capi.Context(local, number_of_frames=FRAMES)
-            cx.pair_load_device(ta.data_ptr(), tb.data_ptr(), tg.data_ptr(), W, H, p1r, p2r)
-            extra.append(cx)
-        allc = [ctx] + extra
-
-        def run_pair(cx, n):
-            for _ in range(n):
-                cx.reset(); cx.render_many(shapes, chain=True)
-            cx.sync()
-        for cx in allc:
-            run_pair(cx, 1)
-        t1 = time.perf_counter()
-        th = [threading.Thread(target=run_pair, args=(cx, args.steps)) for cx in allc]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        batched_fps = batched_pairs * args.steps * FRAMES / (time.perf_counter() - t1)
-        for cx in extra:
-            cx.close()
-
-    # PCIe-inclusive rate: every frame handed to a writer callback from pinned host memory (the library pipelines the
-    # downloads behind the rendering), rank 0, not `value`
-    pcie_fps = None
-    if rank == 0 and not args.headline_only:
-        seen = [0]
-
-        def sink(frame):
-            seen[0] += 1
-        ctx.reset(); ctx.render_many(shapes, chain=(mode == "chain"), write=sink); ctx.sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.reset(); ctx.render_many(shapes, chain=(mode == "chain"), write=sink)
-        ctx.sync()
-        pcie_fps = args.steps * FRAMES / (time.perf_counter() - t1)
-        assert seen[0] == (args.steps + 1) * FRAMES
-
-    # measured device-copy ceiling: a plain device-to-device copy moving as many bytes as the warp kernel does per
-    # launch (14 B/px read + 14 B/px written), timed with events on torch's stream; the vendor peak is not reachable by any kernel
-    copy_ceiling = None
+    assert n == args.steps * FRAMES
+    dt_max = link.max_time(dt)
+    # steady state: the broadcast pair resident, frames only (in HBM)
+    ctx.render_many(ts[1:] if ts[0] == 0.0 else ts, chain=False)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render_many(ts[1:] if ts[0] == 0.0 else ts, chain=False)
+    fence()
+    dt_f = link.max_time(time.perf_counter() - t1)
+    out = None
     if rank == 0:
-        try:
-            nbytes = 14 * W * H
-            src_t = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
-            dst_t = torch.empty_like(src_t)
-            for _ in range(3):
-                dst_t.copy_(src_t)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
-            e0.record()
-            for _ in range(reps):
-                dst_t.copy_(src_t)
-            e1.record(); torch.cuda.synchronize()
-            copy_ceiling = 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del src_t, dst_t
-        except Exception as e:
-            print(f"bench.py: copy ceiling failed: {e}", file=sys.stderr)
-
-    # pair set-up from the raw images (pre-ORB chain, ORB, matcher, gabor2; once per pair), rank 0, outside the timed
-    # region: reported beside `value`, which is the per-frame operator on a resident pair
-    setup_ms = None
-    if rank == 0 and not args.no_setup and not args.headline_only:
-        try:
-            a_h, b_h = ta.cpu().numpy(), tb.cpu().numpy()
-            c2 = capi.Context(local, number_of_frames=FRAMES)
-            c2.pair_begin(a_h, b_h)
-            t1 = time.perf_counter()
-            c2.pair_begin(a_h, b_h)
-            setup_ms = (time.perf_counter() - t1) * 1e3
-            c2.close()
-        except Exception as e:
-            setup_ms = None
-            print(f"bench.py: pair_begin failed: {e}", file=sys.stderr)
-
-    if rank == 0:
-        fps = args.steps * total_frames / dt_max
-        P = W * H
-        kernels = {}
-        group_ms_per_frame = sum(ms for _, ms, _ in summary) / FRAMES
-        summary = [(n, ms, cnt) if n != "warp" else (n, warp_ms, warp_n) for n, ms, cnt in summary]
-        for name, ms, cnt in summary:
-            per_launch_ms = ms / max(cnt, 1)
-            ab = ALGO_BYTES_PER_PX.get(name, 0.0) * P
-            kernels[name] = {"avg_ms": round(per_launch_ms, 5), "launch_groups": cnt,
-                             "algo_MB": round(ab / 1e6, 3), "GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 1) if per_launch_ms > 0 else None}
-        wk = kernels.get("warp", {})
-        achieved = wk.get("GBps") or 0.0
-        traffic, traffic_src = None, None            # PMC counters need their own rocprofv3 passes: quoted from profiles/
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_m_warp_pmc.json"))).get(f"{W}x{H}", {})
-            pm = pm.get("k_warp_tile") if ctx.last_warp_kind() == 1 else pm.get("k_warp4")
-            if pm:
-                traffic = pm["fetch_bytes"] + pm["write_bytes"]
-                traffic_src = "profiles/r01_m_warp.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-        except (OSError, ValueError):
-            pass
+        fps = args.steps * total / dt_max
         out = {
-            "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H) == (1920, 1080) else f"morph frames/sec at {W}x{H}; Mpix/s warped",
-            "value": round(fps, 2), "unit": "frames/s",
-            "mpix_per_s": round(fps * P / 1e6, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8+f32",
-            "dtype_note": "u8 pixels and fixed-point remap, f32 pyramid and unsharp; bit-compatible with the reference (no FMA contraction)",
-            "data": "synthetic (integer-defined shapes pair, synthetic mask field and 436+4 point pairs; poppy_amd/synth.py)",
-            "config": {"workload": f"{W}x{H} pair, {FRAMES}-frame morph per GPU ({total_frames} frames total), "
-                                   f"{'default chained mode' if mode == 'chain' else 'phase-mode frame-range sharding'}, "
-                                   "pyramid_levels 64, per-frame operator on a resident pair",
-                       "frames_per_gpu": FRAMES, "mode": mode, "points": NPTS + 4, "parallelism": f"frame-range x{world}"},
-            "roofline": {"bound": "hbm", "kernel": ("k_warp_tile" if ctx.last_warp_kind() == 1 else "k_warp4") + " (fused create_map + remap of both sources + lbmask)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algo_bytes_per_launch": int(ALGO_BYTES_PER_PX["warp"] * P), "avg_launch_ms": wk.get("avg_ms"), "launches_timed": warp_n,
-                         "copy_ceiling_GBps": round(copy_ceiling, 1) if copy_ceiling else None,
-                         "copy_ceiling_note": "device-to-device copy of 14+14 B/px (buffers that fit the MALL; tools/micro/warp_skeleton.hip measures the kernel's own access mix on cold data: profiles/r01_m_warp.md), measured in this run; "
-                                              "traffic / launch time is the figure to hold against it"},
-            "kernels": kernels,
-            "kernel_groups_ms_per_frame": round(group_ms_per_frame, 4),
-            "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
-            "phase_mode_fps": round(phase_fps, 1) if phase_fps else None,
-            "batched_pairs_fps": {"pairs": batched_pairs, "value": round(batched_fps, 1)} if batched_fps else None,
-            "pair_setup_ms": round(setup_ms, 2) if setup_ms else None,
-            "fps_including_setup": round(FRAMES / (setup_ms * 1e-3 + FRAMES / fps), 1) if setup_ms and world == 1 else None,
+            "metric": "morph frames/sec at 1080p; Mpix/s warped (one %d-frame phase-mode morph sharded by frame range)" % total,
+            "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32",
+            "data": "synthetic (integer-defined shapes pair, poppy_amd/synth.py); pair state from the real pair set-up on rank 0",
+            "config": {"workload": f"{W}x{H} pair, ONE {total}-frame phase-mode morph (BASELINE.json configs[3] at N = 8): per step the pair set-up on rank 0, "
+                                   f"one broadcast of the pair state ({link.how}), then {FRAMES} frames per GPU handed to a writer",
+                       "frames_per_gpu": FRAMES, "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
+                       "broadcast_bytes": link.nbytes},
+            "frames_only_fps": round(args.steps * total / dt_f, 1),
+            "scaling_note": "read against `scaling_baseline.fps` (with set-up) or `scaling_baseline.frames_only_fps` of the --gpus 1 line, not against its chained `value`",
         }
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                a_h, b_h, g_h = ta.cpu().numpy(), tb.cpu().numpy(), tg.cpu().numpy()
-                out["cpu_baseline"] = cpu_baseline(a_h, b_h, g_h, p1r, p2r)
-                if not args.headline_only and (W, H) == (1920, 1080):
-                    out["cpu_baseline_all_cores"] = cpu_baseline_threads(a_h, b_h, g_h, p1r, p2r, max(1, min(64, (os.cpu_count() or 1) // 2)))
-            except Exception as e:   # the checker is optional for the measurement, never for parity
-                out["cpu_baseline"] = {"value": None, "error": str(e)}
-        print(json.dumps(out), flush=True)
-
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -205,6 +205,12 @@ int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* ctx,
  * exact sums that OpenCV's double-precision DFT correlation yields (DESIGN.md section 7 has the fine print).          */
 int poppy_hip_pair_begin(poppy_hip_ctx* ctx, const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2,
                          int width, int height);
+/* poppy_hip_pair_begin with the two raw images already in this GPU's memory (tight rows, width*3 bytes each): the throughput
+ * path of a caller whose decoder or previous stage left the images in HBM, and what bench.py times.                      */
+int poppy_hip_pair_begin_device(poppy_hip_ctx* ctx, const void* d_bgr1, const void* d_bgr2, int width, int height);
+/* A poppy_write_cb that only counts: ++*(long long*)user.  For callers (and the benchmark) that want the frame hand-off —
+ * every frame downloaded into pinned host memory and presented to the writer — without a consumer of their own.           */
+void poppy_count_frames_cb(void* user, const uint8_t* bgr, int width, int height, size_t stride);
 /* nfeatures and the two dft_detail2 values of the last poppy_hip_pair_begin */
 /* Opt-in quality mode with no counterpart in the reference's live code: pair set-up as poppy_hip_pair_begin, but the point
  * pairs come from ORB descriptors (ORB::compute on both keypoint sets, 2-NN both ways, ratio test, symmetry test) instead of
@@ -242,13 +248,57 @@ int poppy_hip_pair_points(poppy_hip_ctx* ctx, float* points1, float* points2, in
 int poppy_hip_render_many(poppy_hip_ctx* ctx, const double* shape_ratio, const double* mask_ratio, int n, int chain,
                           poppy_write_cb write, void* user);
 
+/* ---- multi-GPU (implementation notes in poppy_amd/csrc/comm.cpp) ----------------------------------------------
+ * The path shards by FRAMES of one pair in phase mode (each frame = morph(.., phase = t_j) with number_of_frames = 1,
+ * src/poppy.hpp:186-200,234-235) and by PAIRS (the pairs loop of the CLI, src/poppy.cpp:266-328).  The only exchange is the pair
+ * state — both images, the mask field's grey complement, the point sets: one contiguous allocation — from the GPU that ran the
+ * pair set-up to the others, as ONE ncclBroadcast over RCCL / xGMI.  librccl is loaded on first use.
+ *
+ * One process per GPU:  comm_id on one rank -> the 128 bytes to the others by any out-of-band channel -> comm_init on every
+ * rank's context -> per pair: pair_begin on the root, pair_broadcast everywhere, render_many on every rank's frame range.
+ *   comm_id / comm_init / comm_free   ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for this context's device
+ *   pair_broadcast                    the resident pair of `root` becomes the resident pair of every rank (non-root contexts
+ *                                     allocate for width x height); with auto-align, phase == 1 on a receiver writes the ALIGNED image
+ *   comm_max                          max over the ranks of a host double (step timing)
+ *   pair_state_bytes / pair_export_device / pair_import_device   the same packed state to / from a caller's device buffer, for
+ *                                     callers with a transport of their own                                                 */
+#define POPPY_COMM_ID_BYTES 128
+int poppy_hip_comm_id(uint8_t* id128);
+int poppy_hip_comm_init(poppy_hip_ctx* ctx, int rank, int world, const uint8_t* id128);
+int poppy_hip_comm_free(poppy_hip_ctx* ctx);
+int poppy_hip_pair_broadcast(poppy_hip_ctx* ctx, int root, int width, int height);
+int poppy_hip_comm_max(poppy_hip_ctx* ctx, double* value);
+int poppy_hip_pair_state_bytes(int width, int height, size_t* bytes);
+int poppy_hip_pair_export_device(poppy_hip_ctx* ctx, void* d_dst, size_t bytes);
+int poppy_hip_pair_import_device(poppy_hip_ctx* ctx, const void* d_src, size_t bytes, int width, int height);
+/* One process, several GPUs (a drop-in behind the reference's single-process CLI): one host thread + one context per device,
+ * communicators from ncclCommInitAll.
+ *   morph_sharded  ONE total_frames-frame phase-mode morph of the pair: frame j = morph(img1, img2, .., phase = j / total_frames)
+ *                  with number_of_frames = 1 (frame 0 is the phase == 0 copy of image 1); device k renders the k-th contiguous
+ *                  share.  `write` is called concurrently from n_devices threads, each with ascending frame indices.
+ *   morph_pairs    n_pairs independent pairs, each one whole poppy_hip_morph(.., phase, ..) (default chained mode for phase < 0),
+ *                  taken off a shared counter by contexts_per_device host threads per GPU (2-3 fill a GPU: a chained sequence is
+ *                  a latency chain).  `source` hands out pair p's two images (pointers must stay valid until the pair's last
+ *                  frame was written; return 0); `write` gets (pair, frame) and is called concurrently.  No communication.
+ * err (may be NULL) receives the message of the first failure.                                                              */
+typedef void (*poppy_write_indexed_cb)(void* user, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
+typedef int (*poppy_pair_source_cb)(void* user, int pair_index, const uint8_t** bgr1, size_t* stride1, const uint8_t** bgr2, size_t* stride2);
+typedef void (*poppy_write_pair_cb)(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
+int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_settings* settings,
+                            const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2, int width, int height,
+                            int total_frames, poppy_write_indexed_cb write, void* user, char* err, size_t err_len);
+int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings, int n_pairs,
+                          int width, int height, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
+                          char* err, size_t err_len);
+
 /* No-match fallback  img2*phase + img1*(1-phase)  (src/poppy.hpp:125-134; u8 addWeighted,
  * OCV/core/src/arithm.simd.hpp:1705-1755).                                                          */
 int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, const uint8_t* img2, size_t stride2,
                        int width, int height, double phase, uint8_t* dst, size_t dst_stride);
 
 /* ---- diagnostics: copy an intermediate of the LAST frame to the host (parity tests) -----------
- * names: "triMap"(i32 HxW) "trImg1" "trImg2"(u8 HxWx3) "lbmask"(f32 HxW) "lapBlend" "unsharp"(f32 HxWx3)
+ * names: "triMap"(i32 HxW) "trImg1" "trImg2"(u8 HxWx3) "lbmask"(f32 HxW) "lapBlend" "unsharp"(f32 HxWx3);
+ * of the resident pair: "gabor2"(f32 HxWx3, not on ranks that received the pair by broadcast) "m2"(f32 HxW)
  * "unsharp" is only available after poppy_hip_set_debug(ctx, 1).                                       */
 int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
 /* Which warp kernel rendered the last frame: 1 = the packed-arithmetic kernel (every triangle matrix within the range the

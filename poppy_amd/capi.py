@@ -30,7 +30,9 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_dft_plan", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
+    "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
+    "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
@@ -96,6 +98,17 @@ def lib():
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_points.argtypes = [vp, vp, vp, i, vp]
         L.poppy_dft_plan.argtypes = [i, vp, vp, vp, vp]
+        L.poppy_hip_comm_id.argtypes = [vp]
+        L.poppy_hip_comm_init.argtypes = [vp, i, i, vp]
+        L.poppy_hip_comm_free.argtypes = [vp]
+        L.poppy_hip_pair_broadcast.argtypes = [vp, i, i, i]
+        L.poppy_hip_comm_max.argtypes = [vp, vp]
+        L.poppy_hip_pair_state_bytes.argtypes = [i, i, vp]
+        L.poppy_hip_pair_export_device.argtypes = [vp, vp, sz]
+        L.poppy_hip_pair_import_device.argtypes = [vp, vp, sz, i, i]
+        L.poppy_hip_morph_sharded.argtypes = [vp, i, vp, vp, sz, vp, sz, i, i, i, vp, vp, vp, sz]
+        L.poppy_hip_morph_pairs.argtypes = [vp, i, i, vp, i, i, i, d, vp, vp, vp, vp, sz]
+        L.poppy_hip_pair_begin_device.argtypes = [vp, vp, vp, i, i]
         L.poppy_hip_morph.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, vp, vp, vp]
         L.poppy_hip_pair_distance.argtypes = [vp, vp]
         L.poppy_printed_morph_distance.argtypes = [vp, vp, i, i, i, vp]
@@ -180,6 +193,87 @@ def radial_gradient(w, h):
     if rc:
         raise PoppyError(f"poppy_radial_gradient: {rc}")
     return out
+
+
+WRITE_INDEXED_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
+PAIR_SOURCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+WRITE_PAIR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
+
+
+def comm_id():
+    """128 bytes to hand to every rank's Context.comm_init (ncclGetUniqueId)."""
+    b = (C.c_uint8 * 128)()
+    rc = lib().poppy_hip_comm_id(b)
+    if rc:
+        raise PoppyError(f"poppy_hip_comm_id: {rc} (librccl missing?)")
+    return bytes(b)
+
+
+def pair_state_bytes(w, h):
+    n = C.c_size_t(0)
+    lib().poppy_hip_pair_state_bytes(w, h, C.byref(n))
+    return n.value
+
+
+def morph_sharded(devices, bgr1, bgr2, total_frames, collect=True, **settings):
+    """One total_frames-frame phase-mode morph across `devices` (one process, one thread per GPU): list of frames by index."""
+    a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
+    h, w = a.shape[:2]
+    s = PoppySettings(); lib().poppy_settings_default(C.byref(s))
+    for k, v in settings.items():
+        setattr(s, k, v)
+    frames = {}
+    import threading
+    lock = threading.Lock()
+
+    def cb(user, idx, ptr, ww, hh, stride):
+        f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy()
+        with lock:
+            frames[idx] = f
+    fn = WRITE_INDEXED_CB(cb) if collect else None
+    dv = (C.c_int * len(devices))(*devices)
+    err = C.create_string_buffer(512)
+    rc = lib().poppy_hip_morph_sharded(dv, len(devices), C.byref(s), _p(a), w * 3, _p(b), w * 3, w, h, total_frames,
+                                       C.cast(fn, C.c_void_p) if fn else None, None, err, 512)
+    if rc:
+        raise PoppyError(f"poppy_hip_morph_sharded: {rc}: {err.value.decode()}")
+    return [frames[j] for j in sorted(frames)]
+
+
+def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True, **settings):
+    """`pairs` = list of (bgr1, bgr2): every pair one whole poppy::morph, spread over the devices.  Returns {pair: [frames]}
+    (or the number of frames written when collect is False)."""
+    pairs = [(np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)) for a, b in pairs]
+    h, w = pairs[0][0].shape[:2]
+    s = PoppySettings(); lib().poppy_settings_default(C.byref(s))
+    for k, v in settings.items():
+        setattr(s, k, v)
+    out = {}
+    count = [0]
+    import threading
+    lock = threading.Lock()
+
+    def src(user, p, pa, sa, pb, sb):
+        pa[0] = pairs[p][0].ctypes.data; sa[0] = w * 3
+        pb[0] = pairs[p][1].ctypes.data; sb[0] = w * 3
+        return 0
+
+    def wr(user, p, j, ptr, ww, hh, stride):
+        if collect:
+            f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy()
+            with lock:
+                out.setdefault(p, {})[j] = f
+        else:
+            with lock:
+                count[0] += 1
+    fs, fw = PAIR_SOURCE_CB(src), WRITE_PAIR_CB(wr)
+    dv = (C.c_int * len(devices))(*devices)
+    err = C.create_string_buffer(512)
+    rc = lib().poppy_hip_morph_pairs(dv, len(devices), contexts_per_device, C.byref(s), len(pairs), w, h, phase,
+                                     C.cast(fs, C.c_void_p), C.cast(fw, C.c_void_p), None, err, 512)
+    if rc:
+        raise PoppyError(f"poppy_hip_morph_pairs: {rc}: {err.value.decode()}")
+    return {p: [v[j] for j in sorted(v)] for p, v in out.items()} if collect else count[0]
 
 
 def dft_plan(n):
@@ -309,6 +403,48 @@ class Context:
         nf = C.c_int(0); d = (C.c_double * 2)()
         lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), d)
         return nf.value, (d[0], d[1])
+
+    def comm_init(self, rank, world, id128):
+        buf = (C.c_uint8 * 128).from_buffer_copy(id128)
+        self._chk(lib().poppy_hip_comm_init(self.h, rank, world, buf), "comm_init")
+
+    def comm_free(self):
+        lib().poppy_hip_comm_free(self.h)
+
+    def pair_broadcast(self, root, w, h):
+        self._chk(lib().poppy_hip_pair_broadcast(self.h, root, w, h), "pair_broadcast")
+        self.w, self.h_ = w, h
+
+    def comm_max(self, value):
+        d = C.c_double(value)
+        self._chk(lib().poppy_hip_comm_max(self.h, C.byref(d)), "comm_max")
+        return d.value
+
+    def pair_export_device(self, d_dst, nbytes):
+        self._chk(lib().poppy_hip_pair_export_device(self.h, d_dst, nbytes), "pair_export_device")
+
+    def pair_import_device(self, d_src, nbytes, w, h):
+        self._chk(lib().poppy_hip_pair_import_device(self.h, d_src, nbytes, w, h), "pair_import_device")
+        self.w, self.h_ = w, h
+
+    def pair_begin_device(self, d1, d2, w, h):
+        """Raw BGR pair already in this GPU's memory (device pointers, tight rows)."""
+        self._chk(lib().poppy_hip_pair_begin_device(self.h, d1, d2, w, h), "pair_begin_device")
+        self.w, self.h_ = w, h
+
+    def morph_frames_counted(self, phase=-1.0):
+        """The frame loop with every frame handed to the library's counting writer (pinned host hand-off, no Python per frame)."""
+        n = C.c_longlong(0)
+        cb = C.cast(lib().poppy_count_frames_cb, C.c_void_p)
+        self._chk(lib().poppy_hip_morph_frames(self.h, phase, cb, C.cast(C.byref(n), C.c_void_p)), "morph_frames")
+        return n.value
+
+    def render_many_counted(self, shapes, chain=False):
+        sh = np.ascontiguousarray(shapes, np.float64)
+        n = C.c_longlong(0)
+        cb = C.cast(lib().poppy_count_frames_cb, C.c_void_p)
+        self._chk(lib().poppy_hip_render_many(self.h, _p(sh), _p(sh), len(sh), int(chain), cb, C.cast(C.byref(n), C.c_void_p)), "render_many")
+        return n.value
 
     def orb_input(self, good_features):
         gf = np.ascontiguousarray(good_features, np.uint8)
@@ -446,6 +582,9 @@ class Context:
         self._chk(lib().poppy_hip_dissolve(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, _p(out), w * 3), "dissolve")
         return out
 
+    def warp_kernel_name(self):
+        return {1: "k_warp_tile", 0: "k_warp4"}.get(self.last_warp_kind(), "k_warp")
+
     def last_warp_kind(self):
         return int(lib().poppy_hip_last_warp_kind(self.h))
 
@@ -458,7 +597,7 @@ class Context:
 
     def fetch(self, name):
         h, w = self.h_, self.w
-        shapes = {"triMap": ((h, w), np.int32), "trImg1": ((h, w, 3), np.uint8), "trImg2": ((h, w, 3), np.uint8),
+        shapes = {"gabor2": ((h, w, 3), np.float32), "triMap": ((h, w), np.int32), "trImg1": ((h, w, 3), np.uint8), "trImg2": ((h, w, 3), np.uint8),
                   "lbmask": ((h, w), np.float32), "m2": ((h, w), np.float32), "lapBlend": ((h, w, 3), np.float32),
                   "unsharp": ((h, w, 3), np.float32)}
         shp, dt = shapes[name]

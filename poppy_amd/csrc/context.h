@@ -52,6 +52,9 @@ struct poppy_hip_ctx {
     int W = 0, H = 0;
     bool pair_ready = false;
     // resident buffers
+    // c1, c2 and m2 live in ONE allocation behind a small header + point area (PairStateHeader): the "pair state" that a
+    // frame needs.  Being contiguous, it travels to other GPUs as a single ncclBroadcast / a single device copy (comm.cpp).
+    uint8_t* arena = nullptr; size_t arena_bytes = 0;
     uint8_t *c1 = nullptr, *c2 = nullptr;
     uint8_t* c2_raw = nullptr;           // image 2 before auto-align (only allocated when auto-align ran): what phase == 1 writes
     bool c2_raw_valid = false;           // ... and whether it belongs to the resident pair
@@ -88,6 +91,7 @@ struct poppy_hip_ctx {
     AutoAligner aligner;
     uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
     double last_detail[2] = {0, 0};
@@ -102,6 +106,24 @@ struct poppy_hip_ctx {
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_done[kStageRing] = {};
 };
+
+// ---- packed pair state (see poppy_hip_ctx::arena) -------------------------------------------------------------------------
+constexpr size_t kPairHeadBytes = 4096;
+constexpr int kPairMaxPoints = 16384;              // point pairs the packed state has room for
+struct PairStateHeader {
+    uint32_t magic, version;
+    int32_t W, H, n_points, nfeatures;
+    double initial_morph_dist, detail[2];
+};
+static_assert(sizeof(PairStateHeader) <= kPairHeadBytes, "header area too small");
+constexpr uint32_t kPairMagic = 0x50505931u;        // "PPY1"
+inline size_t pair_align(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t pair_state_bytes(int W, int H) {
+    const size_t P = (size_t)W * H;
+    return kPairHeadBytes + 2 * (size_t)kPairMaxPoints * 8 + 2 * pair_align(P * 3 + 16) + pair_align(P * 4);
+}
+int stage_pair_state(poppy_hip_ctx* c);            // header + points -> arena head (queued on c->stream)
+int adopt_pair_state(poppy_hip_ctx* c);            // arena head -> points, chain state; the pair becomes ready
 
 #define HIPCHK(ctx, call)                                                                             \
     do {                                                                                              \

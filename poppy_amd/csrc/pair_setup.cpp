@@ -168,16 +168,22 @@ int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, in
 }
 
 // Pair set-up from the raw images: the pre-ORB filter chain on the GPU, then the same steps as pair_begin_prefiltered.
-static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
+static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio,
+                           bool on_device = false) {
     if (!c) return POPPY_E_ARG;
     if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = alloc_pair(c, W, H); if (rc) return rc;
     c->pair_ready = false;
     c->c2_raw_valid = false;
-    rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
-    rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
     const size_t P = (size_t)W * H;
+    if (on_device) {
+        HIPCHK(c, hipMemcpyAsync(c->c1, bgr1, P * 3, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->c2, bgr2, P * 3, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
+        rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
+    }
     std::vector<uint8_t> g[2] = {std::vector<uint8_t>(P), std::vector<uint8_t>(P)};
     double d[2] = {0, 0};
     if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
@@ -294,6 +300,10 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
 int poppy_hip_pair_begin(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H) {
     return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, -1.f);
 }
+int poppy_hip_pair_begin_device(poppy_hip_ctx* c, const void* d1, const void* d2, int W, int H) {
+    return pair_begin_impl(c, (const uint8_t*)d1, (size_t)W * 3, (const uint8_t*)d2, (size_t)W * 3, W, H, -1.f, true);
+}
+void poppy_count_frames_cb(void* user, const uint8_t*, int, int, size_t) { if (user) ++*(long long*)user; }
 int poppy_hip_pair_begin_descriptors(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio) {
     if (!(ratio >= 0.f)) return c ? fail(c, POPPY_E_ARG, "ratio must be >= 0") : POPPY_E_ARG;
     return pair_begin_impl(c, bgr1, s1, bgr2, s2, W, H, ratio);

@@ -64,8 +64,9 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
 }
 
 static void free_pair(poppy_hip_ctx* c) {
-    void* bufs[] = {c->c1, c->c2, c->c2_raw, c->gabor2, c->m2, c->d_levels};
+    void* bufs[] = {c->arena, c->c2_raw, c->gabor2, c->d_levels};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    c->arena = nullptr; c->arena_bytes = 0;
     c->c1 = c->c2 = c->c2_raw = nullptr; c->gabor2 = c->m2 = nullptr; c->d_levels = nullptr;
     for (FrameSlot& f : c->slots) {
         void* fb[] = {f.tr1, f.tr2, f.out, f.pyrL, f.pyrR, f.pyrM, f.pyrB, f.tmp, f.diff, f.unsharpF, f.triMap};
@@ -85,6 +86,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)poppy_hip_comm_free(c);
     for (FrameSlot& f : c->slots) if (f.stream) (void)hipStreamSynchronize(f.stream);
     free_pair(c);
     for (FrameSlot& f : c->slots) {
@@ -179,8 +181,12 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         c->first_tail = L;
     }
     // +16: k_warp4 fetches footprints with 8-byte loads (6 bytes used), the last one may run 2 bytes past the image
-    HIPCHK(c, hipMalloc((void**)&c->c1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&c->c2, P * 3 + 16));
-    HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12)); HIPCHK(c, hipMalloc((void**)&c->m2, P * 4));
+    c->arena_bytes = pair_state_bytes(W, H);
+    HIPCHK(c, hipMalloc((void**)&c->arena, c->arena_bytes));
+    c->c1 = c->arena + kPairHeadBytes + 2 * (size_t)kPairMaxPoints * 8;
+    c->c2 = c->c1 + pair_align(P * 3 + 16);
+    c->m2 = (float*)(c->c2 + pair_align(P * 3 + 16));
+    HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12));
     for (FrameSlot& f : c->slots) {
         HIPCHK(c, hipMalloc((void**)&f.tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.out, P * 3 + 16));
@@ -207,6 +213,42 @@ int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n) {
 int finish_pair_load(poppy_hip_ctx* c) {
     launch_gray_inv(c->gabor2, c->m2, c->W * c->H, c->stream);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
+    c->cur1 = c->c1; c->cur1_ready = nullptr; c->last_slot = -1; c->pair_ready = true;
+    return POPPY_OK;
+}
+
+int stage_pair_state(poppy_hip_ctx* c) {
+    const int n = (int)c->pts1_0.size();
+    if (n > kPairMaxPoints) return fail(c, POPPY_E_UNSUPPORTED, "more point pairs than the packed pair state has room for");
+    std::vector<uint8_t> head(kPairHeadBytes + 2 * (size_t)kPairMaxPoints * 8, 0);
+    PairStateHeader h{};
+    h.magic = kPairMagic; h.version = 1; h.W = c->W; h.H = c->H; h.n_points = n; h.nfeatures = c->last_nfeatures;
+    h.initial_morph_dist = c->initial_morph_dist; h.detail[0] = c->last_detail[0]; h.detail[1] = c->last_detail[1];
+    memcpy(head.data(), &h, sizeof h);
+    if (n) {
+        memcpy(head.data() + kPairHeadBytes, c->pts1_0.data(), (size_t)n * 8);
+        memcpy(head.data() + kPairHeadBytes + (size_t)kPairMaxPoints * 8, c->pts2.data(), (size_t)n * 8);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->arena, head.data(), head.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // `head` goes out of scope
+    return POPPY_OK;
+}
+
+int adopt_pair_state(poppy_hip_ctx* c) {
+    std::vector<uint8_t> head(kPairHeadBytes + 2 * (size_t)kPairMaxPoints * 8);
+    HIPCHK(c, hipMemcpyAsync(head.data(), c->arena, head.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    PairStateHeader h;
+    memcpy(&h, head.data(), sizeof h);
+    if (h.magic != kPairMagic || h.version != 1) return fail(c, POPPY_E_ARG, "not a packed pair state");
+    if (h.W != c->W || h.H != c->H) return fail(c, POPPY_E_ARG, "packed pair state has another geometry");
+    if (h.n_points < 0 || h.n_points > kPairMaxPoints) return fail(c, POPPY_E_ARG, "packed pair state is corrupt");
+    c->last_nfeatures = h.nfeatures; c->initial_morph_dist = h.initial_morph_dist;
+    c->last_detail[0] = h.detail[0]; c->last_detail[1] = h.detail[1];
+    int rc = set_points(c, (const float*)(head.data() + kPairHeadBytes), (const float*)(head.data() + kPairHeadBytes + (size_t)kPairMaxPoints * 8), h.n_points);
+    if (rc) return rc;
+    c->c2_raw_valid = false;
     HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
     c->cur1 = c->c1; c->cur1_ready = nullptr; c->last_slot = -1; c->pair_ready = true;
     return POPPY_OK;
@@ -705,7 +747,7 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     const size_t P = (size_t)c->W * c->H;
     const void* src = nullptr; size_t need = 0;
     std::string n(name);
-    if (n != "m2" && c->last_slot < 0) return fail(c, POPPY_E_STATE, "no frame rendered yet");
+    if (n != "m2" && n != "gabor2" && c->last_slot < 0) return fail(c, POPPY_E_STATE, "no frame rendered yet");
     const FrameSlot& f = c->slots[c->last_slot < 0 ? 0 : c->last_slot];          // intermediates of the last frame
     if (n == "triMap") { src = f.triMap; need = P * 4; }
     else if (n == "trImg1") { src = f.tr1; need = P * 3; }
@@ -717,6 +759,7 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
         src = f.unsharpF; need = P * 12;
     }
     else if (n == "m2") { src = c->m2; need = P * 4; }
+    else if (n == "gabor2") { src = c->gabor2; need = P * 12; }
     else return fail(c, POPPY_E_ARG, "unknown debug buffer");
     if (bytes != need) return fail(c, POPPY_E_ARG, "debug buffer size mismatch");
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -43,6 +43,76 @@ def broadcast_pair(dist, tensors, src=0):
     return tensors
 
 
+class PairLink:
+    """Moves the resident pair of rank `root` into every rank's context, once per step.
+
+    Preferred transport: the library's own RCCL communicator (poppy_hip_comm_init + poppy_hip_pair_broadcast: ONE ncclBroadcast of
+    the packed pair state straight out of the context's arena).  The 128-byte unique id is the only thing that goes through
+    torch.distributed.  If that communicator cannot be created (or the job runs on the gloo rehearsal path), the same packed
+    state is exported into a torch tensor, broadcast by torch.distributed and imported — still one broadcast, one more copy."""
+
+    def __init__(self, torch, dist, capi, ctx, rank, world, w, h, device, use_library=True):
+        self.torch, self.dist, self.capi, self.ctx, self.rank, self.world, self.w, self.h, self.device = torch, dist, capi, ctx, rank, world, w, h, device
+        self.nbytes = capi.pair_state_bytes(w, h)
+        self.library = False
+        self._buf = None
+        ok = 1
+        if use_library and device.type == "cuda":
+            ident = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                try:
+                    ident = torch.frombuffer(bytearray(capi.comm_id()), dtype=torch.uint8).to(device)
+                except Exception:
+                    ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.broadcast(flag, src=0)
+            if int(flag.item()):
+                dist.broadcast(ident, src=0)
+                try:
+                    ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+                except Exception:
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                self.library = bool(int(flag.item()))
+                if not self.library:
+                    ctx.comm_free()
+        self.how = ("ncclBroadcast of the packed pair state through the library's own RCCL communicator" if self.library
+                    else "torch.distributed broadcast of the packed pair state (export / import through a device buffer)")
+
+    def broadcast(self, root=0):
+        if self.library:
+            self.ctx.pair_broadcast(root, self.w, self.h)
+            return
+        torch = self.torch
+        if self._buf is None:
+            self._buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        if self.device.type == "cuda":
+            if self.rank == root:
+                self.ctx.pair_export_device(self._buf.data_ptr(), self.nbytes)
+            self.dist.broadcast(self._buf, src=root)
+            torch.cuda.synchronize()
+            if self.rank != root:
+                self.ctx.pair_import_device(self._buf.data_ptr(), self.nbytes, self.w, self.h)
+        else:                                   # gloo rehearsal: staged through the host
+            stage = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda") if not hasattr(self, "_stage") else self._stage
+            self._stage = stage
+            if self.rank == root:
+                self.ctx.pair_export_device(stage.data_ptr(), self.nbytes)
+                self._buf.copy_(stage.cpu())
+            self.dist.broadcast(self._buf, src=root)
+            if self.rank != root:
+                stage.copy_(self._buf)
+                torch.cuda.synchronize()
+                self.ctx.pair_import_device(stage.data_ptr(), self.nbytes, self.w, self.h)
+
+    def max_time(self, seconds):
+        """Slowest rank's step time."""
+        if self.library:
+            return self.ctx.comm_max(seconds)
+        return max_over_ranks(self.torch, self.dist, seconds, self.device)
+
+
 def max_over_ranks(torch, dist, seconds, device):
     """Step time of the job = the slowest rank's."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)

@@ -178,3 +178,58 @@ def test_download_ring_with_two_slots(monkeypatch):
     got_a, got_b = run()
     assert all(np.array_equal(x, y) for x, y in zip(ref_a, got_a)) and len(got_a) == 6
     assert all(np.array_equal(x, y) for x, y in zip(ref_b, got_b)) and len(got_b) == 9
+
+
+# ---- multi-GPU entry points, as far as one GPU can exercise them ----------------------------------------------------------
+def test_pair_state_export_import_and_single_rank_broadcast():
+    """The packed pair state (what travels between GPUs) moved into a second context renders the same frames; a one-rank RCCL
+    communicator created through the library broadcasts it in place."""
+    import torch
+    from poppy_amd import capi
+    case = "a_256x256_phase"
+    inp = G.astage_inputs(case)
+    h, w = inp["img1"].shape[:2]
+    a = _ctx(number_of_frames=1)
+    a.pair_begin(inp["img1"], inp["img2"])
+    n = capi.pair_state_bytes(w, h)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    a.pair_export_device(buf.data_ptr(), n)
+    b = _ctx(number_of_frames=1)
+    b.pair_import_device(buf.data_ptr(), n, w, h)
+    pa, pb = a.pair_points(), b.pair_points()
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+    fb = b.morph_frames(0.5)
+    G.check(case, "frame0", fb[0])
+    # one-rank communicator: init, broadcast (root = the only rank), max
+    a.comm_init(0, 1, capi.comm_id())
+    a.pair_broadcast(0, w, h)
+    assert a.comm_max(3.25) == 3.25
+    G.check(case, "frame0", a.morph_frames(0.5)[0])
+    a.comm_free()
+    a.close(); b.close()
+
+
+def test_morph_sharded_one_device_equals_phase_frames():
+    """poppy_hip_morph_sharded on one device: frame j = morph(.., phase = j / total) with number_of_frames = 1; frame 0 = image 1."""
+    from poppy_amd import capi
+    case = "a_1920x1080_chain60"
+    inp = G.astage_inputs(case)
+    frames = capi.morph_sharded([0], inp["img1"], inp["img2"], 4)
+    assert len(frames) == 4
+    assert np.array_equal(frames[0], inp["img1"])
+    G.check(case, "phase0_frame", frames[1])          # t = 1/4
+    G.check(case, "phase1_frame", frames[2])          # t = 2/4
+
+
+def test_morph_pairs_one_device():
+    """poppy_hip_morph_pairs: three pairs over two contexts of one GPU; each pair's frames equal the single-context run."""
+    from poppy_amd import capi
+    cases = ["a_256x256_chain", "a_256x256_chain", "a_256x256_chain"]
+    inp = G.astage_inputs(cases[0])
+    n = int(inp["cfg"][0])
+    out = capi.morph_pairs([0], [(inp["img1"], inp["img2"])] * 3, contexts_per_device=2, number_of_frames=n)
+    assert sorted(out) == [0, 1, 2]
+    for p in out:
+        assert len(out[p]) == n
+        for j, f in enumerate(out[p]):
+            G.check(cases[p], f"frame{j}", f)
