@@ -27,6 +27,10 @@ One JSON line on rank 0 (driver contract) with
   parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected);
   cfg3_4k       configs[2]: one 3840x2160 pair, 120 phase-mode frames, set-up and writer hand-off included, with its own roofline.
 """
+import os
+# hardware queues the HIP runtime spreads its streams over (read when the runtime initialises, i.e. before torch touches the GPU):
+# with the default of 4 a context's download stream can share a queue with its rendering stream (poppy_hip.cpp, DESIGN.md)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import ctypes
 import json
@@ -70,6 +74,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
             "algo_bytes_per_launch": int(contract), "algo_bytes_note": "16 B/px x pixels (SURVEY.md 8d faithful path)",
             "achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
+            "frames_by_kernel": dict(zip(("k_warp_tile", "k_warp4"), ctx.warp_counts())),
             "traffic": None, "traffic_note": "PMC passes cannot run inside the bench; see profiles/ for the counter passes of this command"}
 
 
@@ -149,6 +154,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts (host threads) the step's pairs are spread over at N = 1")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
     if args.width and args.height:
@@ -199,28 +205,30 @@ def bench_single(args, torch, capi, dev, local):
     pairs_dev = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in pairs_host]
     torch.cuda.synchronize()
     ctx = capi.Context(local, number_of_frames=FRAMES)
+    # The step's pairs are independent (the CLI's pairs loop, src/poppy.cpp:266-328, has no cross-pair state): the library's pool
+    # renders them on CONTEXTS contexts of this GPU, one host thread each, so that one pair's set-up runs beside another's frames.
+    pool = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
+    ptrs = [(ta.data_ptr(), tb.data_ptr()) for ta, tb in pairs_dev]
 
     def step():
-        n = 0
-        for ta, tb in pairs_dev:
-            ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
-            n += ctx.morph_frames_counted(-1.0)
-        return n
+        return pool.morph_pairs_device_counted(ptrs, W, H, -1.0)
 
     for _ in range(args.warmup):
         step()
-    ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch, one launch in seven, on the stream it is launched on
-    ctx.sync(); torch.cuda.synchronize()
+    pool.set_timing(2)         # HIP events on the roofline kernel's own dispatch, one launch in seven, on the stream it is launched on
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     written = 0
     for _ in range(args.steps):
-        written += step()
-    ctx.sync(); torch.cuda.synchronize()
+        written += step()      # returns after every frame of the batch was handed to the writer
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    warp_ms, warp_n = next(((ms, c) for nm, ms, c in ctx.timing_summary() if nm == "warp"), (0.0, 0))
-    ctx.set_timing(0)
+    warp_ms, warp_n = next(((ms, c) for nm, ms, c in pool.timing_summary() if nm == "warp"), (0.0, 0))
+    pool.set_timing(0)
     assert written == args.steps * PAIRS * FRAMES, (written, args.steps * PAIRS * FRAMES)
     fps = written / dt
+    roof = roofline_of(pool, warp_ms, warp_n, W, H)
+    pool.close()
 
     out = {
         "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H, FRAMES) == (1920, 1080, 60) else f"morph frames/sec at {W}x{H}, {FRAMES}-frame sequence; Mpix/s warped",
@@ -233,9 +241,9 @@ def bench_single(args, torch, capi, dev, local):
         "data": "synthetic (integer-defined shapes pairs, seeds 1234+k: poppy_amd/synth.py); point sets and mask field come from the real pair set-up",
         "config": {"workload": f"{W}x{H} pairs, {FRAMES}-frame morph each, default chained mode (BASELINE.json configs[1]): per step {PAIRS} pairs x "
                                "(pair set-up from the raw images + 60 chained frames handed to a writer through pinned host memory), pyramid_levels 64",
-                   "pairs_per_step": PAIRS, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
+                   "pairs_per_step": PAIRS, "contexts": args.contexts, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
                    "parallelism": "1 GPU"},
-        "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
+        "roofline": roof,
     }
     if args.headline_only:
         ctx.close()
@@ -249,6 +257,20 @@ def bench_single(args, torch, capi, dev, local):
     out["config"]["point_pairs_pair0"] = int(len(p1))
     shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
     reps = max(args.steps, 10)
+    # the same step on ONE context, pair after pair (the reference's own order)
+    def seq_step():
+        n = 0
+        for ta_, tb_ in pairs_dev:
+            ctx.pair_begin_device(ta_.data_ptr(), tb_.data_ptr(), W, H)
+            n += ctx.morph_frames_counted(-1.0)
+        return n
+    seq_step()
+    t1 = time.perf_counter()
+    k = 0
+    for _ in range(max(3, args.steps // 4)):
+        k += seq_step()
+    out["sequential_fps"] = round(k / (time.perf_counter() - t1), 1)
+    ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
     # per-frame operator on the resident pair, frames left in HBM (round 1's `value`)
     ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
     t1 = time.perf_counter()

@@ -278,12 +278,27 @@ int poppy_hip_pair_import_device(poppy_hip_ctx* ctx, const void* d_src, size_t b
  *                  share.  `write` is called concurrently from n_devices threads, each with ascending frame indices.
  *   morph_pairs    n_pairs independent pairs, each one whole poppy_hip_morph(.., phase, ..) (default chained mode for phase < 0),
  *                  taken off a shared counter by contexts_per_device host threads per GPU (2-3 fill a GPU: a chained sequence is
- *                  a latency chain).  `source` hands out pair p's two images (pointers must stay valid until the pair's last
- *                  frame was written; return 0); `write` gets (pair, frame) and is called concurrently.  No communication.
+ *                  a latency chain, and one pair's set-up runs beside another pair's frames).  `source` hands out pair p's two
+ *                  images for the device that will render it (pointers must stay valid until the pair's last frame was written;
+ *                  return 0); `write` gets (pair, frame) and is called concurrently.  No communication.
+ *   pool_*         the same with contexts (and their HBM) kept between batches; inputs_on_device != 0: `source` returns device
+ *                  pointers (tight rows) in the memory of the device it is asked for.
  * err (may be NULL) receives the message of the first failure.                                                              */
+typedef struct poppy_hip_pool poppy_hip_pool;
 typedef void (*poppy_write_indexed_cb)(void* user, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
-typedef int (*poppy_pair_source_cb)(void* user, int pair_index, const uint8_t** bgr1, size_t* stride1, const uint8_t** bgr2, size_t* stride2);
+typedef int (*poppy_pair_source_cb)(void* user, int pair_index, int device, const uint8_t** bgr1, size_t* stride1, const uint8_t** bgr2, size_t* stride2);
 typedef void (*poppy_write_pair_cb)(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
+poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
+                                      char* err, size_t err_len);
+void poppy_hip_pool_destroy(poppy_hip_pool* pool);
+int poppy_hip_pool_morph_pairs(poppy_hip_pool* pool, int n_pairs, int width, int height, double phase, int inputs_on_device,
+                               poppy_pair_source_cb source, poppy_write_pair_cb write, void* user, char* err, size_t err_len);
+/* poppy_hip_set_timing / poppy_hip_timing_summary / poppy_hip_warp_counts over all contexts of a pool */
+int poppy_hip_pool_set_timing(poppy_hip_pool* pool, int on);
+int poppy_hip_pool_timing_summary(poppy_hip_pool* pool, const char** names, float* total_ms, int* launches, int max);
+int poppy_hip_pool_warp_counts(poppy_hip_pool* pool, unsigned long long* tiled, unsigned long long* general);
+/* a poppy_write_pair_cb that only counts, atomically: ++*(long long*)user */
+void poppy_count_pair_frames_cb(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_settings* settings,
                             const uint8_t* bgr1, size_t stride1, const uint8_t* bgr2, size_t stride2, int width, int height,
                             int total_frames, poppy_write_indexed_cb write, void* user, char* err, size_t err_len);
@@ -305,6 +320,8 @@ int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
  * host checks, the normal case), 0 = the general kernel (degenerate matrices or odd geometry).  Same output bits either
  * way; exported so that the parity tests can tell which one they exercised.                              */
 int poppy_hip_last_warp_kind(poppy_hip_ctx* ctx);
+/* frames rendered by each of the two since the context was created */
+int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* tiled, unsigned long long* general);
 int poppy_hip_debug_fetch(poppy_hip_ctx* ctx, const char* name, void* host_dst, size_t bytes);
 int poppy_hip_debug_triangles(poppy_hip_ctx* ctx, int* n_tris, int* idx3, float* M1, float* M2, int max_tris);
 

@@ -30,7 +30,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -98,6 +98,14 @@ def lib():
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_points.argtypes = [vp, vp, vp, i, vp]
         L.poppy_dft_plan.argtypes = [i, vp, vp, vp, vp]
+        L.poppy_hip_warp_counts.argtypes = [vp, vp, vp]
+        L.poppy_hip_pool_create.restype = C.c_void_p
+        L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
+        L.poppy_hip_pool_destroy.argtypes = [vp]
+        L.poppy_hip_pool_set_timing.argtypes = [vp, i]
+        L.poppy_hip_pool_timing_summary.argtypes = [vp, vp, vp, vp, i]
+        L.poppy_hip_pool_warp_counts.argtypes = [vp, vp, vp]
+        L.poppy_hip_pool_morph_pairs.argtypes = [vp, i, i, i, d, i, vp, vp, vp, vp, sz]
         L.poppy_hip_comm_id.argtypes = [vp]
         L.poppy_hip_comm_init.argtypes = [vp, i, i, vp]
         L.poppy_hip_comm_free.argtypes = [vp]
@@ -196,7 +204,7 @@ def radial_gradient(w, h):
 
 
 WRITE_INDEXED_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
-PAIR_SOURCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+PAIR_SOURCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 WRITE_PAIR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
 
 
@@ -253,7 +261,7 @@ def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True,
     import threading
     lock = threading.Lock()
 
-    def src(user, p, pa, sa, pb, sb):
+    def src(user, p, device, pa, sa, pb, sb):
         pa[0] = pairs[p][0].ctypes.data; sa[0] = w * 3
         pb[0] = pairs[p][1].ctypes.data; sb[0] = w * 3
         return 0
@@ -274,6 +282,58 @@ def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True,
     if rc:
         raise PoppyError(f"poppy_hip_morph_pairs: {rc}: {err.value.decode()}")
     return {p: [v[j] for j in sorted(v)] for p, v in out.items()} if collect else count[0]
+
+
+class Pool:
+    """Persistent contexts for batches of independent pairs (poppy_hip_pool_*)."""
+
+    def __init__(self, devices, contexts_per_device=2, **settings):
+        s = PoppySettings(); lib().poppy_settings_default(C.byref(s))
+        for k, v in settings.items():
+            setattr(s, k, v)
+        dv = (C.c_int * len(devices))(*devices)
+        err = C.create_string_buffer(512)
+        self.h = lib().poppy_hip_pool_create(dv, len(devices), contexts_per_device, C.byref(s), err, 512)
+        if not self.h:
+            raise PoppyError("poppy_hip_pool_create: " + err.value.decode())
+
+    def close(self):
+        if self.h:
+            lib().poppy_hip_pool_destroy(self.h)
+            self.h = None
+
+    def set_timing(self, on):
+        lib().poppy_hip_pool_set_timing(self.h, int(on))
+
+    def timing_summary(self):
+        names = (C.c_char_p * 32)(); ms = (C.c_float * 32)(); cnt = (C.c_int * 32)()
+        n = lib().poppy_hip_pool_timing_summary(self.h, names, ms, cnt, 32)
+        return [(names[k].decode(), ms[k], cnt[k]) for k in range(n)]
+
+    def warp_counts(self):
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        lib().poppy_hip_pool_warp_counts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def warp_kernel_name(self):
+        t, g = self.warp_counts()
+        return "k_warp_tile" if t >= g else "k_warp4"
+
+    def morph_pairs_device_counted(self, ptr_pairs, w, h, phase=-1.0):
+        """ptr_pairs: list of (device pointer of image 1, of image 2) on the pool's (single) device; frames go to the counting
+        writer.  Returns the number of frames written."""
+        def src(user, p, device, pa, sa, pb, sb):
+            pa[0] = ptr_pairs[p][0]; sa[0] = w * 3
+            pb[0] = ptr_pairs[p][1]; sb[0] = w * 3
+            return 0
+        fs = PAIR_SOURCE_CB(src)
+        n = C.c_longlong(0)
+        err = C.create_string_buffer(512)
+        rc = lib().poppy_hip_pool_morph_pairs(self.h, len(ptr_pairs), w, h, phase, 1, C.cast(fs, C.c_void_p),
+                                              C.cast(lib().poppy_count_pair_frames_cb, C.c_void_p), C.cast(C.byref(n), C.c_void_p), err, 512)
+        if rc:
+            raise PoppyError(f"poppy_hip_pool_morph_pairs: {rc}: {err.value.decode()}")
+        return n.value
 
 
 def dft_plan(n):
@@ -582,8 +642,14 @@ class Context:
         self._chk(lib().poppy_hip_dissolve(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, _p(out), w * 3), "dissolve")
         return out
 
+    def warp_counts(self):
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        lib().poppy_hip_warp_counts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def warp_kernel_name(self):
-        return {1: "k_warp_tile", 0: "k_warp4"}.get(self.last_warp_kind(), "k_warp")
+        t, g = self.warp_counts()
+        return "k_warp_tile" if t >= g else "k_warp4"
 
     def last_warp_kind(self):
         return int(lib().poppy_hip_last_warp_kind(self.h))

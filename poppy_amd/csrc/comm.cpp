@@ -238,56 +238,119 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
     return rc;
 }
 
-// The pairs loop of the reference's CLI (src/poppy.cpp:266-328) over several GPUs: n_pairs independent pairs, each one whole
+// The pairs loop of the reference's CLI (src/poppy.cpp:266-328) over several GPUs: independent pairs, each one whole
 // poppy::morph (default chained mode unless phase says otherwise), handed out one at a time to contexts_per_device host threads
-// per GPU — a chained sequence is a latency chain that leaves most of a GPU idle, independent pairs fill it.
-int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings, int n_pairs,
-                          int W, int H, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
-                          char* err, size_t err_len) {
-    if (!devices || n_devices < 1 || contexts_per_device < 1 || contexts_per_device > 16 || n_pairs < 0 || !source || W <= 0 || H <= 0) {
-        set_err(err, err_len, "bad arguments");
-        return POPPY_E_ARG;
-    }
-    const int n_workers = n_devices * contexts_per_device;
+// per GPU — a chained sequence is a latency chain that leaves most of a GPU idle, and the pair set-up of one pair runs beside the
+// frames of another.  The pool keeps its contexts (and their HBM) between batches.
+struct poppy_hip_pool {
+    std::vector<poppy_hip_ctx*> ctx;
+    std::vector<int> device_of;
+};
+
+poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
+                                      char* err, size_t err_len) {
+    if (!devices || n_devices < 1 || n_devices > 64 || contexts_per_device < 1 || contexts_per_device > 16) { set_err(err, err_len, "bad arguments"); return nullptr; }
+    poppy_hip_pool* p = new poppy_hip_pool();
+    for (int d = 0; d < n_devices; ++d)
+        for (int k = 0; k < contexts_per_device; ++k) {
+            poppy_hip_ctx* c = poppy_hip_create(devices[d], settings);
+            if (!c) { set_err(err, err_len, std::string("poppy_hip_create: ") + poppy_hip_create_error()); poppy_hip_pool_destroy(p); return nullptr; }
+            p->ctx.push_back(c); p->device_of.push_back(devices[d]);
+        }
+    return p;
+}
+
+void poppy_hip_pool_destroy(poppy_hip_pool* p) {
+    if (!p) return;
+    for (poppy_hip_ctx* c : p->ctx) poppy_hip_destroy(c);
+    delete p;
+}
+
+int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, double phase, int inputs_on_device,
+                               poppy_pair_source_cb source, poppy_write_pair_cb write, void* user, char* err, size_t err_len) {
+    if (!p || n_pairs < 0 || !source || W <= 0 || H <= 0) { set_err(err, err_len, "bad arguments"); return POPPY_E_ARG; }
     std::atomic<int> next{0}, failed{POPPY_OK};
     std::mutex mu;
     std::string first_err;
     struct Relay { poppy_write_pair_cb write; void* user; int pair; int frame; };
     auto work = [&](int wk) {
-        poppy_hip_ctx* c = poppy_hip_create(devices[wk / contexts_per_device], settings);
-        if (!c) {
-            std::lock_guard<std::mutex> g(mu);
-            if (first_err.empty()) first_err = std::string("poppy_hip_create: ") + poppy_hip_create_error();
-            failed = POPPY_E_DEVICE;
-            return;
-        }
+        poppy_hip_ctx* c = p->ctx[wk];
         for (;;) {
-            const int p = next.fetch_add(1);
-            if (p >= n_pairs || failed.load() != POPPY_OK) break;
+            const int pi = next.fetch_add(1);
+            if (pi >= n_pairs || failed.load() != POPPY_OK) break;
             const uint8_t *a = nullptr, *b = nullptr; size_t sa = 0, sb = 0;
-            int rc = source(user, p, &a, &sa, &b, &sb) == 0 ? POPPY_OK : POPPY_E_ARG;
+            int rc = source(user, pi, p->device_of[wk], &a, &sa, &b, &sb) == 0 ? POPPY_OK : POPPY_E_ARG;
             if (rc != POPPY_OK) c->err = "the pair source failed";
-            Relay relay{write, user, p, 0};
+            Relay relay{write, user, pi, 0};
             poppy_write_cb cb = write ? +[](void* u, const uint8_t* bgr, int w, int h, size_t stride) {
                 Relay* r = (Relay*)u;
                 r->write(r->user, r->pair, r->frame++, bgr, w, h, stride);
             } : (poppy_write_cb) nullptr;
-            if (rc == POPPY_OK) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
+            if (rc == POPPY_OK && !inputs_on_device) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
+            else if (rc == POPPY_OK) {                              // the same call sequence on images that are already in this GPU's memory
+                rc = poppy_hip_pair_begin_device(c, a, b, W, H);
+                if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_UNSUPPORTED, "no point pairs: the fallback needs the images on the host (poppy_hip_morph)");
+                if (rc == POPPY_OK) rc = poppy_hip_morph_frames(c, phase, cb, &relay);
+            }
             if (rc != POPPY_OK && rc != POPPY_E_NOMATCH) {          // a pair without matches got its fallback frames: not an error of the batch
                 std::lock_guard<std::mutex> g(mu);
-                if (first_err.empty()) first_err = "pair " + std::to_string(p) + ": " + poppy_hip_last_error(c);
+                if (first_err.empty()) first_err = "pair " + std::to_string(pi) + ": " + poppy_hip_last_error(c);
                 failed = rc;
                 break;
             }
         }
-        poppy_hip_destroy(c);
     };
     std::vector<std::thread> th;
+    const int n_workers = std::min((int)p->ctx.size(), std::max(1, n_pairs));
     for (int k = 1; k < n_workers; ++k) th.emplace_back(work, k);
     work(0);
     for (auto& t : th) t.join();
     if (failed.load() != POPPY_OK) set_err(err, err_len, first_err);
     return failed.load();
+}
+
+int poppy_hip_pool_set_timing(poppy_hip_pool* p, int on) {
+    if (!p) return POPPY_E_ARG;
+    for (poppy_hip_ctx* c : p->ctx) poppy_hip_set_timing(c, on);
+    return POPPY_OK;
+}
+// per-kernel-group totals summed over the pool's contexts (same contract as poppy_hip_timing_summary)
+int poppy_hip_pool_timing_summary(poppy_hip_pool* p, const char** names, float* total_ms, int* launches, int max) {
+    if (!p) return 0;
+    int n = 0;
+    for (poppy_hip_ctx* c : p->ctx) {
+        const char* nm[32]; float ms[32]; int cnt[32];
+        const int k = poppy_hip_timing_summary(c, nm, ms, cnt, 32);
+        for (int i = 0; i < k; ++i) {
+            int j = 0;
+            while (j < n && strcmp(names[j], nm[i]) != 0) ++j;
+            if (j == n) { if (n >= max) continue; names[n] = nm[i]; total_ms[n] = 0.f; launches[n] = 0; ++n; }
+            total_ms[j] += ms[i]; launches[j] += cnt[i];
+        }
+    }
+    return n;
+}
+int poppy_hip_pool_warp_counts(poppy_hip_pool* p, unsigned long long* tiled, unsigned long long* general) {
+    if (!p) return POPPY_E_ARG;
+    unsigned long long a = 0, b = 0;
+    for (poppy_hip_ctx* c : p->ctx) { a += c->n_warp_fast; b += c->n_warp_general; }
+    if (tiled) *tiled = a;
+    if (general) *general = b;
+    return POPPY_OK;
+}
+
+int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings, int n_pairs,
+                          int W, int H, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
+                          char* err, size_t err_len) {
+    poppy_hip_pool* p = poppy_hip_pool_create(devices, n_devices, contexts_per_device, settings, err, err_len);
+    if (!p) return POPPY_E_DEVICE;
+    const int rc = poppy_hip_pool_morph_pairs(p, n_pairs, W, H, phase, 0, source, write, user, err, err_len);
+    poppy_hip_pool_destroy(p);
+    return rc;
+}
+
+void poppy_count_pair_frames_cb(void* user, int, int, const uint8_t*, int, int, size_t) {
+    if (user) __atomic_fetch_add((long long*)user, 1ll, __ATOMIC_RELAXED);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,7 +40,8 @@ struct FrameSlot {
     void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
-    hipEvent_t dl_pending = nullptr;                // download of this slot's `out` towards the writer still in flight (one of ctx.dl_done), or null
+    hipEvent_t downloaded = nullptr;                // completes when the last download of this slot's `out` towards the writer has read it
+    bool dl_pending = false;                        // ... and whether such a download was issued since the slot was last rendered into
 };
 constexpr size_t kBlobHeader = 64;
 
@@ -90,6 +92,7 @@ struct poppy_hip_ctx {
     int last_nfeatures = 0;
     AutoAligner aligner;
     uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
+    unsigned long long n_warp_fast = 0, n_warp_general = 0;       // frames rendered by the tiled / the general warp kernel since create
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
@@ -101,8 +104,8 @@ struct poppy_hip_ctx {
     struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
     std::vector<Mark> marks; size_t marks_used = 0;
     // staging for host-image entry points
-    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;
-    static const int kStageRing = 3;          // pinned frames in flight towards the writer
+    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr;
+    static const int kStageRing = 8;          // most pinned frames in flight towards the writer (POPPY_HIP_RING, default 3)
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_done[kStageRing] = {};
 };

@@ -21,6 +21,15 @@
 
 static std::string g_create_error;
 
+namespace {
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one run
+// in order: with the default a context's download stream can land on its rendering stream's queue, and every frame copy then
+// sits IN the chained frame loop instead of beside it (21.8 vs 12.7 ms per 60 frames at 1080p).  The variable is read when the
+// runtime initialises, so this only helps when the library is loaded before the first HIP call of the process; a host
+// application that initialises HIP earlier sets it itself.
+__attribute__((constructor)) void poppy_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+}  // namespace
+
 
 extern "C" {
 
@@ -54,7 +63,8 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     for (FrameSlot& f : c->slots) {
         // (hipEventDisableSystemFence on `done` was measured: +0.6-1 % frames/s; not used, because frame downloads to the
         // host are ordered by this event)
-        if (hipEventCreateWithFlags(&f.prepared, hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreateWithFlags(&f.downloaded, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f.prepared, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&f.uploaded, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "hipStreamCreate failed"; delete c; return nullptr;
@@ -92,12 +102,13 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     for (FrameSlot& f : c->slots) {
         if (f.done) (void)hipEventDestroy(f.done);
         if (f.prepared) (void)hipEventDestroy(f.prepared);
+        if (f.downloaded) (void)hipEventDestroy(f.downloaded);
         if (f.uploaded) (void)hipEventDestroy(f.uploaded);
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
     if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); c->dl_stream = nullptr; }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
@@ -114,6 +125,12 @@ int poppy_warp_records(const float* inv1, const float* inv2, int n_tris, int wid
     return pack_warp_records(inv1, inv2, n_tris, width, height, records) ? 1 : 0;
 }
 int poppy_hip_last_warp_kind(poppy_hip_ctx* c) { return c ? (c->last_warp_fast ? 1 : 0) : POPPY_E_ARG; }
+int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* tiled, unsigned long long* general) {
+    if (!c) return POPPY_E_ARG;
+    if (tiled) *tiled = c->n_warp_fast;
+    if (general) *general = c->n_warp_general;
+    return POPPY_OK;
+}
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -258,7 +275,8 @@ static int stage_host(poppy_hip_ctx* c, size_t bytes) {
     if (bytes <= c->h_stage_bytes) return POPPY_OK;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->h_stage = nullptr; c->h_stage_bytes = 0;
-    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->h_stage_dev, c->h_stage, 0));
     c->h_stage_bytes = bytes;
     return POPPY_OK;
 }
@@ -332,7 +350,8 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
     int rc = POPPY_OK;
     const size_t row = (size_t)W * 3, frame_bytes = row * H;
-    const int R = std::min(poppy_hip_ctx::kStageRing, (int)c->slots.size());
+    static const int ring_pref = getenv("POPPY_HIP_RING") ? std::max(1, atoi(getenv("POPPY_HIP_RING"))) : 3;
+    const int R = std::min({poppy_hip_ctx::kStageRing, ring_pref, (int)c->slots.size()});
     int written = 0;
     if (write) {
         rc = stage_host(c, frame_bytes * R);
@@ -342,37 +361,69 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
                 if (hipEventCreateWithFlags(&c->dl_done[k], hipEventDisableTiming) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipEventCreate failed");
         }
     }
+    // Frame hand-off.  The download of a frame runs on its own stream into a ring of R pinned buffers while the GPU renders the
+    // frames behind it, and the writer gets frames in order, R - 1 downloads behind.  A copy whose start depends on an event of
+    // ANOTHER stream is launched by the runtime's asynchronous-event thread when that event fires; with two contexts rendering and
+    // downloading at once those launches crawled (22 GB/s together against 52 GB/s for copies without a dependency:
+    // tools/experiments/d2h_raw.py, overlap_probe.py).  So the host waits for frame j-1 itself — frame j is already queued, the GPU
+    // never idles for it — and then issues a copy that depends on nothing.  (POPPY_HIP_DL_DEVWAIT=1: the dependent form.)
+    static const bool dev_wait = getenv("POPPY_HIP_DL_DEVWAIT") != nullptr;
+    std::vector<int> slot_of(n, -1);
+    int issued = 0;                                               // downloads queued so far (frames 0 .. issued-1)
+    auto issue_download = [&](int k) -> bool {
+        FrameSlot& f = c->slots[slot_of[k]];
+        const int r = k % R;
+        hipError_t e = dev_wait ? hipStreamWaitEvent(c->dl_stream, f.done, 0) : hipEventSynchronize(f.done);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * frame_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
+        if (e == hipSuccess) e = hipEventRecord(f.downloaded, c->dl_stream);          // the slot's own: ring events are re-recorded every R frames
+        f.dl_pending = true;
+        if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; return false; }
+        return true;
+    };
+    auto deliver = [&](int k) -> bool {
+        const int rr = k % R;
+        if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; return false; }
+        write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
+        ++written;
+        return true;
+    };
     for (int j = 0; j < n && rc == POPPY_OK; ++j) {
         while (!ready[j].load(std::memory_order_acquire)) std::this_thread::yield();
         if (rcs[j]) { rc = fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)"); break; }
         c->plan = std::move(plans[j]);
         if (chain) c->pts1 = src1[j];
+        if (write) {
+            // The slot frame j renders into may still hold a frame whose download has not been issued (few slots, or every frame
+            // landing in the one slot that does not hold corrected1): that copy goes out first; submit_frame then waits for it.
+            int ps = c->next_slot;
+            if (c->slots[ps].out == c->cur1) ps = (ps + 1) % (int)c->slots.size();
+            int last_user = -1;
+            for (int k = issued; k < j; ++k) if (slot_of[k] == ps) last_user = k;
+            while (issued <= last_user && rc == POPPY_OK) {
+                while (issued - written >= R && rc == POPPY_OK) deliver(written);
+                if (rc == POPPY_OK && issue_download(issued)) ++issued;
+            }
+            if (rc != POPPY_OK) break;
+        }
         rc = submit_frame(c, mask[j], chain);
-        if (rc == POPPY_OK && write) {
-            // Frame hand-off: the download of frame j runs on its own stream into a ring of pinned buffers while the GPU
-            // renders frame j+1; the writer gets frame j-(R-1).  R <= number of slots, so by the time a slot is rendered
-            // into again its previous frame has been handed over (the host waited for that download).
-            const int r = j % R;
-            FrameSlot& f = c->slots[c->last_slot];
-            hipError_t e = hipStreamWaitEvent(c->dl_stream, f.done, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * frame_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
-            if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
-            f.dl_pending = c->dl_done[r];
-            if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; break; }
-            if (j >= R - 1) {
-                const int jr = j - (R - 1), rr = jr % R;
-                if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; break; }
-                write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
-                ++written;
+        if (rc != POPPY_OK) break;
+        slot_of[j] = c->last_slot;
+        if (write) {
+            const int upto = dev_wait ? j + 1 : j;                // frames whose download can be issued now
+            while (issued < upto && rc == POPPY_OK) {
+                while (issued - written >= R && rc == POPPY_OK) deliver(written);
+                if (rc == POPPY_OK && issue_download(issued)) ++issued;
             }
         }
     }
-    if (write && rc == POPPY_OK)
-        for (int jr = written; jr < n; ++jr) {            // drain the ring
-            const int rr = jr % R;
-            if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; break; }
-            write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
+    if (write && rc == POPPY_OK) {
+        while (issued < n && rc == POPPY_OK) {                    // the last frame(s), then drain the ring
+            while (issued - written >= R && rc == POPPY_OK) deliver(written);
+            if (rc == POPPY_OK && issue_download(issued)) ++issued;
         }
+        while (written < n && rc == POPPY_OK) deliver(written);
+    }
     next.store(n);                         // on an error: let the workers drain
     for (auto& t : pool) t.join();
     return rc;
@@ -453,7 +504,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     FrameSlot& f = c->slots[fi];
     // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
     // `out` before that copy has read it
-    if (f.dl_pending) { HIPCHK(c, hipEventSynchronize(f.dl_pending)); f.dl_pending = nullptr; }
+    if (f.dl_pending) { HIPCHK(c, hipEventSynchronize(f.downloaded)); f.dl_pending = false; }
 
     HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
@@ -478,6 +529,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader)) &&
                            warp_fast_geometry(W, H) && !exact_warp_only;
     c->last_warp_fast = fast_warp;
+    ++(fast_warp ? c->n_warp_fast : c->n_warp_general);
     const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
     const int* d_tri = (const int*)(f.d_blob + kBlobHeader + rec_bytes);
     const float* d_inv = (const float*)(d_tri + (size_t)T * 6);

@@ -184,7 +184,7 @@ def test_download_ring_with_two_slots(monkeypatch):
 def test_pair_state_export_import_and_single_rank_broadcast():
     """The packed pair state (what travels between GPUs) moved into a second context renders the same frames; a one-rank RCCL
     communicator created through the library broadcasts it in place."""
-    import torch
+    import ctypes
     from poppy_amd import capi
     case = "a_256x256_phase"
     inp = G.astage_inputs(case)
@@ -192,10 +192,13 @@ def test_pair_state_export_import_and_single_rank_broadcast():
     a = _ctx(number_of_frames=1)
     a.pair_begin(inp["img1"], inp["img2"])
     n = capi.pair_state_bytes(w, h)
-    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
-    a.pair_export_device(buf.data_ptr(), n)
+    hip = ctypes.CDLL("libamdhip64.so")             # the HIP runtime the library already runs on (no torch in this process)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), ctypes.c_size_t(n)) == 0
+    a.pair_export_device(buf, n)
     b = _ctx(number_of_frames=1)
-    b.pair_import_device(buf.data_ptr(), n, w, h)
+    b.pair_import_device(buf, n, w, h)
+    hip.hipFree(buf)
     pa, pb = a.pair_points(), b.pair_points()
     assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
     fb = b.morph_frames(0.5)
