@@ -74,7 +74,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
             "algo_bytes_per_launch": int(contract), "algo_bytes_note": "16 B/px x pixels (SURVEY.md 8d faithful path)",
             "achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
-            "frames_by_kernel": dict(zip(("k_warp_tile", "k_warp4"), ctx.warp_counts())),
+            "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
             "traffic": None, "traffic_note": "PMC passes cannot run inside the bench; see profiles/ for the counter passes of this command"}
 
 

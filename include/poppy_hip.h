@@ -296,7 +296,7 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* pool, int n_pairs, int width, int
 /* poppy_hip_set_timing / poppy_hip_timing_summary / poppy_hip_warp_counts over all contexts of a pool */
 int poppy_hip_pool_set_timing(poppy_hip_pool* pool, int on);
 int poppy_hip_pool_timing_summary(poppy_hip_pool* pool, const char** names, float* total_ms, int* launches, int max);
-int poppy_hip_pool_warp_counts(poppy_hip_pool* pool, unsigned long long* tiled, unsigned long long* general);
+int poppy_hip_pool_warp_counts(poppy_hip_pool* pool, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general);
 /* a poppy_write_pair_cb that only counts, atomically: ++*(long long*)user */
 void poppy_count_pair_frames_cb(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_settings* settings,
@@ -316,12 +316,13 @@ int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, 
  * of the resident pair: "gabor2"(f32 HxWx3, not on ranks that received the pair by broadcast) "m2"(f32 HxW)
  * "unsharp" is only available after poppy_hip_set_debug(ctx, 1).                                       */
 int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
-/* Which warp kernel rendered the last frame: 1 = the packed-arithmetic kernel (every triangle matrix within the range the
- * host checks, the normal case), 0 = the general kernel (degenerate matrices or odd geometry).  Same output bits either
- * way; exported so that the parity tests can tell which one they exercised.                              */
+/* Which warp kernel rendered the last frame: 2 = the fused raster + map + remap kernel (k_warp_bin: triangle ids rasterised per
+ * tile in LDS, no id map; the normal case), 1 = the packed-arithmetic kernel on an id map from k_raster (k_warp_tile: debug mode,
+ * POPPY_HIP_IDMAP, or a plan whose per-tile lists outgrew the blob), 0 = the general kernel (degenerate matrices or odd
+ * geometry).  Same output bits in all three; exported so that the parity tests can tell which one they exercised.           */
 int poppy_hip_last_warp_kind(poppy_hip_ctx* ctx);
-/* frames rendered by each of the two since the context was created */
-int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* tiled, unsigned long long* general);
+/* frames rendered by each of the three since the context was created */
+int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general);
 int poppy_hip_debug_fetch(poppy_hip_ctx* ctx, const char* name, void* host_dst, size_t bytes);
 int poppy_hip_debug_triangles(poppy_hip_ctx* ctx, int* n_tris, int* idx3, float* M1, float* M2, int max_tris);
 

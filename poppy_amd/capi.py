@@ -18,6 +18,7 @@ class PoppySettings(C.Structure):
                 ("pyramid_levels", C.c_int), ("enable_radial_mask", C.c_int), ("enable_auto_align", C.c_int)]
 
 
+WARP_KERNELS = ("k_warp_bin", "k_warp_tile", "k_warp4")        # order of poppy_hip_warp_counts
 WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_size_t)
 
 # every symbol include/poppy_hip.h declares (tests check the library exports all of them)
@@ -98,13 +99,13 @@ def lib():
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_points.argtypes = [vp, vp, vp, i, vp]
         L.poppy_dft_plan.argtypes = [i, vp, vp, vp, vp]
-        L.poppy_hip_warp_counts.argtypes = [vp, vp, vp]
+        L.poppy_hip_warp_counts.argtypes = [vp, vp, vp, vp]
         L.poppy_hip_pool_create.restype = C.c_void_p
         L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
         L.poppy_hip_pool_destroy.argtypes = [vp]
         L.poppy_hip_pool_set_timing.argtypes = [vp, i]
         L.poppy_hip_pool_timing_summary.argtypes = [vp, vp, vp, vp, i]
-        L.poppy_hip_pool_warp_counts.argtypes = [vp, vp, vp]
+        L.poppy_hip_pool_warp_counts.argtypes = [vp, vp, vp, vp]
         L.poppy_hip_pool_morph_pairs.argtypes = [vp, i, i, i, d, i, vp, vp, vp, vp, sz]
         L.poppy_hip_comm_id.argtypes = [vp]
         L.poppy_hip_comm_init.argtypes = [vp, i, i, vp]
@@ -311,13 +312,13 @@ class Pool:
         return [(names[k].decode(), ms[k], cnt[k]) for k in range(n)]
 
     def warp_counts(self):
-        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
-        lib().poppy_hip_pool_warp_counts(self.h, C.byref(a), C.byref(b))
-        return a.value, b.value
+        f, a, b = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        lib().poppy_hip_pool_warp_counts(self.h, C.byref(f), C.byref(a), C.byref(b))
+        return f.value, a.value, b.value
 
     def warp_kernel_name(self):
-        t, g = self.warp_counts()
-        return "k_warp_tile" if t >= g else "k_warp4"
+        n = self.warp_counts()
+        return WARP_KERNELS[n.index(max(n))]
 
     def morph_pairs_device_counted(self, ptr_pairs, w, h, phase=-1.0):
         """ptr_pairs: list of (device pointer of image 1, of image 2) on the pool's (single) device; frames go to the counting
@@ -643,13 +644,13 @@ class Context:
         return out
 
     def warp_counts(self):
-        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
-        lib().poppy_hip_warp_counts(self.h, C.byref(a), C.byref(b))
-        return a.value, b.value
+        f, a, b = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        lib().poppy_hip_warp_counts(self.h, C.byref(f), C.byref(a), C.byref(b))
+        return f.value, a.value, b.value
 
     def warp_kernel_name(self):
-        t, g = self.warp_counts()
-        return "k_warp_tile" if t >= g else "k_warp4"
+        n = self.warp_counts()
+        return WARP_KERNELS[n.index(max(n))]
 
     def last_warp_kind(self):
         return int(lib().poppy_hip_last_warp_kind(self.h))

@@ -330,10 +330,11 @@ int poppy_hip_pool_timing_summary(poppy_hip_pool* p, const char** names, float* 
     }
     return n;
 }
-int poppy_hip_pool_warp_counts(poppy_hip_pool* p, unsigned long long* tiled, unsigned long long* general) {
+int poppy_hip_pool_warp_counts(poppy_hip_pool* p, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general) {
     if (!p) return POPPY_E_ARG;
-    unsigned long long a = 0, b = 0;
-    for (poppy_hip_ctx* c : p->ctx) { a += c->n_warp_fast; b += c->n_warp_general; }
+    unsigned long long a = 0, b = 0, f = 0;
+    for (poppy_hip_ctx* c : p->ctx) { a += c->n_warp_fast; b += c->n_warp_general; f += c->n_warp_bin; }
+    if (fused) *fused = f;
     if (tiled) *tiled = a;
     if (general) *general = b;
     return POPPY_OK;

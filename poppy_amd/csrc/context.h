@@ -28,6 +28,7 @@ constexpr int kWarpStampStride = 7;
 
 struct FrameSlot {
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream the frame last rendered here ran on (the context's for chained frames, `stream` otherwise)
     hipEvent_t done = nullptr;           // end of the frame last rendered here
     hipEvent_t prepared = nullptr;       // id map and mask of the frame being rendered here are written
     uint8_t *tr1 = nullptr, *tr2 = nullptr, *out = nullptr;
@@ -37,6 +38,7 @@ struct FrameSlot {
     int32_t* triMap = nullptr;
     int map_tag = 0;                            // frame tag of the values last written to triMap (kernels.h: launch_raster); 0 = must be zeroed first
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
+    uint8_t* tile_data = nullptr;                   // per-tile entries (row masks + records) expanded from the plan on the device (kernels_warp_bin.hip)
     void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
@@ -81,7 +83,7 @@ struct poppy_hip_ctx {
     int max_tris = 0;
     // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
     //              [RasterTri T][work 2*n i32]
-    size_t blob_bytes = 0;
+    size_t blob_bytes = 0; size_t bins_cap = 0;       // bins_cap: most per-tile triangle-list entries a plan blob has room for
     int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
@@ -92,11 +94,12 @@ struct poppy_hip_ctx {
     int last_nfeatures = 0;
     AutoAligner aligner;
     uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
-    unsigned long long n_warp_fast = 0, n_warp_general = 0;       // frames rendered by the tiled / the general warp kernel since create
+    unsigned long long n_warp_fast = 0, n_warp_general = 0, n_warp_bin = 0;   // frames by warp kernel since create: tiled (id map), general, fused raster
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used
+    bool last_warp_bin = false;
     double last_detail[2] = {0, 0};
     // diagnostics
     bool debug = false;
@@ -125,6 +128,7 @@ inline size_t pair_state_bytes(int W, int H) {
     const size_t P = (size_t)W * H;
     return kPairHeadBytes + 2 * (size_t)kPairMaxPoints * 8 + 2 * pair_align(P * 3 + 16) + pair_align(P * 4);
 }
+int drain_frames(poppy_hip_ctx* c);                // waits for every frame queued on this context (all streams)
 int stage_pair_state(poppy_hip_ctx* c);            // header + points -> arena head (queued on c->stream)
 int adopt_pair_state(poppy_hip_ctx* c);            // arena head -> points, chain state; the pair becomes ready
 

@@ -308,6 +308,97 @@ static void build_raster(FramePlan& plan, int w, int h) {
     }
 }
 
+// clipLine (drawing.cpp:80-130) on 64-bit coordinates, with its double arithmetic and truncations
+static bool clip_line_ref(long long W, long long H, long long& x1, long long& y1, long long& x2, long long& y2) {
+    const long long right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a; c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a; c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// The three outline segments of every triangle in the form the fused warp kernel evaluates row by row.
+static void build_outlines(FramePlan& plan, int w, int h) {
+    const int T = plan.n_tris;
+    plan.outline.assign((size_t)T * 3, OutlineSeg{0, 0, -1, 0});
+    for (int t = 0; t < T; ++t) {
+        const int* v = &plan.tri_xy[(size_t)t * 6];
+        for (int e = 0; e < 3; ++e) {
+            const int ia = e == 0 ? 2 : e - 1, ib = e == 0 ? 0 : e;
+            long long ax = v[2 * ia], ay = v[2 * ia + 1], bx = v[2 * ib], by = v[2 * ib + 1];
+            if ((unsigned long long)ax >= (unsigned long long)w || (unsigned long long)bx >= (unsigned long long)w ||
+                (unsigned long long)ay >= (unsigned long long)h || (unsigned long long)by >= (unsigned long long)h) {
+                if (!clip_line_ref(w, h, ax, ay, bx, by)) continue;
+            }
+            long long dx = bx - ax, dy = by - ay, x0 = ax, y0 = ay;
+            if (dx < 0) { dx = -dx; dy = -dy; x0 = bx; y0 = by; }
+            int flags = 0;
+            if (dy < 0) { dy = -dy; flags |= 2; }
+            if (dy > dx) flags |= 1;
+            const long long major = (flags & 1) ? dy : dx, minor = (flags & 1) ? dx : dy;
+            plan.outline[(size_t)t * 3 + e] = OutlineSeg{(int)x0, (int)y0, (int)major, (int)minor | (flags << 24)};
+        }
+    }
+}
+
+bool build_tile_bins(FramePlan& plan, int w, int h, int tile_w, int tile_h, size_t max_entries) {
+    const int T = plan.n_tris;
+    const int tiles_x = (w + tile_w - 1) / tile_w, tiles_y = (h + tile_h - 1) / tile_h;
+    plan.tile_w = tile_w; plan.tile_h = tile_h; plan.bins_ok = false;
+    plan.tile_off.assign((size_t)tiles_x * tiles_y + 1, 0);
+    plan.tile_tris.clear();
+    if (T > 65535) return false;
+    struct Box { int tx0, tx1, ty0, ty1; };
+    std::vector<Box> box(T);
+    size_t total = 0;
+    for (int t = 0; t < T; ++t) {
+        const int* v = &plan.tri_xy[(size_t)t * 6];
+        int x0 = std::min({v[0], v[2], v[4]}) - 1, x1 = std::max({v[0], v[2], v[4]}) + 1;
+        int y0 = std::min({v[1], v[3], v[5]}) - 1, y1 = std::max({v[1], v[3], v[5]}) + 1;
+        x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, w - 1); y1 = std::min(y1, h - 1);
+        if (x1 < x0 || y1 < y0) { box[t] = Box{1, 0, 1, 0}; continue; }
+        box[t] = Box{x0 / tile_w, x1 / tile_w, y0 / tile_h, y1 / tile_h};
+        for (int ty = box[t].ty0; ty <= box[t].ty1; ++ty)
+            for (int tx = box[t].tx0; tx <= box[t].tx1; ++tx) ++plan.tile_off[(size_t)ty * tiles_x + tx + 1];
+        total += (size_t)(box[t].tx1 - box[t].tx0 + 1) * (box[t].ty1 - box[t].ty0 + 1);
+        if (total > max_entries) return false;
+    }
+    for (size_t i = 1; i < plan.tile_off.size(); ++i) plan.tile_off[i] += plan.tile_off[i - 1];
+    plan.tile_tris.resize(total);
+    std::vector<int> fill(plan.tile_off.begin(), plan.tile_off.end() - 1);
+    for (int t = 0; t < T; ++t)                            // ascending t: every tile's list comes out in painter's order
+        for (int ty = box[t].ty0; ty <= box[t].ty1; ++ty)
+            for (int tx = box[t].tx0; tx <= box[t].tx1; ++tx) plan.tile_tris[fill[(size_t)ty * tiles_x + tx]++] = (uint16_t)t;
+    plan.bins_ok = true;
+    return true;
+}
+
 void unique_points_ref(const std::vector<P2f>& pts, std::vector<P2f>& out) {
     std::set<P2f, P2fLess> seen;
     out.clear();
@@ -374,6 +465,7 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
         invert3x3(M2, &plan.inv2[(size_t)t * 9]);
     }
     build_raster(plan, w, h);
+    build_outlines(plan, w, h);
     return 0;
 }
 

@@ -21,6 +21,13 @@ struct RasterTri {
 };
 static_assert(sizeof(RasterTri) == 96, "RasterTri is shared with the device");
 
+// One outline segment of a triangle as Line() walks it (drawing.cpp:80-297): clipped to the image (clipLine, in its double
+// arithmetic) and swapped so that x increases.  Step k = 0 .. major puts a pixel at (x0 + k, y0 +- m_k) — or, when steep,
+// (x0 + m_k, y0 +- k) — with m_k = max(0, ceil((2 minor k - major) / (2 major))).  flags: bit 0 steep, bit 1 the y direction is
+// negative; major < 0 marks a segment that lies outside the image altogether.
+struct OutlineSeg { int x0, y0, major, minor_flags; };     // minor_flags = minor | flags << 24
+static_assert(sizeof(OutlineSeg) == 16, "OutlineSeg is shared with the device");
+
 struct FramePlan {
     std::vector<P2f> morphed;        // n   (after clip_points)
     std::vector<int> idx3;           // T*3 indices into the point sets
@@ -29,8 +36,18 @@ struct FramePlan {
     std::vector<float> inv1, inv2;   // T*9 inverse matrices, what create_map actually uses
     std::vector<RasterTri> raster;   // T fill-edge tables
     std::vector<int> work;           // raster work list: (triangle, -1) = outline, (triangle, row chunk) = fill rows
+    std::vector<OutlineSeg> outline; // T*3 segments: (v2,v0), (v0,v1), (v1,v2) — the order fillConvexPoly draws them in
+    // triangles per warp tile (kernels_warp_bin.hip): tile_off[tile] .. tile_off[tile + 1] indexes tile_tris, ascending ids
+    std::vector<int> tile_off;
+    std::vector<uint16_t> tile_tris;
+    int tile_w = 0, tile_h = 0;
+    bool bins_ok = false;            // build_tile_bins succeeded for (tile_w, tile_h)
     int n_tris = 0;
 };
+// Bins the triangles of `plan` into tile_w x tile_h tiles of the w x h image (every tile a triangle's bounding box touches).
+// Returns false when a triangle index does not fit 16 bits or the list outgrows max_entries (the caller then takes the
+// id-map path).
+bool build_tile_bins(FramePlan& plan, int w, int h, int tile_w, int tile_h, size_t max_entries);
 constexpr int kPlanRasterRows = 16;  // rows of one triangle per raster work item
 
 // Returns 0, or -3 (POPPY_E_RANGE) when a point is outside [0,w)x[0,h) where Subdiv2D::insert throws.

@@ -50,6 +50,19 @@ bool warp_fast_geometry(int w, int h);
 void launch_warp_fast(int32_t* triMap, const float* records, int n_records, const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
                       int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
+// paint_triangles + create_map + remap without an id map in HBM (kernels_warp_bin.hip).  launch_tile_expand turns the host plan's
+// fill-edge tables (RasterTri), outline segments (OutlineSeg) and per-tile triangle lists into per-tile entries — a coverage bit mask
+// per tile row plus the triangle's warp record, warp_bin_entry_bytes() each — and depends on the plan only (it runs on the plan-upload
+// stream); launch_warp_bin resolves every pixel's triangle from those masks and warps.  Same geometries as launch_warp_fast;
+// tile_w = warp_bin_tile_width(w, h) is also what the host bins with.
+int warp_bin_tile_width(int w, int h);
+size_t warp_bin_entry_bytes();
+void launch_tile_expand(const float* records, const void* raster_tris, const void* outline, const int* tile_off, const uint16_t* tile_tris,
+                        void* tile_data, int tile_w, int w, int h, hipStream_t s);
+void launch_warp_bin(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
+                     const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
+                     int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+
 // one Gaussian-pyramid reduction step for L, R (3 channels) and the mask (1 channel) in one launch.
 // level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,

@@ -1,0 +1,248 @@
+// kernels_warp_bin.hip — paint_triangles + create_map + remap of both sources without a triangle-id map in HBM.
+//
+//   src/algo.cpp:95-106 (paint_triangles), OCV/imgproc/src/drawing.cpp:80-297,1093-1255 (Line, FillConvexPoly)
+//   src/algo.cpp:146-176 (create_map), OCV/imgproc/src/imgwarp.cpp:1197-1234,721-731,808-852 (remap)
+//
+// The id a pixel ends up with is the LAST triangle whose outline-or-fill raster covers it (fillConvexPoly paints them one
+// after another), i.e. the largest covering index.  The host bins the triangles by 1024-pixel tile (64 x 16 or 128 x 8;
+// frame_plan.cpp: build_tile_bins, ascending order) and hands every triangle's fill-edge table (RasterTri) and its three outline
+// segments, already clipped and ordered as Line() walks them (OutlineSeg).  Two kernels:
+//   k_tile_expand   one thread per (triangle of a tile's list, row of the tile) evaluates that row of the raster in closed form —
+//                   the fill span from the two edge chains (one 64-bit multiply-add each), the pixels of the three Bresenham
+//                   outlines that fall on the row (an interval per segment: a shallow segment puts a run on a row, a steep one a
+//                   single pixel) — and writes a coverage BIT MASK of the tile row; it also copies the triangle's warp record
+//                   next to the masks.  A tile's entries are contiguous (208 bytes each: 128 of masks + the 80-byte record).
+//                   This kernel depends on the plan only, not on any image: it runs on the plan-upload stream, off the chained
+//                   frames' critical path.  8 bits of mask per pixel-row-triangle instead of a 32-bit id per pixel.
+//   k_warp_bin      a workgroup owns a tile: every thread loads the masks of ITS row for the tile's triangles (independent
+//                   8-byte loads, all in flight together with the record staging into LDS), walks them in painter's order
+//                   keeping the last covering entry for each of its 4 pixels, and continues as k_warp_tile's second half
+//                   (warp_fast_device.h): records from LDS, packed map arithmetic, aligned footprint loads, v_dot2 blends.
+// Compared with k_raster + k_warp_tile this removes 4 B/px written and 4 B/px read, the atomics and the frame tags, and the
+// warp kernel's dependent memory round trips drop from three (ids -> records -> footprints) to two.
+#include "warp_fast_device.h"
+#include <climits>
+#include <cstdlib>
+
+namespace poppy_hip {
+
+namespace {
+
+struct RasterTriDev {                       // frame_plan.h: RasterTri
+    int ymin, ystop, n0, n1;
+    int ybeg[4];
+    long long ex[4], edx[4];
+};
+static_assert(sizeof(RasterTriDev) == 96, "layout shared with the host plan");
+
+struct Interval { int lo, hi; };            // inclusive; lo > hi = empty
+
+// pixels of triangle row y painted by the fill (drawing.cpp:1228-1245)
+__device__ __forceinline__ Interval fill_row(const RasterTriDev& r, int y, int W) {
+    Interval iv{1, 0};
+    if (y < r.ymin || y >= r.ystop || y < 0) return iv;
+    const bool s0 = r.n0 > 1 && y >= r.ybeg[1], s1 = r.n1 > 1 && y >= r.ybeg[3];
+    const long long a = (s0 ? r.ex[1] : r.ex[0]) + (long long)(y - (s0 ? r.ybeg[1] : r.ybeg[0])) * (s0 ? r.edx[1] : r.edx[0]);
+    const long long b = (s1 ? r.ex[3] : r.ex[2]) + (long long)(y - (s1 ? r.ybeg[3] : r.ybeg[2])) * (s1 ? r.edx[3] : r.edx[2]);
+    const long long xl = a > b ? b : a, xr = a > b ? a : b;
+    int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+    if (xx2 >= 0 && xx1 < W) {
+        iv.lo = xx1 < 0 ? 0 : xx1;
+        iv.hi = xx2 >= W ? W - 1 : xx2;
+    }
+    return iv;
+}
+
+// pixels of one outline segment on row y: the steps k of the 8-connected Bresenham walk (drawing.cpp:159-245 with
+// leftToRight) whose minor offset m_k = max(0, ceil((2 minor k - major) / (2 major))) puts them on this row
+__device__ __forceinline__ Interval outline_row(int4 seg, int y) {
+    Interval iv{1, 0};
+    const int x0 = seg.x, y0 = seg.y, major = seg.z, minor = seg.w & 0xffffff, flags = seg.w >> 24;
+    if (major < 0) return iv;
+    const int d = (flags & 2) ? y0 - y : y - y0;                 // rows walked from the start, in the segment's y direction
+    if (flags & 1) {                                             // steep: one pixel per row, k = d
+        if (d < 0 || d > major) return iv;
+        int m = 0;
+        const int num = 2 * minor * d - major;
+        if (num > 0) m = (num + 2 * major - 1) / (2 * major);
+        iv.lo = iv.hi = x0 + m;
+    } else {                                                     // shallow: row d holds the run of steps with m_k == d
+        if (d < 0 || d > minor) return iv;
+        const int k_lo = d == 0 ? 0 : (int)((unsigned)(major * (2 * d - 1)) / (unsigned)(2 * minor)) + 1;
+        const int k_hi = d == minor ? major : (int)((unsigned)(major * (2 * d + 1)) / (unsigned)(2 * minor));
+        iv.lo = x0 + k_lo; iv.hi = x0 + k_hi;
+    }
+    return iv;
+}
+
+// bits [a, b) of a 128-bit tile-row mask for the part of [lo, hi] inside the tile
+template <int kTileW>
+__device__ __forceinline__ void add_interval(Interval iv, int tx0, uint64_t& m0, uint64_t& m1) {
+    int a = iv.lo - tx0, b = iv.hi + 1 - tx0;
+    a = a < 0 ? 0 : a; b = b > kTileW ? kTileW : b;
+    if (b <= a) return;
+    // bits [a, b) = ones(b) & ~ones(a), ones(n) = low n bits set (n in 0..128)
+    auto ones = [](int n, int word) -> uint64_t {
+        const int k = n - 64 * word;
+        return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
+    };
+    m0 |= ones(b, 0) & ~ones(a, 0);
+    if (kTileW > 64) m1 |= ones(b, 1) & ~ones(a, 1);
+}
+
+}  // namespace
+
+// bytes of one tile entry: the masks of the tile's rows (8 x 16 or 16 x 8 bytes) and the triangle's 80-byte warp record
+constexpr int kEntryBytes = 208;
+constexpr int kEntryMaskBytes = 128;
+
+template <int kTileW>
+__global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ rec, const RasterTriDev* __restrict__ tris,
+                                                     const int4* __restrict__ outline, const int* __restrict__ tile_off,
+                                                     const uint16_t* __restrict__ tile_tris, uint8_t* __restrict__ tile_data,
+                                                     int W, int tiles_x) {
+    constexpr int kTileH = 1024 / kTileW, kPass = 256 / kTileH, kWords = kTileW / 64;
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tx0 = tx * kTileW, ty0 = ty * kTileH;
+    const int off0 = tile_off[tile], nb = tile_off[tile + 1] - off0;
+    const int ji = tid / kTileH, jr = tid % kTileH;              // this thread's job: (entry ji of the pass, tile row jr)
+    for (int base = 0; base < nb; base += kPass) {
+        const int n_here = min(kPass, nb - base);
+        if (ji < n_here) {
+            const int t = tile_tris[off0 + base + ji];
+            const RasterTriDev r = tris[t];
+            const int yy = ty0 + jr;
+            uint64_t m0 = 0, m1 = 0;
+            add_interval<kTileW>(fill_row(r, yy, W), tx0, m0, m1);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) add_interval<kTileW>(outline_row(outline[t * 3 + e], yy), tx0, m0, m1);
+            uint64_t* dst = (uint64_t*)(tile_data + (size_t)(off0 + base + ji) * kEntryBytes) + jr * kWords;
+            dst[0] = m0;
+            if (kWords > 1) dst[kWords - 1] = m1;
+        }
+        if (tid < n_here * 5) {                                  // the entries' records
+            const int e = tid / 5, part = tid - e * 5;
+            const int t1 = tile_tris[off0 + base + e] + 1;
+            *(float4*)(tile_data + (size_t)(off0 + base + e) * kEntryBytes + kEntryMaskBytes + part * 16) = rec[(size_t)t1 * 5 + part];
+        }
+    }
+}
+
+template <int kTileW>
+__global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
+                                                  const int* __restrict__ tile_off,
+                                                  const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
+                                                  uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
+                                                  int tiles_x, uint32_t data_bytes, WarpExtras ex) {
+    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4, kWords = kTileW / 64;
+    constexpr int kCached = 31;                                  // entries whose records are staged in LDS (slot 0: the identity)
+    constexpr int kChunk = 32;                                   // entries whose row masks are staged in LDS per pass: 32 x 128 bytes
+    __shared__ float4 s_rec[(kCached + 1) * 5];
+    __shared__ __attribute__((aligned(16))) uint64_t s_mask[kChunk * 16];
+
+    const int tid = threadIdx.x;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int row = tid / kTileTx, xg = tid % kTileTx;           // this thread's pixels: (tx0 + 4 xg .. + 3, ty0 + row)
+    const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
+    const bool active = x0 < W && y < H;
+    const uint32_t g = (uint32_t)y * (uint32_t)(W >> 2) + (uint32_t)(x0 >> 2);
+    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
+    const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
+    const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
+
+    const int off0 = tile_off[tile], nb = tile_off[tile + 1] - off0;          // uniform: scalar loads
+    const uint32_t ebase = (uint32_t)off0 * (uint32_t)kEntryBytes;
+    // ONE round trip brings everything the tile needs: the row masks of its entries (thread t: 16 bytes of entry t / 8), the
+    // entries' records (slot 0 = record 0 = the identity of "no triangle") and this thread's four m2 values
+    const int n_cached = min(nb, kCached);
+    const bool stages = tid < (n_cached + 1) * 5;
+    float4 staged = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stages) {
+        const int slot = tid / 5, part = tid - slot * 5;
+        staged = slot ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ebase + (uint32_t)(slot - 1) * kEntryBytes + kEntryMaskBytes + part * 16, 0, 0))
+                      : rec[part];
+    }
+    float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active && ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
+    int id[4] = {0, 0, 0, 0};                                    // entry index + 1 of the last covering triangle per pixel
+    const int mword = row * kWords + ((xg * 4) >> 6), shift = (xg * 4) & 63;
+    for (int base = 0; base < nb || base == 0; base += kChunk) {
+        const int n_here = min(kChunk, nb - base);
+        if (base) __syncthreads();                               // the previous pass's masks have been read
+        if (tid < n_here * 8) {
+            const u4v mv = __builtin_amdgcn_raw_buffer_load_b128(rdata, ebase + (uint32_t)(base + (tid >> 3)) * kEntryBytes + (uint32_t)(tid & 7) * 16u, 0, 0);
+            *(u4v*)(s_mask + tid * 2) = mv;
+        }
+        if (base == 0 && stages) s_rec[tid] = staged;
+        __syncthreads();
+        for (int i = 0; i < n_here; ++i) {                       // painter's order: a later entry overwrites
+            const uint64_t mm = s_mask[i * 16 + mword];
+            const uint32_t bits = (uint32_t)(mm >> shift) & 15u;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) id[px] = ((bits >> px) & 1u) ? base + i + 1 : id[px];
+        }
+        if (nb == 0) break;
+    }
+    if (active && ex.m2) {                                       // the lbmask rider
+        const float4 o = make_float4(mask_value(m2v.x, ex.alpha, ex.beta), mask_value(m2v.y, ex.alpha, ex.beta),
+                                     mask_value(m2v.z, ex.alpha, ex.beta), mask_value(m2v.w, ex.alpha, ex.beta));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), make_rsrc(ex.mask, npx * 4u), g * 16u, 0, 0);
+    }
+    if (!active) return;
+
+    const float fy = (float)y;
+    FastTap t[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 A, B, C, D; f2 E;
+        if (id[k] <= kCached) {
+            const int li = id[k];
+            A = s_rec[li * 5]; B = s_rec[li * 5 + 1]; C = s_rec[li * 5 + 2]; D = s_rec[li * 5 + 3];
+            const float4 e4 = s_rec[li * 5 + 4];
+            E = f2{e4.x, e4.y};
+        } else {                                                 // a tile with more triangles than the LDS stage holds
+            const uint32_t ro = ebase + (uint32_t)(id[k] - 1) * kEntryBytes + kEntryMaskBytes;
+            A = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro, 0, 0));
+            B = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 16, 0, 0));
+            C = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 32, 0, 0));
+            D = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 48, 0, 0));
+            E = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rdata, ro + 64, 0, 0));
+        }
+        warp_taps(A, B, C, D, E, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
+    }
+    warp_fetch_blend_store(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {
+        return id[k] ? (const float*)(tile_data + (size_t)(off0 + id[k] - 1) * kEntryBytes + kEntryMaskBytes) : (const float*)rec;
+    });
+}
+
+int warp_bin_tile_width(int w, int h) {
+    static const int forced = getenv("POPPY_TILE_W") ? atoi(getenv("POPPY_TILE_W")) : 0;
+    if (forced == 64 || forced == 128) return forced;
+    return (long long)w * h >= 4000000 ? 128 : 64;
+}
+size_t warp_bin_entry_bytes() { return kEntryBytes; }
+
+void launch_tile_expand(const float* records, const void* raster_tris, const void* outline, const int* tile_off, const uint16_t* tile_tris,
+                        void* tile_data, int tile_w, int w, int h, hipStream_t s) {
+#define LE(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
+    hipLaunchKernelGGL(k_tile_expand<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, (const float4*)records, (const RasterTriDev*)raster_tris, \
+                       (const int4*)outline, tile_off, tile_tris, (uint8_t*)tile_data, w, tiles_x); }
+    if (tile_w == 128) LE(128) else LE(64)
+#undef LE
+}
+
+void launch_warp_bin(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
+                     const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
+                     int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+#define LB(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
+    hipExtLaunchKernelGGL(k_warp_bin<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const float4*)records, \
+                          (const uint8_t*)tile_data, tile_off, c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, \
+                          w, h, tiles_x, (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u), ex); }
+    if (tile_w == 128) LB(128) else LB(64)
+#undef LB
+}
+
+}  // namespace poppy_hip

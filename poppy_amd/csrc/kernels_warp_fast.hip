@@ -23,87 +23,11 @@
 //
 // Per-triangle data comes as one 80-byte record holding both inverse matrices in the order the packed
 // instructions consume them; record 0 is the identity (id-map value 0 = no triangle = mapx,mapy = x,y).
-#include "kernels.h"
-#include "warp_device.h"
-#include <hip/hip_ext.h>
+#include "warp_fast_device.h"
 #include <climits>
 #include <cstdlib>
 
 namespace poppy_hip {
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-
-namespace {
-
-__device__ __forceinline__ f2 div_core(f2 n, f2 d, f2 r1) {
-    f2 q0 = n * r1;
-    f2 s0 = __builtin_elementwise_fma(-d, q0, n);
-    f2 q1 = __builtin_elementwise_fma(s0, r1, q0);
-    f2 s1 = __builtin_elementwise_fma(-d, q1, n);
-    return __builtin_elementwise_fma(s1, r1, q1);
-}
-
-// (sx, sy) = cvRound(q * 32) for both coordinates; out-of-range values come back far outside any image
-__device__ __forceinline__ void to_fixed(f2 q, int& sx, int& sy) {
-    const f2 k32 = {32.f, 32.f};
-    f2 v = q * k32;
-    v.x = __builtin_amdgcn_fmed3f(v.x, -2097152.f, 2097152.f);
-    v.y = __builtin_amdgcn_fmed3f(v.y, -2097152.f, 2097152.f);
-    const f2 magic = {12582912.f, 12582912.f};
-    const f2 t = v + magic;
-    sx = __float_as_int(t.x) - 0x4B400000;
-    sy = __float_as_int(t.y) - 0x4B400000;
-}
-
-struct FastTap { uint32_t wt, wb, off; bool inside; };
-
-__device__ __forceinline__ FastTap make_fast_tap(int sx, int sy, int W, int H) {
-    FastTap t;
-    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
-    t.inside = (unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1);
-    const uint32_t P = __umul24(fx, 65535u) + 32u;                 // (32 - fx) | fx << 16
-    t.wt = __umul24(P, (uint32_t)(1024 - (fy << 5)));              // w00 | w01 << 16
-    t.wb = __umul24(P, (uint32_t)(fy << 5));                       // w10 | w11 << 16
-    t.off = t.inside ? (uint32_t)(__umul24(iy, W) + ix) * 3u : 0u;
-    return t;
-}
-
-__device__ __forceinline__ uint32_t blend_fast(const FastTap& t, u2v a, u2v b) {
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 3) << 16);
-        const uint32_t pt = __builtin_amdgcn_perm(a.y, a.x, sel);                // s00 | s01 << 16
-        const uint32_t pb = __builtin_amdgcn_perm(b.y, b.x, sel);
-        uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pt), __builtin_bit_cast(us2, t.wt), 16384u, false);
-        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pb), __builtin_bit_cast(us2, t.wb), acc, false);
-        out |= (acc >> 15) << (8 * k);
-    }
-    return out;
-}
-
-// raw buffer descriptor over [p, p + bytes): 32-bit offsets straight into the load instruction, no 64-bit address arithmetic
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-
-// footprint on or over the image border: the byte-wise definition, from the record's matrix
-__device__ __forceinline__ uint32_t slow_pixel(const float* __restrict__ rec, int src, const uint8_t* __restrict__ img, int W, int H, int x, int y) {
-    float h[9];
-    if (src == 0) { h[0] = rec[0]; h[3] = rec[1]; h[1] = rec[2]; h[4] = rec[3]; h[2] = rec[4]; h[5] = rec[5]; }
-    else          { h[0] = rec[6]; h[3] = rec[7]; h[1] = rec[8]; h[4] = rec[9]; h[2] = rec[10]; h[5] = rec[11]; }
-    h[6] = rec[12 + src]; h[7] = rec[14 + src]; h[8] = rec[16 + src];
-    float mx, my;
-    map_point(h, x, y, mx, my);
-    uint8_t o[3];
-    sample3(img, W, H, mx, my, o);
-    return o[0] | (o[1] << 8) | (o[2] << 16);
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 // One workgroup = one 64 x 16 pixel tile (16 x 16 threads, 4 pixels per thread), tiles numbered XCD by XCD.
@@ -113,7 +37,6 @@ __device__ __forceinline__ uint32_t slow_pixel(const float* __restrict__ rec, in
 // ALIGNED dwords per row and shifted into place (v_alignbyte): the unaligned 8-byte form costs the texture path more.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSlots = 64;
-typedef unsigned u3v __attribute__((ext_vector_type(3)));
 
 template <int kTileW>
 __global__ void __launch_bounds__(256) k_warp_tile(int4* __restrict__ triMap4, const float4* __restrict__ rec,

@@ -87,7 +87,8 @@ static void free_pair(poppy_hip_ctx* c) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }
         if (f.h_blob) (void)hipHostFree(f.h_blob);
         if (f.d_blob) (void)hipFree(f.d_blob);
-        f.h_blob = nullptr; f.d_blob = nullptr;
+        if (f.tile_data) (void)hipFree(f.tile_data);
+        f.h_blob = nullptr; f.d_blob = nullptr; f.tile_data = nullptr;
     }
     c->max_tris = 0; c->W = c->H = 0; c->pair_ready = false;
 }
@@ -124,9 +125,10 @@ int poppy_warp_records(const float* inv1, const float* inv2, int n_tris, int wid
     if (n_tris < 0 || width < 1 || height < 1 || !records || (n_tris > 0 && (!inv1 || !inv2))) return POPPY_E_ARG;
     return pack_warp_records(inv1, inv2, n_tris, width, height, records) ? 1 : 0;
 }
-int poppy_hip_last_warp_kind(poppy_hip_ctx* c) { return c ? (c->last_warp_fast ? 1 : 0) : POPPY_E_ARG; }
-int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* tiled, unsigned long long* general) {
+int poppy_hip_last_warp_kind(poppy_hip_ctx* c) { return c ? (c->last_warp_bin ? 2 : c->last_warp_fast ? 1 : 0) : POPPY_E_ARG; }
+int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general) {
     if (!c) return POPPY_E_ARG;
+    if (fused) *fused = c->n_warp_bin;
     if (tiled) *tiled = c->n_warp_fast;
     if (general) *general = c->n_warp_general;
     return POPPY_OK;
@@ -134,8 +136,7 @@ int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* tiled, unsigned 
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
-// `stream` waits on every frame as it is queued (submit_frame), so draining it drains the slots' streams too
-int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return POPPY_OK; }
+int poppy_hip_sync(poppy_hip_ctx* c) { if (!c) return POPPY_E_ARG; HIPCHK(c, hipSetDevice(c->device)); return drain_frames(c); }
 
 }  // extern "C"
 
@@ -147,13 +148,19 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 3);
+    const int tw = warp_bin_tile_width(c->W, c->H), th = 1024 / tw;
+    const size_t ntiles = (size_t)((c->W + tw - 1) / tw) * ((c->H + th - 1) / th);
+    c->bins_cap = 64 * (size_t)need + 16 * ntiles;
     const size_t bytes = ((kBlobHeader + (size_t)(need + 1) * kWarpRecordFloats * 4 +
-                          (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 + 15) / 16) * 16;
+                          (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 +
+                          (size_t)need * 3 * sizeof(OutlineSeg) + (ntiles + 1) * 4 + c->bins_cap * 2 + 64 + 15) / 16) * 16;
     for (FrameSlot& f : c->slots) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob
         if (f.h_blob) (void)hipHostFree(f.h_blob);
         if (f.d_blob) (void)hipFree(f.d_blob);
-        f.h_blob = f.d_blob = nullptr;
+        if (f.tile_data) (void)hipFree(f.tile_data);
+        f.h_blob = f.d_blob = f.tile_data = nullptr;
+        HIPCHK(c, hipMalloc((void**)&f.tile_data, c->bins_cap * warp_bin_entry_bytes() + 256));
         HIPCHK(c, hipHostMalloc((void**)&f.h_blob, bytes, hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer(&f.h_blob_dev, f.h_blob, 0));
         HIPCHK(c, hipMalloc((void**)&f.d_blob, bytes));
@@ -164,9 +171,8 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
 }
 
 int alloc_pair(poppy_hip_ctx* c, int W, int H) {
+    { int rc = drain_frames(c); if (rc) return rc; }              // every pair loader comes through here: no frame still reads the old pair
     if (c->W == W && c->H == H && c->c1) return POPPY_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (FrameSlot& f : c->slots) if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
     free_pair(c);
     if (c->cfg.pyramid_levels < 1 || c->cfg.pyramid_levels > 256) return fail(c, POPPY_E_UNSUPPORTED, "pyramid_levels must be in [1,256]");
     const size_t P = (size_t)W * H;
@@ -231,7 +237,15 @@ int finish_pair_load(poppy_hip_ctx* c) {
     launch_gray_inv(c->gabor2, c->m2, c->W * c->H, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // frames on other streams do not wait for the pair on the device: it is complete here
     c->cur1 = c->c1; c->cur1_ready = nullptr; c->last_slot = -1; c->pair_ready = true;
+    return POPPY_OK;
+}
+
+// every frame queued on this context has finished (independent frames run on their slots' streams)
+int drain_frames(poppy_hip_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (FrameSlot& f : c->slots) if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
     return POPPY_OK;
 }
 
@@ -267,6 +281,7 @@ int adopt_pair_state(poppy_hip_ctx* c) {
     if (rc) return rc;
     c->c2_raw_valid = false;
     HIPCHK(c, hipEventRecord(c->inputs_ready, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // frames on other streams do not wait for the pair on the device: it is complete here
     c->cur1 = c->c1; c->cur1_ready = nullptr; c->last_slot = -1; c->pair_ready = true;
     return POPPY_OK;
 }
@@ -306,6 +321,7 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
     int rc = plan_frame(c->W, c->H, c->pts1, c->pts2, shape, c->plan);
     if (rc) return fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)");
+    if (warp_fast_geometry(c->W, c->H)) { const int tw = warp_bin_tile_width(c->W, c->H); build_tile_bins(c->plan, c->W, c->H, tw, 1024 / tw, c->bins_cap); }
     return submit_frame(c, mask, chain);
 }
 
@@ -338,11 +354,13 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     for (auto& r : ready) r.store(0);
     std::atomic<int> next{0};
     const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency() - 1}));
+    const int bin_tw = warp_fast_geometry(W, H) ? warp_bin_tile_width(W, H) : 0;
     auto worker = [&]() {
         for (;;) {
             const int j = next.fetch_add(1);
             if (j >= n) return;
             rcs[j] = plan_frame(W, H, chain ? src1[j] : src1[0], c->pts2, shape[j], plans[j]);
+            if (!rcs[j] && bin_tw) build_tile_bins(plans[j], W, H, bin_tw, 1024 / bin_tw, c->bins_cap);
             ready[j].store(1, std::memory_order_release);
         }
     };
@@ -515,7 +533,17 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 144 + 176*T: 8-byte aligned
     int* h_work = (int*)(h_edges + T);
     const int n_work = (int)(c->plan.work.size() / 2);
-    const size_t used = kBlobHeader + rec_bytes + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + (size_t)n_work * 8;
+    // the fused raster+warp kernel's inputs follow the work list: outline segments, per-tile offsets, per-tile triangle lists
+    const size_t work_ints = ((size_t)n_work * 2 + 3) & ~(size_t)3;       // the work list padded to 16 bytes: what follows is read as int4
+    OutlineSeg* h_outl = (OutlineSeg*)(h_work + work_ints);
+    int* h_toff = (int*)(h_outl + (size_t)T * 3);
+    const size_t n_toff = c->plan.tile_off.size(), n_ttri = c->plan.tile_tris.size();
+    uint16_t* h_ttri = (uint16_t*)(h_toff + n_toff);
+    static const bool idmap_only = getenv("POPPY_HIP_IDMAP") != nullptr;
+    const bool bins = c->plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap &&
+                      c->plan.tile_w == warp_bin_tile_width(W, H);
+    const size_t used = kBlobHeader + rec_bytes + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + work_ints * 4 +
+                        (bins ? (size_t)T * 3 * sizeof(OutlineSeg) + n_toff * 4 + n_ttri * 2 : 0);
     if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     if (T) {
         memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
@@ -524,27 +552,41 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         memcpy(h_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
         memcpy(h_work, c->plan.work.data(), (size_t)n_work * 8);
     }
+    if (bins) {
+        if (T) memcpy(h_outl, c->plan.outline.data(), (size_t)T * 3 * sizeof(OutlineSeg));
+        memcpy(h_toff, c->plan.tile_off.data(), n_toff * 4);
+        if (n_ttri) memcpy(h_ttri, c->plan.tile_tris.data(), n_ttri * 2);
+    }
     // the fast warp kernel takes the frame when every matrix passes the host's range check (always, short of degenerate input)
     static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
     const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader)) &&
                            warp_fast_geometry(W, H) && !exact_warp_only;
-    c->last_warp_fast = fast_warp;
-    ++(fast_warp ? c->n_warp_fast : c->n_warp_general);
+    const bool bin_warp = fast_warp && bins;                 // raster fused into the warp kernel: no id map at all
+    c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;
+    ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
     const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
     const int* d_tri = (const int*)(f.d_blob + kBlobHeader + rec_bytes);
     const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
     const RasterTri* d_edges = (const RasterTri*)(d_inv + (size_t)T * 18);
     const int* d_work = (const int*)(d_edges + T);
+    const OutlineSeg* d_outl = (const OutlineSeg*)(d_work + work_ints);
+    const int* d_toff = (const int*)(d_outl + (size_t)T * 3);
+    const uint16_t* d_ttri = (const uint16_t*)(d_toff + n_toff);
 
-    // POPPY_HIP_HEADMODE=1 moves a chained frame's clear/raster/mask to the slot's stream so that it overlaps the previous
-    // frame.  Measured on MI355X (profiles/r01_e_streams.md) the cross-queue hand-over costs 12-20 us, more than the
-    // ~45 us head saves once queue sharing is counted, so chained frames stay on one stream by default.
-    static const int head_mode = getenv("POPPY_HIP_HEADMODE") ? atoi(getenv("POPPY_HIP_HEADMODE")) : 0;
+    // Streams.  Device-side waits between streams that sit on different hardware queues cost 12-20 us each on this part
+    // (profiles/r01_e_streams.md), and which streams share a queue is the runtime's choice (GPU_MAX_HW_QUEUES); phase-mode frames
+    // ran at 8.3k or at 5.2k frames/s depending on it (tools/experiments/frames_only.py).  So no frame waits on another stream's
+    // event on the device:
+    //   chained frames      every kernel on the context's stream; the plan upload and the raster expansion run on the copy stream
+    //                       beside the previous frame and the HOST waits for them (it is a frame ahead of the GPU anyway);
+    //   independent frames  everything — upload, expansion, kernels — in order on the slot's own stream; the other slots' frames
+    //                       hide the upload.  Whoever needs all frames finished drains the slot streams (drain_frames).
     static const bool no_graph = getenv("POPPY_HIP_NOGRAPH") != nullptr;
     const bool chained = chain || c->cur1_ready;
-    if (!f.stream && (!chained || head_mode != 0)) HIPCHK(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
-    hipStream_t s = chained ? c->stream : f.stream;                           // warp .. unsharp
-    hipStream_t head = (chained && head_mode == 0) ? s : f.stream;            // clear, raster, mask
+    if (!f.stream && !chained) HIPCHK(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    hipStream_t s = chained ? c->stream : f.stream;
+    if (f.last_stream && f.last_stream != s) HIPCHK(c, hipEventSynchronize(f.done));     // the mode changed: settle the slot's last frame once, on the host
+    f.last_stream = s;
     if (c->debug && !f.unsharpF) HIPCHK(c, hipMalloc((void**)&f.unsharpF, (size_t)W * H * 12));
     const bool all_marks = c->timing == 1;
     // The captured body is for frames in flight beside each other (phase mode), where the submitting host thread is the
@@ -553,37 +595,31 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const bool use_graph = !no_graph && !chained && !c->debug && !all_marks && W > 1 && H > 1;
     if (use_graph && !f.body) { int rc = capture_body(c, f); if (rc) return rc; }
 
-    Timer th(c, head), tm(c, s);
-    // the plan goes up on its own stream, after the frame that last used this slot has let go of the device copy
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, f.done, 0));
-    launch_upload(f.h_blob_dev, f.d_blob, used, c->copy_stream);
-    HIPCHK(c, hipEventRecord(f.uploaded, c->copy_stream));
-    if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, c->inputs_ready, 0));
-    if (head != c->stream) HIPCHK(c, hipStreamWaitEvent(head, f.done, 0));    // the frame that last used this slot's buffers
-    if (all_marks) th.mark(nullptr);
+    Timer tm(c, s);
+    if (all_marks) tm.mark(nullptr);
+    hipStream_t up = chained ? c->copy_stream : s;
+    if (chained) HIPCHK(c, hipEventSynchronize(f.done));          // the frame that last read this slot's device copy of the plan (2+ frames back)
+    launch_upload(f.h_blob_dev, f.d_blob, used, up);
+    // the raster of the frame, as per-tile row masks: needs the plan only
+    if (bin_warp) launch_tile_expand(d_rec, d_edges, d_outl, d_toff, d_ttri, f.tile_data, c->plan.tile_w, W, H, up);
+    HIPCHK(c, hipEventRecord(f.uploaded, up));
+    if (chained) HIPCHK(c, hipEventSynchronize(f.uploaded));
     // -- independent of the previous frame ---------------------------------------------------------------------
-    // The id map is not cleared between frames: every frame writes its ids above a tag that grows from frame to frame, and
-    // its warp kernel reads everything else as "no triangle" (kernels.h: launch_raster).  A memset is needed for a slot's
-    // first frame, when the tags run out (every 2047 frames), and around debug frames, which keep a plain map for
-    // poppy_hip_debug_fetch.
-    if (c->debug || f.map_tag == 0 || f.map_tag >= kIdTagMax) {
-        HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, head));
-        f.map_tag = 0;
+    // Id-map path only (debug mode, POPPY_HIP_IDMAP, oversized tile lists).  The id map is not cleared between frames: every
+    // frame writes its ids above a tag that grows from frame to frame, and its warp kernel reads everything else as "no
+    // triangle" (kernels.h: launch_raster).  A memset is needed for a slot's first frame, when the tags run out (every 2047
+    // frames), and around debug frames, which keep a plain map for poppy_hip_debug_fetch.
+    if (!bin_warp) {
+        if (c->debug || f.map_tag == 0 || f.map_tag >= kIdTagMax) {
+            HIPCHK(c, hipMemsetAsync(f.triMap, 0, (size_t)W * H * 4, s));
+            f.map_tag = 0;
+        }
+        if (!c->debug) ++f.map_tag;
     }
-    if (!c->debug) ++f.map_tag;
     const uint32_t id_base = (uint32_t)f.map_tag << kIdTagShift;
-    // Chained frames: the host waits for the plan upload itself (it is ~100 us ahead of the GPU, the copy takes ~10) instead of
-    // putting a cross-stream wait in front of the raster, which costs the critical path ~4 us per frame.
-    static const bool host_wait = getenv("POPPY_HIP_STREAMWAIT") == nullptr;
-    if (chained && host_wait) HIPCHK(c, hipEventSynchronize(f.uploaded));
-    else HIPCHK(c, hipStreamWaitEvent(head, f.uploaded, 0));
-    if (all_marks) th.mark("upload+clear");
-    launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, id_base, head);
-    if (all_marks) th.mark("raster");
-    if (s != head) {
-        HIPCHK(c, hipEventRecord(f.prepared, head));
-        HIPCHK(c, hipStreamWaitEvent(s, f.prepared, 0));            // (implies inputs_ready)
-    }
+    if (all_marks) tm.mark("upload+clear");
+    if (!bin_warp) launch_raster(d_tri, d_edges, d_work, n_work, f.triMap, W, H, id_base, s);
+    if (all_marks) tm.mark("raster");
     // -- chained mode: corrected1 is the previous frame (src/poppy.hpp:217) -------------------------------------
     if (c->cur1_ready && c->cur1_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->cur1_ready, 0));
     WarpExtras ex;
@@ -596,11 +632,13 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         static const int stride = getenv("POPPY_HIP_WARP_STAMP_STRIDE") ? std::max(1, atoi(getenv("POPPY_HIP_WARP_STAMP_STRIDE"))) : kWarpStampStride;
         const bool stamp = (c->warp_seq++ % (unsigned)stride) == 0;
         hipEvent_t t0 = stamp ? tm.take(nullptr) : nullptr, t1 = stamp ? tm.take("warp") : nullptr;
-        if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->bins_cap * warp_bin_entry_bytes(), d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
     } else {
-        tm.mark(nullptr);
-        if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        if (!all_marks) tm.mark(nullptr);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->bins_cap * warp_bin_entry_bytes(), d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
@@ -612,7 +650,6 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     else enqueue_body(c, f, s, all_marks ? &tm : nullptr, (float)(1.0 - amount), c->debug, done_rides ? f.done : nullptr);
     HIPCHK(c, hipGetLastError());
     if (!done_rides) HIPCHK(c, hipEventRecord(f.done, s));
-    if (s != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, f.done, 0));   // anything queued on `stream` later sees this frame
     c->last_slot = fi;
     if (chain) {                                   // src/poppy.hpp:217-218
         c->cur1 = f.out;
@@ -676,8 +713,10 @@ int poppy_hip_render(poppy_hip_ctx* c, double shape, double mask, int chain, uin
     int rc = render_frame(c, shape, mask, chain != 0); if (rc) return rc;
     if (dst) {
         if (dst_stride < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "dst_stride too small");
-        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->slots[c->last_slot].out, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FrameSlot& f = c->slots[c->last_slot];
+        hipStream_t fs = f.last_stream ? f.last_stream : c->stream;               // in order behind the frame itself
+        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, f.out, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, fs));
+        HIPCHK(c, hipStreamSynchronize(fs));
     }
     return POPPY_OK;
 }
@@ -814,7 +853,7 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     else if (n == "gabor2") { src = c->gabor2; need = P * 12; }
     else return fail(c, POPPY_E_ARG, "unknown debug buffer");
     if (bytes != need) return fail(c, POPPY_E_ARG, "debug buffer size mismatch");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = drain_frames(c); if (rc) return rc; }
     HIPCHK(c, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
     return POPPY_OK;
 }
@@ -862,7 +901,7 @@ int poppy_hip_pair_points(poppy_hip_ctx* c, float* p1, float* p2, int max_points
 
 int poppy_hip_timing_summary(poppy_hip_ctx* c, const char** names, float* total_ms, int* launches, int max) {
     if (!c) return 0;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    if (drain_frames(c) != POPPY_OK) return 0;
     int n = 0;
     for (size_t i = 1; i < c->marks_used; ++i) {
         const char* nm = c->marks[i].name;

@@ -1,0 +1,150 @@
+// warp_fast_device.h — the packed-arithmetic pieces shared by the two tiled warp kernels (kernels_warp_fast.hip: ids from the
+// id map; kernels_warp_bin.hip: ids rasterised in LDS).  The header comment of kernels_warp_fast.hip explains why each of them
+// returns the reference's bits.
+#pragma once
+#include "kernels.h"
+#include "warp_device.h"
+#include <hip/hip_ext.h>
+
+namespace poppy_hip {
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 div_core(f2 n, f2 d, f2 r1) {
+    f2 q0 = n * r1;
+    f2 s0 = __builtin_elementwise_fma(-d, q0, n);
+    f2 q1 = __builtin_elementwise_fma(s0, r1, q0);
+    f2 s1 = __builtin_elementwise_fma(-d, q1, n);
+    return __builtin_elementwise_fma(s1, r1, q1);
+}
+
+// (sx, sy) = cvRound(q * 32) for both coordinates; out-of-range values come back far outside any image
+__device__ __forceinline__ void to_fixed(f2 q, int& sx, int& sy) {
+    const f2 k32 = {32.f, 32.f};
+    f2 v = q * k32;
+    v.x = __builtin_amdgcn_fmed3f(v.x, -2097152.f, 2097152.f);
+    v.y = __builtin_amdgcn_fmed3f(v.y, -2097152.f, 2097152.f);
+    const f2 magic = {12582912.f, 12582912.f};
+    const f2 t = v + magic;
+    sx = __float_as_int(t.x) - 0x4B400000;
+    sy = __float_as_int(t.y) - 0x4B400000;
+}
+
+struct FastTap { uint32_t wt, wb, off; bool inside; };
+
+__device__ __forceinline__ FastTap make_fast_tap(int sx, int sy, int W, int H) {
+    FastTap t;
+    const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
+    t.inside = (unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1);
+    const uint32_t P = __umul24(fx, 65535u) + 32u;                 // (32 - fx) | fx << 16
+    t.wt = __umul24(P, (uint32_t)(1024 - (fy << 5)));              // w00 | w01 << 16
+    t.wb = __umul24(P, (uint32_t)(fy << 5));                       // w10 | w11 << 16
+    t.off = t.inside ? (uint32_t)(__umul24(iy, W) + ix) * 3u : 0u;
+    return t;
+}
+
+__device__ __forceinline__ uint32_t blend_fast(const FastTap& t, u2v a, u2v b) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 3) << 16);
+        const uint32_t pt = __builtin_amdgcn_perm(a.y, a.x, sel);                // s00 | s01 << 16
+        const uint32_t pb = __builtin_amdgcn_perm(b.y, b.x, sel);
+        uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pt), __builtin_bit_cast(us2, t.wt), 16384u, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pb), __builtin_bit_cast(us2, t.wb), acc, false);
+        out |= (acc >> 15) << (8 * k);
+    }
+    return out;
+}
+
+// raw buffer descriptor over [p, p + bytes): 32-bit offsets straight into the load instruction, no 64-bit address arithmetic
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// footprint on or over the image border: the byte-wise definition, from the record's matrix
+__device__ __forceinline__ uint32_t slow_pixel(const float* __restrict__ rec, int src, const uint8_t* __restrict__ img, int W, int H, int x, int y) {
+    float h[9];
+    if (src == 0) { h[0] = rec[0]; h[3] = rec[1]; h[1] = rec[2]; h[4] = rec[3]; h[2] = rec[4]; h[5] = rec[5]; }
+    else          { h[0] = rec[6]; h[3] = rec[7]; h[1] = rec[8]; h[4] = rec[9]; h[2] = rec[10]; h[5] = rec[11]; }
+    h[6] = rec[12 + src]; h[7] = rec[14 + src]; h[8] = rec[16 + src];
+    float mx, my;
+    map_point(h, x, y, mx, my);
+    uint8_t o[3];
+    sample3(img, W, H, mx, my, o);
+    return o[0] | (o[1] << 8) | (o[2] << 16);
+}
+
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+
+// Footprint fetch + bilinear blend + store of one thread's four pixels (both sources), given the eight taps; then the rare
+// byte-wise redo of pixels whose 2x2 footprint touches the image border.  rec_of(k) returns the record pointer of pixel k.
+template <typename RecOf>
+__device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amdgpu_buffer_rsrc_t rs1, __amdgpu_buffer_rsrc_t rs2,
+                                                       __amdgpu_buffer_rsrc_t ro1, __amdgpu_buffer_rsrc_t ro2, uint32_t pitch, uint32_t g,
+                                                       const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
+                                                       uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, int x0, int y, RecOf rec_of) {
+    u3v ra[2][4], rb[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint32_t o4 = t[im][k].off & ~3u;
+            ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
+            rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
+        }
+    }
+    uint32_t p[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint32_t bs = t[im][k].off & 3u;
+            const u3v a3 = ra[im][k], b3 = rb[im][k];
+            const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
+            const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
+            p[im][k] = blend_fast(t[im][k], a, b);
+        }
+    }
+    const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
+    const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
+    __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, g * 12u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, g * 12u, 0, 0);
+    uint32_t edges = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
+    if (__builtin_amdgcn_ballot_w64(edges != 0) != 0 && edges != 0) {
+        for (int e = 0; e < 8; ++e) {
+            if (!((edges >> e) & 1u)) continue;
+            const int k = e & 3, im = e >> 2;
+            const uint32_t v = slow_pixel(rec_of(k), im, im ? c2 : c1, W, H, x0 + k, y);
+            uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y * W + x0 + k) * 3;
+            dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+        }
+    }
+}
+
+// the eight taps of one pixel pair from its record (A..E as laid out by pack_warp_records)
+__device__ __forceinline__ void warp_taps(float4 A, float4 B, float4 C, float4 D, f2 E, float fx, float fy, int W, int H, FastTap& t0, FastTap& t1) {
+    const f2 fx2 = {fx, fx}, fy2 = {fy, fy}, one2 = {1.f, 1.f};
+    const f2 n1 = (f2{A.x, A.y} * fx2 + f2{A.z, A.w} * fy2) + f2{B.x, B.y};
+    const f2 n2 = (f2{B.z, B.w} * fx2 + f2{C.x, C.y} * fy2) + f2{C.z, C.w};
+    const f2 z = (f2{D.x, D.y} * fx2 + f2{D.z, D.w} * fy2) + f2{E.x, E.y};
+    const f2 r0 = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
+    const f2 e0 = __builtin_elementwise_fma(-z, r0, one2);
+    const f2 r1 = __builtin_elementwise_fma(e0, r0, r0);
+    const f2 q1 = div_core(n1, f2{z.x, z.x}, f2{r1.x, r1.x});
+    const f2 q2 = div_core(n2, f2{z.y, z.y}, f2{r1.y, r1.y});
+    int sx, sy;
+    to_fixed(q1, sx, sy);
+    t0 = make_fast_tap(sx, sy, W, H);
+    to_fixed(q2, sx, sy);
+    t1 = make_fast_tap(sx, sy, W, H);
+}
+
+}  // namespace
+}  // namespace poppy_hip

@@ -208,12 +208,17 @@ def test_two_pairs_concurrently_match_sequential():
 def test_warp_kernel_selection(ctx):
     """The tiled warp kernel takes frames whose width is a multiple of 4; other widths use the general kernel.
     Both are checked bit for bit against the oracle by the tests above; this one pins which ran."""
+    plain = capi.Context(0)                       # outside debug mode the raster is fused into the warp kernel (kind 2)
     for (w, h), kind in (((640, 360), 1), ((97, 61), 0)):
         c1 = synth.textured_bgr(w, h, 5); c2 = synth.textured_bgr(w, h, 6)
         g = synth.unit_field(w, h, 3)
         p1, p2 = synth.point_pairs(w, h, 12, seed=1, dup=0, oob=0)
-        ctx.morph_images(c1, c2, g, p1, p2, 0.5, 0.5)
+        a, _ = ctx.morph_images(c1, c2, g, p1, p2, 0.5, 0.5)
         assert ctx.last_warp_kind() == (kind and TILED)
+        b, _ = plain.morph_images(c1, c2, g, p1, p2, 0.5, 0.5)
+        assert plain.last_warp_kind() == (2 if kind and TILED and os.environ.get("POPPY_HIP_IDMAP") is None else (kind and TILED))
+        _same("fused vs id-map path", b, a)
+    plain.close()
 
 
 @pytest.mark.parametrize("w,h", [(640, 480), (1000, 96), (1920, 1080)])

@@ -1,7 +1,7 @@
 """Differential fuzz of the per-frame path: random sizes (all widths, so both warp kernels run), random point sets (with
 duplicates, points on the border, strong deformations), random ratios; every frame and its triangle map / warped sources
 against the oracle, bit for bit.   python tools/experiments/fuzz_frames.py [cases] [seed] [size scale] [nodebug]
-(nodebug: a context outside debug mode - frame-tagged id map, riding completion events - comparing frame and points only)"""
+(nodebug: a context outside debug mode - raster fused into the warp kernel, riding completion events - no triangle map to compare)"""
 import sys, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import oracle_lib as O
@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 nodebug = len(sys.argv) > 4 and sys.argv[4] == 'nodebug'
 ctx = capi.Context(0); ctx.set_debug(not nodebug)
-bad = 0; kinds = {0: 0, 1: 0}; t0 = time.time()
+bad = 0; kinds = {0: 0, 1: 0, 2: 0}; t0 = time.time()
 for i in range(cases):
     w = int(rng.integers(8, int(420 * scale))); h = int(rng.integers(6, int(300 * scale)))
     if rng.random() < 0.5: w = max(8, w & ~3)
@@ -50,12 +50,13 @@ for i in range(cases):
         print(f"case {i} {w}x{h} n={len(p1)} mode={mode}: library raised {e}"); bad += 1; continue
     kinds[ctx.last_warp_kind()] += 1
     checks = [("frame", got, want), ("points", gmp, wmp)]
+    checks += [("trImg1", ctx.fetch("trImg1"), d["trImg1"]), ("trImg2", ctx.fetch("trImg2"), d["trImg2"])]
     if not nodebug:
-        checks += [("triMap", ctx.fetch("triMap"), d["triMap"]), ("trImg1", ctx.fetch("trImg1"), d["trImg1"]), ("trImg2", ctx.fetch("trImg2"), d["trImg2"])]
+        checks += [("triMap", ctx.fetch("triMap"), d["triMap"])]
     for name, a, b in checks:
         av = a.view(np.uint32) if a.dtype == np.float32 else a
         bv = b.view(np.uint32) if b.dtype == np.float32 else b
         if a.shape != b.shape or (av != bv).any():
             print(f"case {i} {w}x{h} n={len(p1)} mode={mode} s={s:.3f}: {name} differs in {(av != bv).sum() if a.shape == b.shape else 'shape'}"); bad += 1; break
-print(f"{cases} cases, {bad} mismatches, kernels: general {kinds[0]}, tiled {kinds[1]}, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} mismatches, kernels: general {kinds[0]}, tiled on an id map {kinds[1]}, fused raster {kinds[2]}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
