@@ -176,3 +176,12 @@ def test_matcher_hypot_is_libm_hypotf():
     L = capi.lib()
     assert L.poppy_hypotf_selfcheck(2000000, 12345) == 0
     assert L.poppy_hypotf_selfcheck(500000, 999) == 0
+
+
+def test_shim_header_compiles_against_reference_headers():
+    """include/poppy_hip_shim.hpp, the binding a Poppy maintainer adds, syntax-checked against the vendored OpenCV headers and
+    Poppy's settings.hpp (only where the reference tree exists: this container)."""
+    import subprocess
+    if not (os.path.isdir("/root/reference/src") and os.path.exists("/tmp/ocv-build/opencv2/opencv_modules.hpp")):
+        pytest.skip("reference tree / OpenCV build tree not present")
+    subprocess.check_call([os.path.join(ROOT, "tools", "check_shim.sh")])
