@@ -587,137 +587,10 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
         for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
     }
 }
-// The same tail with one WAVE per plane instead of block-wide steps.  A pyrDown output only needs its own plane (the three
-// channels of L and of R and the mask are seven independent planes, the interleaved element index only picks the reference's
-// SIMD-body / scalar-tail association), and a collapse output only its own channel of L, R, B plus the mask.  So seven waves run
-// the whole down pass — wide levels, then the ~50 single-pixel levels on one lane — without a block barrier: writes and reads of a
-// level stay inside one wave, where LDS operations complete in issue order.  One barrier, the residuals of the single-pixel
-// levels on all lanes, one barrier, then three waves (one per channel) run the up pass the same way.  The block-wide version
-// spends ~1.8 us per tiny level in barriers and per-step set-up (27 us at 1080p); this one is bound by the dependent chains.
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
-constexpr int kTailPlaneThreads = 448;               // 7 waves
-
-__global__ void __launch_bounds__(kTailPlaneThreads) k_pyr_tail_planes(const float* __restrict__ gL, const float* __restrict__ gR,
-                                                                       const float* __restrict__ gM, float* __restrict__ gB,
-                                                                       const PyrLevel* __restrict__ glv, int first, int levels, int k1,
-                                                                       int n3, int n1) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    PyrLevel* lv = (PyrLevel*)lds;
-    float* sL = (float*)(lv + (levels + 1));
-    float* sR = sL + n3;
-    float* sB = sR + n3;
-    float* sM = sB + n3;
-    float* sRes = sM + n1;
-    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63;
-    const int wide_end = k1 < levels ? k1 : levels;
-    const int tab_end = wide_end + 1 < levels ? wide_end + 1 : levels;
-    for (int i = first + tid; i <= tab_end; i += nth) lv[i] = glv[i];
-    {
-        const PyrLevel f = glv[first];
-        const int c3 = f.w * f.h * 3, c1 = f.w * f.h;
-        for (int e = tid; e < c3; e += nth) { sL[e] = gL[f.off3 + e]; sR[e] = gR[f.off3 + e]; }
-        for (int e = tid; e < c1; e += nth) sM[e] = gM[f.off1 + e];
-    }
-    __syncthreads();
-    const size_t base3 = lv[first].off3, base1 = lv[first].off1;
-    const int nl = k1 < levels ? levels - k1 : 0;                // single-pixel reductions
-    const int o3k = k1 < levels ? (int)(lv[k1].off3 - base3) : 0, o1k = k1 < levels ? (int)(lv[k1].off1 - base1) : 0;
-
-    // ---- down: wave p owns plane p (0-2: L channel p, 3-5: R channel p-3, 6: mask) ----------------------------------------------
-    {
-        const int p = wave;
-        const bool is_mask = p == 6;
-        float* plane = is_mask ? sM : (p < 3 ? sL : sR);
-        const int ch = is_mask ? 0 : (p < 3 ? p : p - 3);
-        for (int i = first; i < wide_end; ++i) {
-            const PyrLevel s = lv[i], d = lv[i + 1];
-            const bool big = s.w >= 3 && s.h >= 3;
-            const int count = d.w * d.h;
-            const float invw = 1.f / (float)d.w;
-            if (is_mask) {
-                const DownGeom g1 = make_down_geom(s.w, s.h, 1);
-                const float* src = sM + (int)(s.off1 - base1);
-                float* dst = sM + (int)(d.off1 - base1);
-                for (int o = lane; o < count; o += 64) {
-                    const int y = div_small(o, d.w, invw), x = o - y * d.w;
-                    dst[o] = big ? pyrdown_elem_wide<false, 1>(src, g1, y, x) : pyrdown_elem<false>(src, g1, y, x);
-                }
-            } else {
-                const DownGeom g3 = make_down_geom(s.w, s.h, 3);
-                const float* src = plane + (int)(s.off3 - base3);
-                float* dst = plane + (int)(d.off3 - base3);
-                for (int o = lane; o < count; o += 64) {
-                    const int y = div_small(o, d.w, invw), x = o - y * d.w, xe = x * 3 + ch;
-                    dst[y * d.w * 3 + xe] = big ? pyrdown_elem_wide<false, 3>(src, g3, y, xe) : pyrdown_elem<false>(src, g3, y, xe);
-                }
-            }
-            wave_lds_fence();
-        }
-        if (nl && lane == 0) {                                   // the single-pixel levels: pyrDown of one pixel, over and over
-            float* chain = is_mask ? sM + o1k : plane + o3k + ch;
-            const int step = is_mask ? 1 : 3;
-            float v = chain[0];
-            int j = 1;
-            for (; j <= nl; ++j) {
-                const float nv = down_1x1(v);
-                chain[j * step] = nv;
-                if (__float_as_uint(nv) == __float_as_uint(v)) { ++j; break; }      // a fixed point: every deeper level is the same value
-                v = nv;
-            }
-            for (; j <= nl; ++j) chain[j * step] = v;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < nl * 3; e += nth) {                    // residual of single-pixel level k1 + e/3, channel e%3
-        const int j = e / 3;
-        const float lapL = sL[o3k + e] - up_1x1(sL[o3k + e + 3]), lapR = sR[o3k + e] - up_1x1(sR[o3k + e + 3]);
-        sRes[e] = mix_lr(lapL, lapR, sM[o1k + j]);
-    }
-    __syncthreads();
-    // ---- up: wave c owns channel c ------------------------------------------------------------------------------------------------
-    if (wave < 3) {
-        const int ch = wave;
-        if (nl) {
-            if (lane == 0) {
-                const int top = o3k + nl * 3 + ch;
-                float cur = mix_lr(sL[top], sR[top], sM[o1k + nl]);
-                sB[top] = cur;
-                float res = sRes[(nl - 1) * 3 + ch];
-                for (int j = nl - 1; j >= 0; --j) {
-                    const float nxt = sRes[(j > 0 ? j - 1 : 0) * 3 + ch];
-                    cur = up_1x1(cur) + res;
-                    sB[o3k + j * 3 + ch] = cur;
-                    res = nxt;
-                }
-            }
-        } else {
-            const PyrLevel t = lv[levels];
-            const int o3 = (int)(t.off3 - base3), o1 = (int)(t.off1 - base1);
-            for (int o = lane; o < t.w * t.h; o += 64) sB[o3 + o * 3 + ch] = mix_lr(sL[o3 + o * 3 + ch], sR[o3 + o * 3 + ch], sM[o1 + o]);
-        }
-        wave_lds_fence();
-        for (int i = wide_end - 1; i >= first; --i) {
-            const PyrLevel c = lv[i], n = lv[i + 1];
-            const int co3 = (int)(c.off3 - base3), no3 = (int)(n.off3 - base3), co1 = (int)(c.off1 - base1);
-            const bool big = n.w >= 2 && n.h >= 2;
-            const int count = c.w * c.h;
-            const float invw = 1.f / (float)c.w;
-            for (int o = lane; o < count; o += 64) {
-                const int y = div_small(o, c.w, invw), x = o - y * c.w, xe = x * 3 + ch;
-                sB[co3 + y * c.w * 3 + xe] =
-                    big ? collapse_elem_wide<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe)
-                        : collapse_elem<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe);
-            }
-            wave_lds_fence();
-        }
-    }
-    __syncthreads();
-    {
-        const PyrLevel f = lv[first];
-        for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
-    }
-}
+// (A variant with one WAVE per plane — the seven planes of the down pass and the three channels of the up pass are independent,
+// so their levels need no block barrier — was built and measured in round 2: bit-identical, but 9 us per frame SLOWER at 1080p:
+// a lone wave walks 8 outputs per lane of the 30 x 17 level at one instruction every few cycles, which costs more than the
+// barriers it saves.  tools/experiments/frames_only.py, profiles/r02_notes.md.)
 
 // The dynamic-LDS limit of a kernel is process state per device, not per context: it is only ever RAISED here, so a context
 // with a smaller geometry cannot lower it under a live one.  Call outside any stream capture.
@@ -729,7 +602,6 @@ bool prepare_pyr_tail(size_t lds_bytes) {
     std::lock_guard<std::mutex> lock(mu);
     if (lds_bytes <= granted[dev]) return true;
     if (hipFuncSetAttribute((const void*)k_pyr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void*)k_pyr_tail_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
     granted[dev] = lds_bytes;
     return true;
 }
@@ -750,9 +622,7 @@ size_t pyr_tail_lds_bytes(int levels, int n3, int n1) {
 void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
                      int k1, int n3, int n1, hipStream_t s) {
     const size_t lds = pyr_tail_lds_bytes(levels, n3, n1);
-    static const bool block_wide = getenv("POPPY_HIP_OLDTAIL") != nullptr;
-    if (block_wide) hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(kTailThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
-    else hipLaunchKernelGGL(k_pyr_tail_planes, dim3(1), dim3(kTailPlaneThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
+    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(kTailThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
 }
 
 // ------------------------------------------------------------------------------------------------

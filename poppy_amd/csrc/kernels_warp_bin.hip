@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
     constexpr int kChunk = 32;                                   // entries whose row masks are staged in LDS per pass: 32 x 128 bytes
     __shared__ float4 s_rec[(kCached + 1) * 5];
     __shared__ __attribute__((aligned(16))) uint64_t s_mask[kChunk * 16];
+    __shared__ u4v s_ids[256];
 
     const int tid = threadIdx.x;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -192,6 +193,8 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), make_rsrc(ex.mask, npx * 4u), g * 16u, 0, 0);
     }
     if (!active) return;
+    // the ids are only needed again by the rare border path: parked in LDS so that they do not count against the footprint phase
+    s_ids[tid] = u4v{(unsigned)id[0], (unsigned)id[1], (unsigned)id[2], (unsigned)id[3]};
 
     const float fy = (float)y;
     FastTap t[2][4];
@@ -214,7 +217,9 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
         warp_taps(A, B, C, D, E, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
     }
     warp_fetch_blend_store(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {
-        return id[k] ? (const float*)(tile_data + (size_t)(off0 + id[k] - 1) * kEntryBytes + kEntryMaskBytes) : (const float*)rec;
+        const u4v ids = s_ids[tid];
+        const unsigned e = k == 0 ? ids.x : k == 1 ? ids.y : k == 2 ? ids.z : ids.w;
+        return e ? (const float*)(tile_data + (size_t)(off0 + (int)e - 1) * kEntryBytes + kEntryMaskBytes) : (const float*)rec;
     });
 }
 
