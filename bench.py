@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
     ap.add_argument("--contexts", type=int, default=2, help="contexts (host threads) the step's pairs are spread over at N = 1")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
@@ -295,7 +296,7 @@ def bench_single(args, torch, capi, dev, local):
 
     def phase_step():
         ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
-        return ctx.morph_frames_counted(0.0) + ctx.render_many_counted(ph[1:], chain=False)   # frame 0 (t = 0) is a copy of image 1 (src/poppy.hpp:54-62)
+        return ctx.render_phases(ph, counted=True)        # frame 0 (t = 0) is a copy of image 1 (src/poppy.hpp:54-62)
     phase_step()
     t1 = time.perf_counter()
     for _ in range(reps):
@@ -358,11 +359,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
         if rank == 0:
             ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
         link.broadcast(root=0)
-        n = 0
-        for t in ts[:1]:
-            if t == 0.0:                      # global frame 0: the reference's phase == 0 short-circuit, a copy of image 1
-                n += ctx.morph_frames_counted(0.0)
-        return n + ctx.render_many_counted(ts[1:] if ts[0] == 0.0 else ts, chain=False)
+        return ctx.render_phases(ts, counted=True)        # global frame 0 (t = 0) is the reference's phase == 0 short-circuit: a copy of image 1
 
     def fence():
         ctx.sync(); torch.cuda.synchronize()
@@ -388,6 +385,24 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
         ctx.render_many(ts[1:] if ts[0] == 0.0 else ts, chain=False)
     fence()
     dt_f = link.max_time(time.perf_counter() - t1)
+    # configs[4]: independent pairs spread over the GPUs (8 per GPU: 64 pairs on 8), each a whole chained poppy::morph from the raw
+    # images, handed out to two contexts per GPU by the library's pool; no communication at all
+    ppg = args.pairs_per_gpu
+    mine = sharding.pair_range(rank, world, ppg * world)
+    pool = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
+    dev_pairs = [tuple(torch.from_numpy(x).to(dev) for x in synth_pair(W, H, k)) for k in mine]
+    ptrs = [(a_.data_ptr(), b_.data_ptr()) for a_, b_ in dev_pairs]
+    pool.morph_pairs_device_counted(ptrs[:2], W, H, -1.0)
+    fence()
+    t2 = time.perf_counter()
+    reps = max(1, args.steps // 4)
+    nfr = 0
+    for _ in range(reps):
+        nfr += pool.morph_pairs_device_counted(ptrs, W, H, -1.0)
+    fence()
+    dt_p = link.max_time(time.perf_counter() - t2)
+    pool.close()
+    assert nfr == reps * len(ptrs) * FRAMES
     out = None
     if rank == 0:
         fps = args.steps * total / dt_max
@@ -402,6 +417,11 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
                        "frames_per_gpu": FRAMES, "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
                        "broadcast_bytes": link.nbytes},
             "frames_only_fps": round(args.steps * total / dt_f, 1),
+            "cfg4_note": "value = configs[3] (one %d-frame morph sharded by frame range)" % total,
+            "cfg5_pairs": {"workload": f"BASELINE.json configs[4]: {ppg * world} independent {W}x{H} pairs x {FRAMES} chained frames, {ppg} pairs per GPU on "
+                                       f"{args.contexts} contexts each, set-up from the raw images and the writer hand-off included, no communication",
+                           "value": round(reps * ppg * world * FRAMES / dt_p, 2), "unit": "frames/s", "pairs": ppg * world, "steps": reps,
+                           "ms_per_step": round(dt_p / reps * 1e3, 3), "scaling_baseline": "the `value` of the --gpus 1 line (same per-GPU work)"},
             "scaling_note": "read against `scaling_baseline.fps` (with set-up) or `scaling_baseline.frames_only_fps` of the --gpus 1 line, not against its chained `value`",
         }
     ctx.close()

@@ -306,6 +306,11 @@ int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_de
                           int width, int height, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
                           char* err, size_t err_len);
 
+/* n frames of the sharded job on the resident pair: frame k = morph(img1, img2, .., phase = t[k]) with number_of_frames = 1, i.e. a
+ * copy of image 1 / image 2 for t == 0 / t == 1 (src/poppy.hpp:54-70) and an independent phase-mode frame otherwise.  What a rank
+ * renders for its frame range t_j = j / total (poppy_hip_morph_sharded does the same internally).                              */
+int poppy_hip_render_phases(poppy_hip_ctx* ctx, const double* t, int n, poppy_write_cb write, void* user);
+
 /* No-match fallback  img2*phase + img1*(1-phase)  (src/poppy.hpp:125-134; u8 addWeighted,
  * OCV/core/src/arithm.simd.hpp:1705-1755).                                                          */
 int poppy_hip_dissolve(poppy_hip_ctx* ctx, const uint8_t* img1, size_t stride1, const uint8_t* img2, size_t stride2,

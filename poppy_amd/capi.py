@@ -31,7 +31,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -103,6 +103,7 @@ def lib():
         L.poppy_hip_pool_create.restype = C.c_void_p
         L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
         L.poppy_hip_pool_destroy.argtypes = [vp]
+        L.poppy_hip_render_phases.argtypes = [vp, vp, i, vp, vp]
         L.poppy_hip_pool_set_timing.argtypes = [vp, i]
         L.poppy_hip_pool_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_pool_warp_counts.argtypes = [vp, vp, vp, vp]
@@ -499,6 +500,21 @@ class Context:
         cb = C.cast(lib().poppy_count_frames_cb, C.c_void_p)
         self._chk(lib().poppy_hip_morph_frames(self.h, phase, cb, C.cast(C.byref(n), C.c_void_p)), "morph_frames")
         return n.value
+
+    def render_phases(self, ts, write=None, counted=False):
+        """Frames of the sharded job: phase t_k each (t == 0 / 1: copies of image 1 / 2).  counted: frames go to the library's
+        counting writer and the count is returned."""
+        t = np.ascontiguousarray(ts, np.float64)
+        if counted:
+            n = C.c_longlong(0)
+            self._chk(lib().poppy_hip_render_phases(self.h, _p(t), len(t), C.cast(lib().poppy_count_frames_cb, C.c_void_p), C.cast(C.byref(n), C.c_void_p)), "render_phases")
+            return n.value
+        fn = None
+        if write is not None:
+            def cb(user, ptr, w, h, stride):
+                write(np.ctypeslib.as_array(ptr, shape=(h, stride))[:, :w * 3].reshape(h, w, 3))
+            fn = WRITE_CB(cb)
+        self._chk(lib().poppy_hip_render_phases(self.h, _p(t), len(t), C.cast(fn, C.c_void_p) if fn else None, None), "render_phases")
 
     def render_many_counted(self, shapes, chain=False):
         sh = np.ascontiguousarray(shapes, np.float64)

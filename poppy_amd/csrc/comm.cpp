@@ -214,16 +214,9 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
                 Relay* r = (Relay*)u;
                 r->write(r->user, r->base++, bgr, w, h, stride);
             } : (poppy_write_cb) nullptr;
-            int first = lo;
-            if (lo == 0) {                              // t_0 = 0: the phase == 0 short-circuit (src/poppy.hpp:54-62)
-                rc = poppy_hip_morph_frames(c, 0.0, cb, &relay);
-                first = 1;
-            }
-            if (rc == POPPY_OK && hi > first) {
-                std::vector<double> t(hi - first);
-                for (int j = first; j < hi; ++j) t[j - first] = (double)j / (double)total_frames;
-                rc = poppy_hip_render_many(c, t.data(), t.data(), hi - first, 0, cb, &relay);
-            }
+            std::vector<double> t(hi - lo);
+            for (int j = lo; j < hi; ++j) t[j - lo] = (double)j / (double)total_frames;      // t_0 = 0: a copy of image 1 (src/poppy.hpp:54-62)
+            rc = poppy_hip_render_phases(c, t.data(), hi - lo, cb, &relay);
         }
         rcs[k] = rc;
     };

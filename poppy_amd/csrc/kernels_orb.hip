@@ -137,10 +137,18 @@ __global__ void __launch_bounds__(256) k_fast_nms(const uint8_t* __restrict__ sc
     if (x < edge || x >= L.w - edge || y < edge || y >= L.h - edge) return;
     const uint8_t* p = scores + L.score_offset + (size_t)y * L.w + x;
     int s = p[0];
-    if (s == 0) return;
     int W = L.w;
-    if (s > p[-1] && s > p[1] && s > p[-W - 1] && s > p[-W] && s > p[-W + 1] && s > p[W - 1] && s > p[W] && s > p[W + 1]) {
-        int slot = atomicAdd(&counters[lvl], 1);
+    const bool keep = s != 0 && s > p[-1] && s > p[1] && s > p[-W - 1] && s > p[-W] && s > p[-W + 1] && s > p[W - 1] && s > p[W] && s > p[W + 1];
+    // one atomic per WAVE: the survivors of a wave take consecutive slots (the order inside a level is restored on the host anyway);
+    // ~10^5 survivors per image on one counter were the whole kernel (363 us at 1080p)
+    const unsigned long long vote = __builtin_amdgcn_ballot_w64(keep);
+    if (vote == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(vote)) base = atomicAdd(&counters[lvl], __builtin_popcountll(vote));
+    base = __shfl(base, __builtin_ctzll(vote));
+    if (keep) {
+        const int slot = base + __builtin_popcountll(vote & ((1ull << lane) - 1ull));
         if (slot < cap) { cand[((size_t)lvl * cap + slot) * 2] = y * W + x; cand[((size_t)lvl * cap + slot) * 2 + 1] = s; }
     }
 }

@@ -300,7 +300,7 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
     // serial instruction stream and 35 KB of LDS limits a CU to 4 of them, so the time is that of ONE segment as long as
     // there are no more than ~1000: aim for that many, never shorter than ksize / 2 rows.
     const int col_blocks = (w + kMedLanes - 1) / kMedLanes;
-    int segs = std::max(1, 1024 / col_blocks);
+    int segs = std::max(1, 1024 / col_blocks);              // (512 .. 1024 waves per launch measured the same, fewer slower: profiles/r02_notes.md)
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
     const int ndw = (ksize + 3) >> 2;

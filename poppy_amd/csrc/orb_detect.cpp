@@ -82,11 +82,12 @@ hipError_t OrbDetector::prepare(int w, int h) {
 
 #define ORB_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
 
-int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out) {
+int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out,
+                        bool gray_on_device) {
     out.clear();
     ORB_CHK(prepare(w, h));
     const int edge = 31, patch = 31, fastThreshold = 20;
-    ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, hipMemcpyHostToDevice, s));
+    ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, gray_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
     ORB_CHK(hipMemsetAsync(d_counters, 0, kOrbLevels * sizeof(int), s));
     launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, s);

@@ -12,7 +12,8 @@ class OrbDetector {
 public:
     ~OrbDetector() { release(); }
     // ORB::create(nfeatures)->detect(gray): host image in, keypoints (order significant) out.  <0 on error (see err).
-    int detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out);
+    int detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out,
+               bool gray_on_device = false);   // gray_on_device: `gray` is a device pointer of this GPU (no host round trip)
     // ORB::compute: 32 bytes per keypoint (kps7 rows in cv::KeyPoint field order); returns n or <0
     int describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out);
     // BFMatcher(NORM_HAMMING).match on 32-byte descriptors: out3 rows (queryIdx, trainIdx, distance)

@@ -184,7 +184,9 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
         rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
     }
-    std::vector<uint8_t> g[2] = {std::vector<uint8_t>(P), std::vector<uint8_t>(P)};
+    std::vector<uint8_t> g[2];
+    if (ratio >= 0.f) { g[0].resize(P); g[1].resize(P); }
+    const uint8_t* g_dev[2] = {nullptr, nullptr};
     double d[2] = {0, 0};
     if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamSynchronize(c->stream));                         // the uploads above
@@ -204,7 +206,8 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-        hipError_t e = hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st);
+        g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
+        hipError_t e = ratio >= 0.f ? hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st) : hipSuccess;
         if (e == hipSuccess && i == 1 && !align_first) {
             const float* gab = fg.gabor_field(c->c2, W, H, st);
             if (!gab) { errs[i] = "gabor_field: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
@@ -226,8 +229,8 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     std::vector<OrbKeyPoint> k1, k2;
     {   // the two detections are independent too
         int r1 = 0, r2 = 0;
-        std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g[1].data(), W, W, H, nfeatures, c->aux_stream, k2) : -2; });
-        r1 = c->orb.detect(g[0].data(), W, W, H, nfeatures, c->stream, k1);
+        std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g_dev[1], W, W, H, nfeatures, c->aux_stream, k2, true) : -2; });
+        r1 = c->orb.detect(g_dev[0], W, W, H, nfeatures, c->stream, k1, true);
         other.join();
         if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }

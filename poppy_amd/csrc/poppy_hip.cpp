@@ -772,6 +772,32 @@ int poppy_hip_morph_frames(poppy_hip_ctx* c, double phase, poppy_write_cb write,
     return render_sequence(c, ratio.data(), ratio.data(), n, true, write, user);
 }
 
+int poppy_hip_render_phases(poppy_hip_ctx* c, const double* t, int n, poppy_write_cb write, void* user) {
+    if (!c || (n > 0 && !t) || n < 0) return POPPY_E_ARG;
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t row = (size_t)c->W * 3;
+    for (int i = 0; i < n;) {
+        if (t[i] == 0 || t[i] == 1) {                             // a plain copy of image 1 / image 2
+            if (write) {
+                int rc = stage_host(c, row * c->H); if (rc) return rc;
+                const uint8_t* img = t[i] == 0 ? c->c1 : (c->c2_raw_valid ? c->c2_raw : c->c2);
+                HIPCHK(c, hipMemcpyAsync(c->h_stage, img, row * c->H, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                write(user, c->h_stage, c->W, c->H, row);
+            }
+            ++i;
+            continue;
+        }
+        int j = i;
+        while (j < n && t[j] != 0 && t[j] != 1) ++j;
+        { int rc = poppy_hip_pair_reset(c); if (rc) return rc; }
+        int rc = render_sequence(c, t + i, t + i, j - i, false, write, user); if (rc) return rc;
+        i = j;
+    }
+    return POPPY_OK;
+}
+
 int poppy_printed_morph_distance(const float* p1, const float* p2, int n, int W, int H, double* out) {
     if (n < 1 || !p1 || !p2 || !out || W <= 0 || H <= 0) return POPPY_E_ARG;
     std::vector<P2f> a(n), b(n), u1, u2;

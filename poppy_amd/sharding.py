@@ -1,7 +1,8 @@
 """Frame-range sharding of one phase-mode morph across the ranks of a node (BASELINE.json configs[3]).
 
 The job is ONE morph of `frames_per_rank * world` frames with phase t_j = j / total; frame j equals the reference call
-morph(img1, img2, ..., phase = t_j) with number_of_frames = 1 (src/poppy.hpp:177-210,234-235), so frames are
+morph(img1, img2, ..., phase = t_j) with number_of_frames = 1 (src/poppy.hpp:177-210,234-235; t_0 = 0 takes the phase == 0
+short-circuit of :54-62 and is a copy of image 1: poppy_hip_render_phases), so frames are
 independent and rank r renders the contiguous range [r * frames_per_rank, (r + 1) * frames_per_rank).  The only
 exchange is one broadcast of the pair (sources, mask field, point sets) from rank 0; there is no data-path
 collective afterwards.  Default (chained) mode cannot be sharded: frame j warps frame j-1 (src/poppy.hpp:217).
@@ -22,6 +23,16 @@ def phase_schedule(rank, world, frames_per_rank):
     """shape = mask ratio of every frame of `rank`: t_j = j / (frames_per_rank * world), float64 as the reference's."""
     total = float(frames_per_rank * world)
     return np.array([j / total for j in frame_range(rank, world, frames_per_rank)], dtype=np.float64)
+
+
+def pair_range(rank, world, n_pairs):
+    """Pairs rendered by `rank` when n_pairs independent pairs are split over the ranks (BASELINE.json configs[4]: 64 pairs over 8
+    GPUs): contiguous, disjoint, complete; the first n_pairs % world ranks take one more."""
+    if not (0 <= rank < world) or n_pairs < 0:
+        raise ValueError("bad rank / world / n_pairs")
+    base, extra = divmod(n_pairs, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
 
 
 def pair_tensors(torch, device, w, h, n_points, host_inputs=None):

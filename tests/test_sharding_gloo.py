@@ -98,6 +98,31 @@ def test_two_ranks_gloo():
     assert plans == [_plan_digest(p1, p2, s) for s in sharding.phase_schedule(0, 1, total)]
 
 
+def test_pair_partition():
+    """configs[4]: independent pairs over ranks — contiguous, disjoint, complete, balanced to within one pair."""
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 64, 65):
+            seen, sizes = [], []
+            for r in range(world):
+                pr = list(sharding.pair_range(r, world, n))
+                seen += pr; sizes.append(len(pr))
+            assert seen == list(range(n))
+            assert max(sizes) - min(sizes) <= 1
+    assert list(sharding.pair_range(3, 8, 64)) == list(range(24, 32))
+    with pytest.raises(ValueError):
+        sharding.pair_range(8, 8, 64)
+
+
+def test_frame_zero_of_the_sharded_job_is_the_phase_zero_shortcut():
+    """Global frame 0 has t = 0: only rank 0 holds it, and the scheduler the library applies to a phase-mode call with phase 0 < t < 1
+    never yields it (the reference short-circuits phase == 0 before any rendering, src/poppy.hpp:54-62)."""
+    for world in (1, 2, 8):
+        for r in range(world):
+            ts = sharding.phase_schedule(r, world, 60)
+            assert (ts[0] == 0.0) == (r == 0)
+            assert (ts[1:] > 0).all() and (ts < 1).all()
+
+
 def test_partition_properties():
     for world in (1, 2, 4, 8):
         seen = []

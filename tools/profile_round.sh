@@ -1,20 +1,20 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence on the GPU box: kernel trace + stats of the bench command, and the two
-# HBM-traffic counter passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).  Usage:
-#   gpurun -- bash tools/profile_round.sh <tag>         ->  gpurun_out/<tag>_{trace,fetch,write}[_4k]/
-tag=${1:-r01_l}
+# Collects the round's rocprofv3 evidence on the GPU box: kernel trace + stats of the bench command, of the chained frame loop at
+# 1080p and 4K and of the pair set-up, and the two HBM-traffic counter passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on
+# gfx950; counter passes run with --pmc only).  Usage:  gpurun -- bash tools/profile_round.sh <tag>   ->  gpurun_out/<tag>_*/
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only"
-K4="--width 3840 --height 2160 --frames 20"
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace -o t -- $B > gpurun_out/${tag}_trace.json 2> gpurun_out/${tag}_trace.log
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -o f -- $B > /dev/null 2> gpurun_out/${tag}_fetch.log
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_write -o w -- $B > /dev/null 2> gpurun_out/${tag}_write.log
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace_4k -o t -- $B $K4 > gpurun_out/${tag}_trace_4k.json 2> gpurun_out/${tag}_trace_4k.log
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch_4k -o f -- $B $K4 > /dev/null 2> gpurun_out/${tag}_fetch_4k.log
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_write_4k -o w -- $B $K4 > /dev/null 2> gpurun_out/${tag}_write_4k.log
-# pair set-up (poppy_hip_pair_begin from raw BGR), three calls: kernel trace of the filter chain, ORB and matcher launches
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_setup_trace -o t -- python3 tools/experiments/pair_begin_time.py > gpurun_out/${tag}_setup.log 2>&1
-python3 bench.py --steps 10 --warmup 3 > gpurun_out/${tag}_bench.json
-python3 bench.py --steps 5 --warmup 2 $K4 --no-cpu-baseline > gpurun_out/${tag}_bench_4k.json
-ls -la gpurun_out/${tag}_*
+R="$GRAFT_REPO_ROOT"
+B="python3 $R/bench.py --steps 4 --warmup 1 --headline-only"
+F="python3 $R/tools/experiments/frames_only.py"
+O="$R/gpurun_out"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/${tag}_bench_trace -o t -- $B > $O/${tag}_bench_trace.json 2> $O/${tag}_bench_trace.log
+for sz in "1920 1080" "3840 2160"; do set -- $sz
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/${tag}_chain_$1 -o t -- $F $1 $2 60 chain 3 > $O/${tag}_chain_$1.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_fetch_$1 -o f -- $F $1 $2 60 chain 1 > /dev/null 2> $O/${tag}_fetch_$1.log
+  timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write_$1 -o w -- $F $1 $2 60 chain 1 > /dev/null 2> $O/${tag}_write_$1.log
+done
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/${tag}_setup_trace -o t -- python3 $R/tools/experiments/pair_begin_time.py > $O/${tag}_setup.log 2>&1
+cd "$R"
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+ls gpurun_out | grep "^${tag}_"
