@@ -63,6 +63,25 @@ def synth_pair(w, h, k):
     return synth.gen_pair(w, h, seed=1234 + k)
 
 
+def measured_traffic(kernel, w, h):
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_warp_pmc.json) — only when those passes were
+    taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
+    import hashlib
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
+        hsh = hashlib.sha256()
+        for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
+            hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
+        if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
+            return None, "profiles/r02_warp_pmc.json was taken from other kernel sources: not quoted"
+        e = pm.get(f"{w}x{h}", {}).get(kernel)
+        if not e:
+            return None, "no counter pass for this kernel / size in profiles/r02_warp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_k_pmc.md)"
+    except (OSError, ValueError, KeyError):
+        return None, "profiles/r02_warp_pmc.json missing"
+
+
 def roofline_of(ctx, warp_ms, warp_n, w, h):
     per_launch_ms = warp_ms / max(warp_n, 1)
     P = w * h
@@ -75,7 +94,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
             "achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
             "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
-            "traffic": None, "traffic_note": "PMC passes cannot run inside the bench; see profiles/ for the counter passes of this command"}
+            **dict(zip(("traffic", "traffic_source"), measured_traffic(ctx.warp_kernel_name(), w, h)))}
 
 
 def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):

@@ -1,5 +1,6 @@
-import sys, time, numpy as np
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root
+import os, sys, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from poppy_amd import capi, synth
 for (w,h) in [(1920,1080)]:
     a,b = synth.gen_pair(w,h)
