@@ -306,6 +306,16 @@ int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_de
                           int width, int height, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
                           char* err, size_t err_len);
 
+/* File sinks for the frame hand-off, host only, no codec library: poppy_sink_write has the poppy_write_cb signature
+ * (user = the sink), so  poppy_hip_morph(ctx, .., poppy_sink_write, sink, ..)  writes the sequence to disk.  RAW: one file, BGR rows back
+ * to back; PPM: one P6 file per frame, `path` is a printf pattern with one %d; Y4M: one YUV4MPEG2 file, C444, full-range BT.601.
+ * poppy_sink_close returns the number of frames written, or a negative status if a write failed or a frame had another geometry.   */
+typedef struct poppy_sink poppy_sink;
+enum { POPPY_SINK_RAW = 0, POPPY_SINK_PPM = 1, POPPY_SINK_Y4M = 2 };
+poppy_sink* poppy_sink_open(const char* path, int format, int width, int height, int fps_num, int fps_den);
+void poppy_sink_write(void* sink, const uint8_t* bgr, int width, int height, size_t stride);
+int poppy_sink_close(poppy_sink* sink);
+
 /* n frames of the sharded job on the resident pair: frame k = morph(img1, img2, .., phase = t[k]) with number_of_frames = 1, i.e. a
  * copy of image 1 / image 2 for t == 0 / t == 1 (src/poppy.hpp:54-70) and an independent phase-mode frame otherwise.  What a rank
  * renders for its frame range t_j = j / total (poppy_hip_morph_sharded does the same internally).                              */

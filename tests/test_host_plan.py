@@ -185,3 +185,36 @@ def test_shim_header_compiles_against_reference_headers():
     if not (os.path.isdir("/root/reference/src") and os.path.exists("/tmp/ocv-build/opencv2/opencv_modules.hpp")):
         pytest.skip("reference tree / OpenCV build tree not present")
     subprocess.check_call([os.path.join(ROOT, "tools", "check_shim.sh")])
+
+
+def test_file_sinks(tmp_path):
+    """poppy_sink_* (raw / PPM / Y4M writers with the poppy_write_cb signature): written files parse back to the frames."""
+    from poppy_amd import synth
+    L = capi.lib()
+    w, h = 37, 21
+    frames = [synth.textured_bgr(w, h, 5 + k) for k in range(3)]
+    padded = [np.ascontiguousarray(np.pad(f, ((0, 0), (0, 5), (0, 0)))) for f in frames]          # a row stride larger than w*3
+    raw = tmp_path / "out.bgr"; ppm = str(tmp_path / "f%03d.ppm"); y4m = tmp_path / "out.y4m"
+    for path, fmt in ((str(raw), 0), (ppm, 1), (str(y4m), 2)):
+        s = L.poppy_sink_open(path.encode(), fmt, w, h, 30, 1)
+        assert s
+        for f in padded:
+            L.poppy_sink_write(s, f.ctypes.data, w, h, f.strides[0])
+        assert L.poppy_sink_close(s) == 3
+    assert np.array_equal(np.fromfile(raw, np.uint8).reshape(3, h, w, 3), np.stack(frames))
+    for k in range(3):
+        data = open(ppm % k, "rb").read()
+        head = b"P6\n%d %d\n255\n" % (w, h)
+        assert data.startswith(head)
+        rgb = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
+        assert np.array_equal(rgb[..., ::-1], frames[k])
+    data = open(y4m, "rb").read()
+    assert data.startswith(b"YUV4MPEG2 W37 H21 F30:1") and data.count(b"FRAME\n") == 3
+    body = data[data.index(b"\n") + 1:]
+    yplane = np.frombuffer(body[6:6 + w * h], np.uint8).reshape(h, w)
+    f0 = frames[0].astype(np.int64)
+    assert np.array_equal(yplane, (19595 * f0[..., 2] + 38470 * f0[..., 1] + 7471 * f0[..., 0] + 32768) >> 16)
+    # a frame of another geometry poisons the sink
+    s = L.poppy_sink_open(str(raw).encode(), 0, w, h, 30, 1)
+    L.poppy_sink_write(s, padded[0].ctypes.data, w + 1, h, padded[0].strides[0])
+    assert L.poppy_sink_close(s) < 0
