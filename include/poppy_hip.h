@@ -338,6 +338,10 @@ int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
 int poppy_hip_last_warp_kind(poppy_hip_ctx* ctx);
 /* frames rendered by each of the three since the context was created */
 int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general);
+/* 1 when the warp kernel of this pair also writes the blend mask (lbmask = clamp((1 - mr) - m2 * mr), src/algo.cpp:262-263) beside the
+ * two warped images, 0 when the level-0 blend kernels compute it from the pair's m2 field on the values they load (the normal case:
+ * 8 B/px per frame less; POPPY_HIP_LBMASK_RIDER=1 or a geometry the wide blend kernels do not take select the former).           */
+int poppy_hip_mask_rider(poppy_hip_ctx* ctx);
 int poppy_hip_debug_fetch(poppy_hip_ctx* ctx, const char* name, void* host_dst, size_t bytes);
 int poppy_hip_debug_triangles(poppy_hip_ctx* ctx, int* n_tris, int* idx3, float* M1, float* M2, int max_tris);
 

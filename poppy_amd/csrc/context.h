@@ -45,7 +45,8 @@ struct FrameSlot {
     hipEvent_t downloaded = nullptr;                // completes when the last download of this slot's `out` towards the writer has read it
     bool dl_pending = false;                        // ... and whether such a download was issued since the slot was last rendered into
 };
-constexpr size_t kBlobHeader = 64;
+constexpr size_t kBlobHeader = 64;            // [0] float: unsharp amount; [16], [24] double: the frame's mask (alpha, beta)
+constexpr size_t kBlobMaskAB = 16;
 
 struct poppy_hip_ctx {
     int device = 0;
@@ -103,6 +104,7 @@ struct poppy_hip_ctx {
     double last_detail[2] = {0, 0};
     // diagnostics
     bool debug = false;
+    bool lazy_mask = false;                     // the level-0 blend kernels compute lbmask from m2; the warp kernel does not write it
     int timing = 0;                      // 0 off, 1 every kernel group (direct launches), 2 the warp kernel only
     struct Mark { const char* name; hipEvent_t ev; };   // name == nullptr opens a frame
     std::vector<Mark> marks; size_t marks_used = 0;

@@ -65,19 +65,24 @@ void launch_warp_bin(const float* records, const void* tile_data, size_t tile_da
 
 // one Gaussian-pyramid reduction step for L, R (3 channels) and the mask (1 channel) in one launch.
 // level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
+// mask_ab (level 0 only, frames whose geometry pyr_level0_vec_ok admits): srcM is the pair's m2 field and mask_ab points to this
+// frame's (alpha, beta) in device memory — the kernel computes lbmask = clamp(alpha + m2 * beta) on the values it loads.
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s);
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr);
 
 // one collapse step: B_i = pyrUp(B_{i+1}) + mix(G_i - pyrUp(G_{i+1}))   (src/blend.hpp:58-77)
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
                      const float* nL, const float* nR, const float* nB, float* outB,
-                     int w, int h, int nw, int nh, hipStream_t s);
+                     int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr);
+bool pyr_level0_vec_ok(int w, int h);
+// lbmask = clamp(alpha + m2 * beta) as an array (debug fetches of frames that did not materialise it)
+void launch_lbmask(const float* m2, const double* mask_ab, float* dst, size_t n, hipStream_t s);
 
 // wide-access forms (kernels_pyramid_vec.hip); return false when the level's geometry does not allow them
 bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s);
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr);
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                         float* outB, int w, int h, int nw, int nh, hipStream_t s);
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr);
 
 // all remaining (small) levels in one workgroup: reductions down to level `levels`, the smallest-level
 // mix and the collapse back up to level `first`; writes B_first.

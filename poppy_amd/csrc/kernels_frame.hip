@@ -377,8 +377,9 @@ static void launch_pyrdown_v(const void* srcL, const void* srcR, const float* sr
     hipLaunchKernelGGL((k_pyrdown<U8, V>), grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
 }
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
-    if (launch_pyrdown_vec(srcL, srcR, srcM, src_u8, dstL, dstR, dstM, sw, sh, s)) return;
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab) {
+    if (launch_pyrdown_vec(srcL, srcR, srcM, src_u8, dstL, dstR, dstM, sw, sh, s, mask_ab)) return;
+    if (mask_ab) abort();                      // the caller asks for the m2 form only where pyr_level0_vec_ok holds
     DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
     // taller strips share more row sums but leave fewer threads: only worth it when the level is large
     const size_t outputs = (size_t)g3.dw * g3.dh * 3;
@@ -453,11 +454,20 @@ __global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, c
     }
 }
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                     float* outB, int w, int h, int nw, int nh, hipStream_t s) {
-    if (launch_collapse_vec(gL, gR, g_u8, gM, nL, nR, nB, outB, w, h, nw, nh, s)) return;
+                     float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab) {
+    if (launch_collapse_vec(gL, gR, g_u8, gM, nL, nR, nB, outB, w, h, nw, nh, s, mask_ab)) return;
+    if (mask_ab) abort();
     dim3 grid((nw * 3 + 255) / 256, nh);
     if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
     else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+}
+
+__global__ void k_lbmask(const float* __restrict__ m2, const double* __restrict__ ab, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = mask_value(m2[i], ab[0], ab[1]);
+}
+void launch_lbmask(const float* m2, const double* mask_ab, float* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_lbmask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m2, mask_ab, dst, n);
 }
 
 // --- all small levels in one workgroup, staged in LDS ---------------------------------------------

@@ -36,28 +36,28 @@ __host__ __device__ inline int border_count(int w, int h, int x0, int x1, int y0
 }
 
 // one thread per border ELEMENT (7 per pixel for pyrDown: 3 + 3 + mask; 3 per pixel for the collapse)
-template <bool U8>
+template <bool U8, typename F>
 __device__ __forceinline__ void pyrdown_border_body(int block, const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
                                                     float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
-                                                    const DownGeom& g3, const DownGeom& g1, int x0, int x1, int y0, int y1) {
+                                                    const DownGeom& g3, const DownGeom& g1, int x0, int x1, int y0, int y1, F fn) {
     const int i = block * 256 + threadIdx.y * 64 + threadIdx.x;
     const int pix = i / 7, k = i - pix * 7;
     int x, y;
     if (!border_pixel(pix, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
     if (k < 3)      dstL[((size_t)y * g3.dw + x) * 3 + k] = pyrdown_elem_wide<U8, 3>(srcL, g3, y, x * 3 + k);
     else if (k < 6) dstR[((size_t)y * g3.dw + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8, 3>(srcR, g3, y, x * 3 + (k - 3));
-    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false, 1>(srcM, g1, y, x);
+    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false, 1>(srcM, g1, y, x, fn);
 }
 
-template <bool U8>
+template <bool U8, typename F>
 __device__ __forceinline__ void collapse_border_body(int block, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                      const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                     float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1) {
+                                                     float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1, F fn) {
     const int i = block * 256 + threadIdx.y * 64 + threadIdx.x;
     const int pix = i / 3, c = i - pix * 3;
     int x, y;
     if (!border_pixel(pix, w, h, x0, x1, y0, y1, x, y)) return;
-    outB[((size_t)y * w + x) * 3 + c] = collapse_elem_wide<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
+    outB[((size_t)y * w + x) * 3 + c] = collapse_elem_wide<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c, fn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,7 +124,8 @@ __device__ __forceinline__ void pyrdown3_body(int bx, int by, const void* __rest
 
 // pyrDown, 1 channel (mask).  Thread (t, y): output pixels 4t..4t+3; source pixels 8t-2 .. 8t+8 of rows 2y-2 .. 2y+2,
 // fetched as four float4 from the aligned window 8t-4 .. 8t+11.
-__device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b) {
+template <typename F>
+__device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b, F fn) {
     const int t = bx * 64 + threadIdx.x;
     const int y = by * 4 + threadIdx.y;
     const int nt = g.dw >> 2;
@@ -137,6 +138,8 @@ __device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __res
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+#pragma unroll
+        for (int i = 2; i <= 12; ++i) v[i] = fn(v[i]);    // the eleven values the four outputs use
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = 2 + 2 * e;                       // source pixel 8t + 2e - 2 -> window index 2 + 2e
@@ -160,10 +163,10 @@ __device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __res
 
 // One launch per level: blocks [0, 3*nbi) are the interior tiles of L, R and the mask, the rest enumerate the border
 // elements.  The role of a block is uniform, so nothing diverges inside a wave.
-template <bool U8>
-__global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
-                                                       float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
-                                                       DownGeom g3, DownGeom g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1) {
+template <bool U8, typename F>
+__device__ __forceinline__ void pyrdown_level_body(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                   float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                   const DownGeom& g3, const DownGeom& g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1, F fn) {
     const int nbi = gx * gy;
     int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {                 // border blocks come first: their load chains are the longest
@@ -172,28 +175,49 @@ __global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ 
         const int by = blk / gx, bx = blk - by * gx;
         if (which == 0)      pyrdown3_body<U8>(bx, by, srcL, dstL, g3, b);
         else if (which == 1) pyrdown3_body<U8>(bx, by, srcR, dstR, g3, b);
-        else                 pyrdown1_body(bx, by, srcM, dstM, g1, b);
+        else                 pyrdown1_body(bx, by, srcM, dstM, g1, b, fn);
     } else {
-        pyrdown_border_body<U8>(blk, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1);
+        pyrdown_border_body<U8>(blk, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1, fn);
     }
 }
+// mask_ab: nullptr = srcM holds the mask itself; else srcM is the pair's m2 and mask_ab -> (alpha, beta) of this frame (level 0 only)
+template <bool U8>
+__global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
+                                                       float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
+                                                       DownGeom g3, DownGeom g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1,
+                                                       const double* __restrict__ mask_ab) {
+    if (U8 && mask_ab) pyrdown_level_body<U8>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
+    else               pyrdown_level_body<U8>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
+}
 
-bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s) {
-    const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+static bool pyrdown_vec_bounds(int sw, int sh, VecBounds& b) {
+    const DownGeom g3 = make_down_geom(sw, sh, 3);
     if ((g3.dw & 3) != 0 || (sw & 3) != 0 || g3.dw < 32 || g3.dh < 8) return false;
     // interior threads: 24t + 27 < 3 sw  (this also covers the 1-channel window 8t + 11 < sw) and 2y + 2 <= sh - 1
-    VecBounds b;
     b.t1 = std::min(g3.dw / 4 - 1, (3 * sw - 28) / 24);
     b.t1 = std::min(b.t1, (sw - 12) / 8);
     b.y1 = std::min(g3.dh - 1, (sh - 3) / 2);
-    if (b.t1 < 1 || b.y1 < 1) return false;
+    return b.t1 >= 1 && b.y1 >= 1;
+}
+static bool collapse_vec_ok(int w, int h, int nw, int nh) { (void)h; return (w & 3) == 0 && nw * 2 == w && nw >= 16 && nh >= 8; }
+
+// both level-0 kernels of a w x h frame take the wide forms (the ones that can read the mask through m2)
+bool pyr_level0_vec_ok(int w, int h) {
+    VecBounds b;
+    return pyrdown_vec_bounds(w, h, b) && collapse_vec_ok(w, h, (w + 1) / 2, (h + 1) / 2);
+}
+
+bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab) {
+    const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+    VecBounds b;
+    if (!pyrdown_vec_bounds(sw, sh, b)) return false;
     const int gx = (g3.dw / 4 + 63) / 64, gy = (g3.dh + 3) / 4;
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
     const int nborder = (nb * 7 + 255) / 256, blocks = 3 * gx * gy + nborder;
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1);
-    else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
+    else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
     return true;
 }
 
@@ -251,10 +275,10 @@ __device__ __forceinline__ void load_g12(const void* g, size_t elem_off, float v
     }
 }
 
-template <bool U8>
+template <bool U8, typename F>
 __device__ __forceinline__ void collapse_body(int bx, int by, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                               const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                              float* __restrict__ outB, int w, int h, int nw, int nh) {
+                                              float* __restrict__ outB, int w, int h, int nw, int nh, F fn) {
     const int t = bx * 64 + threadIdx.x;
     const int sy = by * 4 + threadIdx.y;
     if (t >= (nw >> 1) || sy >= nh) return;
@@ -265,7 +289,7 @@ __device__ __forceinline__ void collapse_body(int bx, int by, const void* __rest
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const float4 q = *(const float4*)(gM + (size_t)(2 * sy + r) * w + 4 * t);
-        m[r][0] = q.x; m[r][1] = q.y; m[r][2] = q.z; m[r][3] = q.w;
+        m[r][0] = fn(q.x); m[r][1] = fn(q.y); m[r][2] = fn(q.z); m[r][3] = fn(q.w);
     }
     {   // A = (G_L - up(nL)) * m
         float up[2][4][3];
@@ -309,31 +333,39 @@ __device__ __forceinline__ void collapse_body(int bx, int by, const void* __rest
     }
 }
 
-template <bool U8>
-__global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
-                                                        const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                        float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
-                                                        int x0, int x1, int y0, int y1) {
+template <bool U8, typename F>
+__device__ __forceinline__ void collapse_level_body(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                    const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                    float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
+                                                    int x0, int x1, int y0, int y1, F fn) {
     int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {
         blk -= nborder;
         const int by = blk / gx, bx = blk - by * gx;
-        collapse_body<U8>(bx, by, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+        collapse_body<U8>(bx, by, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, fn);
     } else {
-        collapse_border_body<U8>(blk, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1);
+        collapse_border_body<U8>(blk, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1, fn);
     }
+}
+template <bool U8>
+__global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
+                                                        const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
+                                                        float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
+                                                        int x0, int x1, int y0, int y1, const double* __restrict__ mask_ab) {
+    if (U8 && mask_ab) collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
+    else               collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
 }
 
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                         float* outB, int w, int h, int nw, int nh, hipStream_t s) {
-    if ((w & 3) != 0 || nw * 2 != w || nw < 16 || nh < 8) return false;
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab) {
+    if (!collapse_vec_ok(w, h, nw, nh)) return false;
     const int t1 = (nw - 3) / 2;                      // last interior thread: 2t + 2 <= nw - 1
     const int gx = (nw / 2 + 63) / 64, gy = (nh + 3) / 4;
     const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
     const int nb = border_count(w, h, x0, x1, y0, y1);
     const int nborder = (nb * 3 + 255) / 256, blocks = gx * gy + nborder;
-    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1);
-    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
+    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
     return true;
 }
 

@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active && ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
     int id[4] = {0, 0, 0, 0};                                    // entry index + 1 of the last covering triangle per pixel
-    const int mword = row * kWords + ((xg * 4) >> 6), shift = (xg * 4) & 63;
+    // the thread's four coverage bits never straddle a dword: (x offset in the tile) is a multiple of 4
+    const int mdword = row * kWords * 2 + ((xg * 4) >> 5), shift = (xg * 4) & 31;
+    const uint32_t* s_mask32 = (const uint32_t*)s_mask;
     for (int base = 0; base < nb || base == 0; base += kChunk) {
         const int n_here = min(kChunk, nb - base);
         if (base) __syncthreads();                               // the previous pass's masks have been read
@@ -179,11 +181,19 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
         }
         if (base == 0 && stages) s_rec[tid] = staged;
         __syncthreads();
-        for (int i = 0; i < n_here; ++i) {                       // painter's order: a later entry overwrites
-            const uint64_t mm = s_mask[i * 16 + mword];
-            const uint32_t bits = (uint32_t)(mm >> shift) & 15u;
+        // painter's order, a later entry overwrites: the four pixels' entry numbers of this pass (1..32) ride in the four bytes of
+        // one register; an entry's four coverage bits become the byte selector of one v_perm between the old bytes and the entry's
+        // number — five vector instructions per entry for the thread's four pixels
+        uint32_t packed = 0;
+        for (int i = 0; i < n_here; ++i) {
+            const uint32_t bits = (s_mask32[i * 32 + mdword] >> shift) & 15u;
+            const uint32_t spread = __umul24(bits, 0x204081u) & 0x01010101u;          // bit k of `bits` -> bit 0 of byte k
+            packed = __builtin_amdgcn_perm((uint32_t)(i + 1) * 0x01010101u, packed, (spread << 2) | 0x03020100u);
+        }
 #pragma unroll
-            for (int px = 0; px < 4; ++px) id[px] = ((bits >> px) & 1u) ? base + i + 1 : id[px];
+        for (int px = 0; px < 4; ++px) {
+            const int e = (int)((packed >> (8 * px)) & 255u);
+            id[px] = e ? base + e : id[px];
         }
         if (nb == 0) break;
     }

@@ -133,6 +133,7 @@ int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* fused, unsigned 
     if (general) *general = c->n_warp_general;
     return POPPY_OK;
 }
+int poppy_hip_mask_rider(poppy_hip_ctx* c) { return c ? (c->lazy_mask ? 0 : 1) : POPPY_E_ARG; }
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
 void* poppy_hip_stream(poppy_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -196,6 +197,8 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
     const size_t tail_lds = pyr_tail_lds_bytes(L, c->tail_n3, c->tail_n1);
     c->use_tail = tail_lds <= 160 * 1024;
+    static const bool rider = getenv("POPPY_HIP_LBMASK_RIDER") != nullptr;
+    c->lazy_mask = !rider && c->cfg.pyramid_levels >= 1 && c->first_tail >= 1 && pyr_level0_vec_ok(W, H);
     if (c->use_tail) {
         if (!prepare_pyr_tail(tail_lds)) return fail(c, POPPY_E_DEVICE, "could not raise the tail kernel's LDS limit");
     } else {
@@ -466,7 +469,9 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         }
         const void* sl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
         const void* sr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
-        launch_pyrdown(sl, sr, f.pyrM + a.off1, i == 0, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1, a.w, a.h, s);
+        const bool lazy = i == 0 && c->lazy_mask;      // level 0 reads the mask through m2 (kernels.h: launch_pyrdown)
+        launch_pyrdown(sl, sr, lazy ? c->m2 : f.pyrM + a.off1, i == 0, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1, a.w, a.h, s,
+                       lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr);
         ++i;
     }
     if (tm) tm->mark("pyrdown");
@@ -488,8 +493,9 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
         const void* gl = i == 0 ? (const void*)f.tr1 : (const void*)(f.pyrL + a.off3);
         const void* gr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
-        launch_collapse(gl, gr, i == 0, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrB + b.off3, f.pyrB + a.off3,
-                        a.w, a.h, b.w, b.h, s);
+        const bool lazy = i == 0 && c->lazy_mask;
+        launch_collapse(gl, gr, i == 0, lazy ? c->m2 : f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrB + b.off3, f.pyrB + a.off3,
+                        a.w, a.h, b.w, b.h, s, lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr);
         --j;
     }
     if (tm) tm->mark("collapse");
@@ -527,6 +533,8 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
     *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
+    ((double*)(f.h_blob + kBlobMaskAB))[0] = 1.0 - mask;           // lbmask = clamp(alpha + m2 * beta), read by the level-0 blend kernels
+    ((double*)(f.h_blob + kBlobMaskAB))[1] = -mask;
     const size_t rec_bytes = (size_t)(T + 1) * kWarpRecordFloats * sizeof(float);
     int* h_tri = (int*)(f.h_blob + kBlobHeader + rec_bytes);
     float* h_inv = (float*)(h_tri + (size_t)T * 6);
@@ -628,7 +636,8 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     if (c->cur1_ready && c->cur1_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->cur1_ready, 0));
     WarpExtras ex;
     ex.id_base = id_base;
-    ex.m2 = c->m2; ex.mask = f.pyrM; ex.alpha = 1.0 - mask; ex.beta = -mask;       // lbmask rides along (level 0 of pyrM)
+    // lbmask (level 0 of pyrM) rides along with the warp only where the blend kernels cannot read it through m2
+    ex.m2 = c->lazy_mask ? nullptr : c->m2; ex.mask = f.pyrM; ex.alpha = 1.0 - mask; ex.beta = -mask;
     if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
         // A stamped dispatch still costs the frame loop ~5 us (it completes through a signal the host can read: 2.6 % of a
         // chained 1080p frame when every launch is stamped), so one launch in kWarpStampStride carries the stamps; the
@@ -873,7 +882,14 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     if (n == "triMap") { src = f.triMap; need = P * 4; }
     else if (n == "trImg1") { src = f.tr1; need = P * 3; }
     else if (n == "trImg2") { src = f.tr2; need = P * 3; }
-    else if (n == "lbmask") { src = f.pyrM; need = P * 4; }
+    else if (n == "lbmask") {
+        if (c->lazy_mask) {                    // never materialised by the frame: made here from m2 and the frame's (alpha, beta)
+            if (hipStreamSynchronize(f.last_stream ? f.last_stream : c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "sync failed");
+            launch_lbmask(c->m2, (const double*)(f.d_blob + kBlobMaskAB), f.pyrM, P, c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "lbmask kernel failed");
+        }
+        src = f.pyrM; need = P * 4;
+    }
     else if (n == "lapBlend") { src = f.pyrB; need = P * 12; }
     else if (n == "unsharp") {
         if (!c->debug || !f.unsharpF) return fail(c, POPPY_E_STATE, "enable debug before rendering the frame");

@@ -36,6 +36,32 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : 
 
 constexpr float kInv255 = (float)(1.0 / 255.0);
 
+// lbmask = clamp((1-mr) - m2*mr)            arithm.simd.hpp:1160-1216,1808 (double, one rounding)
+__device__ __forceinline__ float mask_value(float m2, double alpha, double beta) {
+    double t = (double)m2 * beta + 0.0;
+    float v = (float)(1.0 * alpha + t);
+    if (v < 0.f) v = 0.f;
+    if (v > 1.f) v = 1.f;
+    return v;
+}
+
+// How the level-0 blend kernels see the blend mask: either the materialised lbmask (ab == nullptr: the values are used as
+// they are) or the pair's m2 field with the frame's (alpha, beta) — then every loaded value goes through mask_value, and
+// the warp kernel does not have to write lbmask (4 B/px written + 4 B/px read less per frame).
+struct MaskSource {
+    double alpha, beta;
+    bool lazy;
+    __device__ __forceinline__ float operator()(float raw) const { return lazy ? mask_value(raw, alpha, beta) : raw; }
+};
+__device__ __forceinline__ MaskSource mask_source(const double* __restrict__ ab) {
+    MaskSource m;
+    m.lazy = ab != nullptr;
+    m.alpha = m.lazy ? ab[0] : 0.0;
+    m.beta = m.lazy ? ab[1] : 0.0;
+    return m;
+}
+struct MaskPlain { __device__ __forceinline__ float operator()(float raw) const { return raw; } };
+
 template <bool U8> __device__ __forceinline__ float ld(const void* p, size_t i) {
     if (U8) return (float)((const uint8_t*)p)[i] * kInv255;      // convertTo(CV_32F, 1/255): v*a + 0
     return ((const float*)p)[i];
@@ -143,8 +169,8 @@ __device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, c
 // chain of dependent branches and loads.
 __device__ __forceinline__ int reflect101_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }
 
-template <bool U8, int CN>
-__device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGeom& g, int y, int xe) {
+template <bool U8, int CN, typename F = MaskPlain>
+__device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGeom& g, int y, int xe, F fn = F()) {
     constexpr int cn = CN;                                   // == g.cn; a constant keeps xe / cn off the division path
     const int px = xe / cn, c = xe - px * cn;
     const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
@@ -159,7 +185,7 @@ __device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGe
 #pragma unroll
     for (int k = 0; k < 5; ++k)
 #pragma unroll
-        for (int m = 0; m < 5; ++m) t[k][m] = ld<U8>(src, rowo[k] + col[m]);
+        for (int m = 0; m < 5; ++m) t[k][m] = fn(ld<U8>(src, rowo[k] + col[m]));
     float r[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k)
@@ -192,11 +218,11 @@ __device__ __forceinline__ float pyrup_elem_wide(const float* __restrict__ src, 
     return (dy & 1) ? ((r1 + r2) * 4.f) * s : (r0 + r1 * 6.f + r2) * s;
 }
 
-template <bool U8>
+template <bool U8, typename F = MaskPlain>
 __device__ __forceinline__ float collapse_elem_wide(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
-                                                    const float* nB, int w, int h, int nw, int nh, int y, int xe) {
+                                                    const float* nB, int w, int h, int nw, int nh, int y, int xe, F fn = F()) {
     const size_t i = (size_t)y * w * 3 + xe;
-    const float m = gM[(size_t)y * w + xe / 3];
+    const float m = fn(gM[(size_t)y * w + xe / 3]);
     const float gl = ld<U8>(gL, i), gr = ld<U8>(gR, i);
     const float uL = pyrup_elem_wide(nL, nw, nh, y, xe), uR = pyrup_elem_wide(nR, nw, nh, y, xe), uB = pyrup_elem_wide(nB, nw, nh, y, xe);
     return uB + mix_lr(gl - uL, gr - uR, m);

@@ -12,15 +12,6 @@ __device__ __forceinline__ int decode_id(uint32_t raw, uint32_t id_base) {
     return d < (1u << 20) ? (int)d : 0;
 }
 
-// lbmask = clamp((1-mr) - m2*mr)            arithm.simd.hpp:1160-1216,1808 (double, one rounding)
-__device__ __forceinline__ float mask_value(float m2, double alpha, double beta) {
-    double t = (double)m2 * beta + 0.0;
-    float v = (float)(1.0 * alpha + t);
-    if (v < 0.f) v = 0.f;
-    if (v > 1.f) v = 1.f;
-    return v;
-}
-
 __device__ __forceinline__ void bilinear_weights(int fx, int fy, int& w00, int& w01, int& w10, int& w11) {
     // BilinearTab_i: saturate_cast<short>((1-fy/32)(1-fx/32)*32768) etc.  All products are exact; only the
     // very first entry saturates (32768 -> 32767) and its deficit goes to tap [1][1] (imgwarp.cpp:251-267).
