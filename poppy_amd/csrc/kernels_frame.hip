@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
     __shared__ __attribute__((aligned(16))) float S[kUSy * kUSs];
     __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
-    __shared__ __attribute__((aligned(16))) float D[kUDy * kURs];
+    float* const D = R;                 // the difference rows take R's place once every thread has read its R rows (phase 3)
     const int tid = threadIdx.x;
     const int tiles_x = (W + kUTx - 1) / kUTx;
     const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -801,18 +801,29 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     __syncthreads();
     // 3. column pass + difference.  D(q, u) for q in [0, 18) <-> image row ty0 - 1 + q <-> S / R row q + 4.
     //    A thread takes 4 neighbouring u and 2 neighbouring rows: 10 R rows feed 8 outputs.
-    for (int i = tid; i < 26 * (kUDy / 2); i += 256) {
+    static_assert(26 * (kUDy / 2) <= 256, "one item per thread: the results wait in registers for the barrier below");
+    {
+        const int i = tid;
+        const bool has = i < 26 * (kUDy / 2);
         const int qi = i / 26, t = i - qi * 26;
         const int u0 = 12 + 4 * t, q0 = 2 * qi;
-        f4 rr[10];
+        f4 dd[2];
+        if (has) {
+            f4 rr[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) rr[k] = *(const f4*)(R + (q0 + k) * kURs + u0);
+            for (int k = 0; k < 10; ++k) rr[k] = *(const f4*)(R + (q0 + k) * kURs + u0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f4 acc = c_gauss9[4] * rr[4 + j] + 0.f;
+            for (int j = 0; j < 2; ++j) {
+                f4 acc = c_gauss9[4] * rr[4 + j] + 0.f;
 #pragma unroll
-            for (int k = 1; k <= 4; ++k) acc = c_gauss9[4 + k] * (rr[4 + j + k] + rr[4 + j - k]) + acc;
-            *(f4*)(D + (q0 + j) * kURs + u0) = *(const f4*)(S + (q0 + j + 4) * kUSs + u0) - acc;
+                for (int k = 1; k <= 4; ++k) acc = c_gauss9[4 + k] * (rr[4 + j + k] + rr[4 + j - k]) + acc;
+                dd[j] = *(const f4*)(S + (q0 + j + 4) * kUSs + u0) - acc;
+            }
+        }
+        __syncthreads();                                   // R has been read: D may overwrite it
+        if (has) {
+            *(f4*)(D + q0 * kURs + u0) = dd[0];
+            *(f4*)(D + (q0 + 1) * kURs + u0) = dd[1];
         }
     }
     __syncthreads();
