@@ -75,7 +75,8 @@ struct poppy_hip_ctx {
     // frames are in flight at once.
     int next_slot = 0, last_slot = -1;
     std::vector<PyrLevel> levels;        // 0..pyramid_levels
-    PyrLevel* d_levels = nullptr;
+    void* d_levels = nullptr;            // the tail kernel's tap descriptors (kernels.h: PyrTailPlan), written once per pair geometry
+    PyrTailPlan tail;                    // ... and its step table (a kernel argument)
     int first_tail = 1;
     bool use_tail = true;                // false: the coarsest level is too large for one workgroup's LDS (shallow --pyramid): per-level kernels all the way
     // points
@@ -85,7 +86,6 @@ struct poppy_hip_ctx {
     // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
     //              [RasterTri T][work 2*n i32]
     size_t blob_bytes = 0; size_t bins_cap = 0;       // bins_cap: most per-tile triangle-list entries a plan blob has room for
-    int tail_n3 = 0, tail_n1 = 0, tail_k1 = 0;    // tail_k1: first single-pixel level (or the last level)
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
     OrbDetector orb, orb_b;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
+#include <vector>
 
 namespace poppy_hip {
 
@@ -84,10 +86,6 @@ bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, b
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
                          float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr);
 
-// all remaining (small) levels in one workgroup: reductions down to level `levels`, the smallest-level
-// mix and the collapse back up to level `first`; writes B_first.
-// n3 / n1 = number of 3-channel / 1-channel floats of levels first..levels (they are staged in LDS);
-// k1 = first level in [first, levels] that is a single pixel, or `levels` when there is none.
 // Two levels per launch for levels that are launch-latency bound (kernels_pyramid_fused.hip): the workgroup that owns a
 // tile of the second level computes the part of the intermediate level it needs into LDS itself.
 constexpr size_t kFuseMaxPixels = 150000;          // first level of the pair: 480 x 270 and below
@@ -104,10 +102,33 @@ void launch_collapse2(const float* gL, const float* gR, const float* gM, const f
 
 // blended smallest level = L*m + R*(1-m), for pyramids whose coarsest level does not fit the tail kernel's LDS
 void launch_mix_top(const float* l, const float* r, const float* m, float* out, int n_px, hipStream_t s);
-size_t pyr_tail_lds_bytes(int levels, int n3, int n1);      // dynamic LDS the tail kernel needs
-bool prepare_pyr_tail(size_t lds_bytes);                    // raises the kernel's LDS limit; call outside stream capture
-void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels,
-                     int first, int levels, int k1, int n3, int n1, hipStream_t s);
+
+// All remaining (small) levels in ONE workgroup (kernels_pyramid_tail.hip): reductions from level `first` down to the last level,
+// the smallest-level mix and the collapse back up to level `first`; reads L/R/M of level `first`, writes B of level `first`.
+// The level geometry is fixed for the life of a pair, so the host writes one 16-byte tap descriptor per output of every
+// multi-pixel level step once (build_pyr_tail_plan); the kernel stages them in LDS beside the levels.
+constexpr int kPyrTailMaxWide = 12;                // multi-pixel level steps (the tail starts at a few hundred pixels)
+struct PyrTailDown { int c3, c1, desc, so3, so1, do3, do1, stride3, stride1; };   // outputs per 3-channel plane / of the mask, first descriptor, source / destination level offsets (floats, relative to level `first`), source row strides
+struct PyrTailUp { int cnt, desc, co3, co1, no3, nstride; };                       // outputs, first descriptor, offsets of the output level (3-channel, mask) and of the coarser level, its row stride
+struct PyrTailArgs {
+    int n_wide, n3, n1, n_desc;                    // multi-pixel steps; 3-channel / 1-channel floats of levels first..last; descriptors
+    int first_c3, first_c1;                        // elements of level `first`
+    int nl, one_o3, one_o1;                        // single-pixel levels: number of reductions from the first of them (-1: the last level has more than one pixel), its offsets
+    int top_o3, top_o1, top_c3;                    // the last level (used when nl < 0)
+    unsigned long long g_off3, g_off1;             // level `first` inside the pyramid buffers
+    PyrTailDown down[kPyrTailMaxWide];
+    PyrTailUp up[kPyrTailMaxWide];
+};
+struct PyrTailPlan {
+    bool ok = false;                               // false: geometry outside the descriptor fields or LDS; use the per-level kernels
+    PyrTailArgs args;
+    size_t lds_bytes = 0;
+    std::vector<uint32_t> desc;                    // 4 words per descriptor, uploaded once per pair
+};
+PyrTailPlan build_pyr_tail_plan(const PyrLevel* levels, int first, int last);
+bool prepare_pyr_tail(size_t lds_bytes);           // raises the kernel's dynamic-LDS limit; call outside stream capture
+void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const void* d_desc, const PyrTailArgs& args,
+                     size_t lds_bytes, hipStream_t s);
 
 // unsharp_mask(lapBlend, 1, amount, 0.3) + convertTo(CV_8U, 255)  (src/util.cpp:113-148, src/algo.cpp:263-265)
 // d_amount (device, may be null): when set, the tile kernel reads the amount from there instead of the argument, so

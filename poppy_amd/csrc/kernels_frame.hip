@@ -470,152 +470,6 @@ void launch_lbmask(const float* m2, const double* mask_ab, float* dst, size_t n,
     hipLaunchKernelGGL(k_lbmask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m2, mask_ab, dst, n);
 }
 
-// --- all small levels in one workgroup, staged in LDS ---------------------------------------------
-// Levels first..levels live in LDS (a few hundred pixels in total).  The kernel is a single workgroup, so its time is
-// a chain of short dependent steps: branch-free per-element forms for every level of at least 3x3 and no
-// level-table lookups inside the sequential part.  (Measured: ~1.8 us per tiny level whatever the thread count; 1024
-// threads pay off once the first level has a few hundred pixels.)
-// Once a level is 1x1 (level k1, found by the host) every deeper level is 1x1 too — ~50 of them at 1080p with
-// pyramid_levels = 64.  Going down, the seven scalar chains (L and R per channel, mask) run on seven lanes.  Going
-// up, everything that does not depend on the running value (the Laplacian residual of each level) is computed for all
-// levels at once, one lane per (level, channel); what remains sequential is  cur = pyrUp(cur) + residual[i].
-constexpr int kTailMaxLevels = 257;
-constexpr int kTailThreads = 1024;
-
-__device__ __forceinline__ int div_small(int e, int d, float inv) {     // e / d for 0 <= e < 2^20, inv = 1.f / d
-    int q = (int)((float)e * inv);
-    const int r = e - q * d;
-    return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
-}
-__device__ __forceinline__ float down_1x1(float v) {                    // pyrDown of a single pixel: every tap is the pixel
-    const float h = v * 6.f + (v + v) * 4.f + v + v;
-    return (h * 6.f + (h + h) * 4.f + h + h) * (1.f / 256);
-}
-__device__ __forceinline__ float up_1x1(float v) {                      // pyrUp of a single pixel to a single pixel
-    const float h = v * 8.f;
-    return (h + h * 6.f + h) * (1.f / 64);
-}
-
-__global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restrict__ gL, const float* __restrict__ gR,
-                                                           const float* __restrict__ gM, float* __restrict__ gB,
-                                                           const PyrLevel* __restrict__ glv, int first, int levels, int k1,
-                                                           int n3, int n1) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    PyrLevel* lv = (PyrLevel*)lds;   // indexed by absolute level; entries first..min(k1+1, levels) are filled
-    float* sL = (float*)(lv + (levels + 1));     // n3 floats each, indexed by (off3 - base3)
-    float* sR = sL + n3;
-    float* sB = sR + n3;
-    float* sM = sB + n3;             // n1 floats, indexed by (off1 - base1)
-    float* sRes = sM + n1;           // 3 x kTailMaxLevels residuals of the single-pixel levels
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int wide_end = k1 < levels ? k1 : levels;        // levels [first, wide_end) are reduced block-wide
-    const int tab_end = wide_end + 1 < levels ? wide_end + 1 : levels;
-    for (int i = first + tid; i <= tab_end; i += nth) lv[i] = glv[i];
-    {   // stage level `first` (produced by the previous pyrDown launch)
-        const PyrLevel f = glv[first];
-        const int c3 = f.w * f.h * 3, c1 = f.w * f.h;
-        for (int e = tid; e < c3; e += nth) { sL[e] = gL[f.off3 + e]; sR[e] = gR[f.off3 + e]; }
-        for (int e = tid; e < c1; e += nth) sM[e] = gM[f.off1 + e];
-    }
-    __syncthreads();
-    const size_t base3 = lv[first].off3, base1 = lv[first].off1;
-
-    for (int i = first; i < wide_end; ++i) {
-        const PyrLevel s = lv[i], d = lv[i + 1];
-        const DownGeom g3 = make_down_geom(s.w, s.h, 3), g1 = make_down_geom(s.w, s.h, 1);
-        const int row3 = d.w * 3, c3 = row3 * d.h, c1 = d.w * d.h;
-        const float inv3 = 1.f / (float)row3, inv1 = 1.f / (float)d.w;
-        const int so3 = (int)(s.off3 - base3), do3 = (int)(d.off3 - base3), so1 = (int)(s.off1 - base1), do1 = (int)(d.off1 - base1);
-        const bool big = s.w >= 3 && s.h >= 3;             // one reflection reaches every tap
-        for (int e = tid; e < 2 * c3 + c1; e += nth) {
-            if (e < 2 * c3) {
-                const bool right = e >= c3;
-                const int q = right ? e - c3 : e;
-                const int y = div_small(q, row3, inv3), xe = q - y * row3;
-                const float* src = (right ? sR : sL) + so3;
-                const float v = big ? pyrdown_elem_wide<false, 3>(src, g3, y, xe) : pyrdown_elem<false>(src, g3, y, xe);
-                (right ? sR : sL)[do3 + q] = v;
-            } else {
-                const int q = e - 2 * c3;
-                const int y = div_small(q, d.w, inv1), xe = q - y * d.w;
-                sM[do1 + q] = big ? pyrdown_elem_wide<false, 1>(sM + so1, g1, y, xe) : pyrdown_elem<false>(sM + so1, g1, y, xe);
-            }
-        }
-        __syncthreads();
-    }
-
-    if (k1 < levels) {
-        const int nl = levels - k1;                        // single-pixel reductions; 1x1 levels are 3 (1) floats apart
-        const int o3 = (int)(lv[k1].off3 - base3), o1 = (int)(lv[k1].off1 - base1);
-        if (tid < 7) {
-            float* chain = tid < 3 ? sL + o3 + tid : tid < 6 ? sR + o3 + (tid - 3) : sM + o1;
-            const int step = tid < 6 ? 3 : 1;
-            float v = chain[0];
-            for (int j = 1; j <= nl; ++j) { v = down_1x1(v); chain[j * step] = v; }
-        }
-        __syncthreads();
-        for (int e = tid; e < nl * 3; e += nth) {          // residual of single-pixel level k1 + e/3, channel e%3
-            const int j = e / 3;
-            const float lapL = sL[o3 + e] - up_1x1(sL[o3 + e + 3]), lapR = sR[o3 + e] - up_1x1(sR[o3 + e + 3]);
-            sRes[e] = mix_lr(lapL, lapR, sM[o1 + j]);
-        }
-        __syncthreads();
-        if (tid < 3) {
-            const int top = o3 + nl * 3 + tid;
-            float cur = mix_lr(sL[top], sR[top], sM[o1 + nl]);
-            sB[top] = cur;
-            float res = sRes[(nl - 1) * 3 + tid];
-            for (int j = nl - 1; j >= 0; --j) {
-                const float nxt = sRes[(j > 0 ? j - 1 : 0) * 3 + tid];      // fetched while the chain below runs
-                cur = up_1x1(cur) + res;
-                sB[o3 + j * 3 + tid] = cur;
-                res = nxt;
-            }
-        }
-    } else {
-        const PyrLevel t = lv[levels];
-        const int o3 = (int)(t.off3 - base3), o1 = (int)(t.off1 - base1);
-        for (int e = tid; e < t.w * t.h * 3; e += nth) sB[o3 + e] = mix_lr(sL[o3 + e], sR[o3 + e], sM[o1 + e / 3]);
-    }
-    __syncthreads();
-
-    for (int i = wide_end - 1; i >= first; --i) {
-        const PyrLevel c = lv[i], n = lv[i + 1];
-        const int co3 = (int)(c.off3 - base3), no3 = (int)(n.off3 - base3), co1 = (int)(c.off1 - base1);
-        const int row3 = c.w * 3;
-        const float inv3 = 1.f / (float)row3;
-        const bool big = n.w >= 2 && n.h >= 2;
-        for (int e = tid; e < row3 * c.h; e += nth) {
-            const int y = div_small(e, row3, inv3), xe = e - y * row3;
-            sB[co3 + e] = big ? collapse_elem_wide<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe)
-                              : collapse_elem<false>(sL + co3, sR + co3, sM + co1, sL + no3, sR + no3, sB + no3, c.w, c.h, n.w, n.h, y, xe);
-        }
-        __syncthreads();
-    }
-    {
-        const PyrLevel f = lv[first];
-        for (int e = tid; e < f.w * f.h * 3; e += nth) gB[f.off3 + e] = sB[e];
-    }
-}
-// (A variant with one WAVE per plane — the seven planes of the down pass and the three channels of the up pass are independent,
-// so their levels need no block barrier — was built and measured in round 2: bit-identical, but 9 us per frame SLOWER at 1080p:
-// a lone wave walks 8 outputs per lane of the 30 x 17 level at one instruction every few cycles, which costs more than the
-// barriers it saves.  tools/experiments/frames_only.py, profiles/r02_notes.md.)
-
-// The dynamic-LDS limit of a kernel is process state per device, not per context: it is only ever RAISED here, so a context
-// with a smaller geometry cannot lower it under a live one.  Call outside any stream capture.
-bool prepare_pyr_tail(size_t lds_bytes) {
-    static std::mutex mu;
-    static size_t granted[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    std::lock_guard<std::mutex> lock(mu);
-    if (lds_bytes <= granted[dev]) return true;
-    if (hipFuncSetAttribute((const void*)k_pyr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
-    granted[dev] = lds_bytes;
-    return true;
-}
-
 // Smallest-level mix of a pyramid too shallow for the LDS tail (blend.hpp:72-76: resultHighestLevel = left * mask + right * (1 - mask)
 // with the mask replicated to three channels), straight from and to global memory.
 __global__ void __launch_bounds__(256) k_mix_top(const float* __restrict__ l, const float* __restrict__ r, const float* __restrict__ m,
@@ -625,14 +479,6 @@ __global__ void __launch_bounds__(256) k_mix_top(const float* __restrict__ l, co
 }
 void launch_mix_top(const float* l, const float* r, const float* m, float* out, int n_px, hipStream_t s) {
     hipLaunchKernelGGL(k_mix_top, dim3((n_px * 3 + 255) / 256), dim3(256), 0, s, l, r, m, out, n_px * 3);
-}
-size_t pyr_tail_lds_bytes(int levels, int n3, int n1) {
-    return ((size_t)3 * n3 + n1 + 3 * kTailMaxLevels) * sizeof(float) + (size_t)(levels + 1) * sizeof(PyrLevel) + 16;
-}
-void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* d_levels, int first, int levels,
-                     int k1, int n3, int n1, hipStream_t s) {
-    const size_t lds = pyr_tail_lds_bytes(levels, n3, n1);
-    hipLaunchKernelGGL(k_pyr_tail, dim3(1), dim3(kTailThreads), lds, s, pyrL, pyrR, pyrM, pyrB, d_levels, first, levels, k1, n3, n1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -190,17 +190,12 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     static const size_t tail_px = getenv("POPPY_TAIL_PX") ? (size_t)atoi(getenv("POPPY_TAIL_PX")) : 600;
     for (int i = 1; i <= L; ++i)
         if ((size_t)c->levels[i].w * c->levels[i].h <= tail_px) { c->first_tail = i; break; }   // everything below runs in ONE workgroup: keep it small
-    c->tail_n3 = c->tail_n1 = 0;
-    c->tail_k1 = L;
-    for (int i = std::min(c->first_tail, L); i <= L; ++i)
-        if (c->levels[i].w == 1 && c->levels[i].h == 1) { c->tail_k1 = i; break; }
-    for (int i = c->first_tail; i <= L; ++i) { c->tail_n3 += c->levels[i].w * c->levels[i].h * 3; c->tail_n1 += c->levels[i].w * c->levels[i].h; }
-    const size_t tail_lds = pyr_tail_lds_bytes(L, c->tail_n3, c->tail_n1);
-    c->use_tail = tail_lds <= 160 * 1024;
+    c->tail = build_pyr_tail_plan(c->levels.data(), std::min(c->first_tail, L), L);
+    c->use_tail = c->tail.ok;
     static const bool rider = getenv("POPPY_HIP_LBMASK_RIDER") != nullptr;
     c->lazy_mask = !rider && c->cfg.pyramid_levels >= 1 && c->first_tail >= 1 && pyr_level0_vec_ok(W, H);
     if (c->use_tail) {
-        if (!prepare_pyr_tail(tail_lds)) return fail(c, POPPY_E_DEVICE, "could not raise the tail kernel's LDS limit");
+        if (!prepare_pyr_tail(c->tail.lds_bytes)) return fail(c, POPPY_E_DEVICE, "could not raise the tail kernel's LDS limit");
     } else {
         // A shallow pyramid (--pyramid 4 at 1080p ends at 120 x 68): every level goes through the per-level kernels and the
         // coarsest-level mix runs from global memory (blend.hpp simply loops `levels` times, any depth is legal).
@@ -222,8 +217,10 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
         HIPCHK(c, hipMalloc((void**)&f.pyrB, off3 * 4)); HIPCHK(c, hipMalloc((void**)&f.pyrM, off1 * 4));
         if (W < 2 || H < 2) { HIPCHK(c, hipMalloc((void**)&f.tmp, P * 12)); HIPCHK(c, hipMalloc((void**)&f.diff, P * 12)); }
     }
-    HIPCHK(c, hipMalloc((void**)&c->d_levels, sizeof(PyrLevel) * (L + 1)));
-    HIPCHK(c, hipMemcpy(c->d_levels, c->levels.data(), sizeof(PyrLevel) * (L + 1), hipMemcpyHostToDevice));
+    if (c->use_tail) {
+        HIPCHK(c, hipMalloc(&c->d_levels, c->tail.desc.size() * 4 + 16));
+        if (!c->tail.desc.empty()) HIPCHK(c, hipMemcpy(c->d_levels, c->tail.desc.data(), c->tail.desc.size() * 4, hipMemcpyHostToDevice));
+    }
     c->W = W; c->H = H;
     return POPPY_OK;
 }
@@ -475,7 +472,7 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         ++i;
     }
     if (tm) tm->mark("pyrdown");
-    if (c->use_tail) launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, ft, L, c->tail_k1, c->tail_n3, c->tail_n1, s);
+    if (c->use_tail) launch_pyr_tail(f.pyrL, f.pyrR, f.pyrM, f.pyrB, c->d_levels, c->tail.args, c->tail.lds_bytes, s);
     else launch_mix_top(f.pyrL + c->levels[L].off3, f.pyrR + c->levels[L].off3, f.pyrM + c->levels[L].off1, f.pyrB + c->levels[L].off3,
                         c->levels[L].w * c->levels[L].h, s);
     if (tm) tm->mark("pyr_tail");
