@@ -470,29 +470,45 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
 }
 
 namespace {
-bool warp_matrix_ok(const float* m, int w, int h, bool& zero) {
+// What the tiled warp kernels assume of a matrix over the pixels that use it — the box [x0, x1] x [y0, y1]: every entry finite
+// and moderate, the denominator z = m6 x + m7 y + m8 of one sign and within [2^-20, 2^20] (the hardware division sequence then
+// needs no range fix-up).  z is affine in (x, y): its extremes over the box are at the corners.
+bool warp_matrix_ok(const float* m, int x0, int x1, int y0, int y1, bool& zero) {
     zero = true;
     for (int i = 0; i < 9; ++i) {
         if (!std::isfinite(m[i]) || std::fabs(m[i]) > 1099511627776.f) return false;
         if (m[i] != 0.f) zero = false;
     }
     if (zero) return true;
-    const double spread = std::fabs((double)m[6]) * (w - 1) + std::fabs((double)m[7]) * (h - 1);
-    const double lo = (double)m[8] - spread, hi = (double)m[8] + spread;
+    double zlo = 0, zhi = 0;
+    for (int k = 0; k < 4; ++k) {
+        const double x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0;
+        const double z = (double)m[6] * x + (double)m[7] * y + (double)m[8];
+        zlo = k ? std::min(zlo, z) : z; zhi = k ? std::max(zhi, z) : z;
+    }
     const double kMin = 1.0 / 1048576.0, kMax = 1048576.0;
-    return (lo >= kMin && hi <= kMax) || (hi <= -kMin && lo >= -kMax);
+    return (zlo >= kMin && zhi <= kMax) || (zhi <= -kMin && zlo >= -kMax);
 }
 }  // namespace
 
-bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* rec) {
+// tri_xy (optional): the triangles' integer corners, 6 per triangle — a record is only used by pixels of its triangle's raster,
+// which lies inside the corners' bounding box; without it the whole image is assumed.
+bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* rec, const int* tri_xy) {
     static const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     bool ok = true;
     for (int t = -1; t < n_tris; ++t, rec += kWarpRecordFloats) {
         const float* a = t < 0 ? ident : inv1 + (size_t)t * 9;
         const float* b = t < 0 ? ident : inv2 + (size_t)t * 9;
+        int x0 = 0, x1 = w - 1, y0 = 0, y1 = h - 1;
+        if (t >= 0 && tri_xy) {
+            const int* v = tri_xy + (size_t)t * 6;
+            x0 = std::max(0, std::min(std::min(v[0], v[2]), v[4]) - 1); x1 = std::min(w - 1, std::max(std::max(v[0], v[2]), v[4]) + 1);
+            y0 = std::max(0, std::min(std::min(v[1], v[3]), v[5]) - 1); y1 = std::min(h - 1, std::max(std::max(v[1], v[3]), v[5]) + 1);
+            if (x0 > x1 || y0 > y1) { x0 = x1 = std::min(std::max(x0, 0), w - 1); y0 = y1 = std::min(std::max(y0, 0), h - 1); }   // wholly outside: paints nothing
+        }
         bool za, zb;
-        ok = warp_matrix_ok(a, w, h, za) && ok;
-        ok = warp_matrix_ok(b, w, h, zb) && ok;
+        ok = warp_matrix_ok(a, x0, x1, y0, y1, za) && ok;
+        ok = warp_matrix_ok(b, x0, x1, y0, y1, zb) && ok;
         rec[0] = a[0]; rec[1] = a[3]; rec[2] = a[1]; rec[3] = a[4]; rec[4] = a[2]; rec[5] = a[5];
         rec[6] = b[0]; rec[7] = b[3]; rec[8] = b[1]; rec[9] = b[4]; rec[10] = b[2]; rec[11] = b[5];
         rec[12] = a[6]; rec[13] = b[6]; rec[14] = a[7]; rec[15] = b[7];

@@ -62,7 +62,7 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
 // range where it equals IEEE division (non-finite or > 2^40 entries, or a denominator h6*x + h7*y + h8 that can leave
 // [2^-20, 2^20] in magnitude or change sign over the image); such frames use the general kernel.
 constexpr int kWarpRecordFloats = 20;
-bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* records);
+bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* records, const int* tri_xy = nullptr);
 
 void clip_points_ref(std::vector<P2f>& pts, int cols, int rows);   // src/util.cpp:453-460
 void unique_points_ref(const std::vector<P2f>& pts, std::vector<P2f>& out);   // make_uniq, src/util.cpp:541-548: first occurrences, input order

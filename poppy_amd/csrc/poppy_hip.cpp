@@ -564,7 +564,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     }
     // the fast warp kernel takes the frame when every matrix passes the host's range check (always, short of degenerate input)
     static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
-    const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader)) &&
+    const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), c->plan.tri_xy.data()) &&
                            warp_fast_geometry(W, H) && !exact_warp_only;
     const bool bin_warp = fast_warp && bins;                 // raster fused into the warp kernel: no id map at all
     c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;

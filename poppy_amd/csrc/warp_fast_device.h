@@ -23,6 +23,8 @@ __device__ __forceinline__ f2 div_core(f2 n, f2 d, f2 r1) {
 }
 
 // (sx, sy) = cvRound(q * 32) for both coordinates; out-of-range values come back far outside any image
+// (Dropping the two clamps behind a host-side bound on the quotients was measured: same kernel time, and the bound sent 8 % of the
+// frames of a real pair — sliver triangles — to the general kernel.)
 __device__ __forceinline__ void to_fixed(f2 q, int& sx, int& sy) {
     const f2 k32 = {32.f, 32.f};
     f2 v = q * k32;
@@ -36,29 +38,35 @@ __device__ __forceinline__ void to_fixed(f2 q, int& sx, int& sy) {
 
 struct FastTap { uint32_t wt, wb, off; bool inside; };
 
+// The four bilinear weights of a tap, DOUBLED and held two to a register: wt = 2 w00 | 2 w01 << 16, wb = 2 w10 | 2 w11 << 16 with
+// w = BilinearTab_i (imgwarp.cpp:213-287) = 32 (32 - fx or fx)(32 - fy or fy).  Doubling moves the result byte of
+// (sum w s + 16384) >> 15 = (sum 2w s + 32768) >> 16 onto a byte boundary, so three channels are packed with two v_perm instead of
+// three shift / shift-or pairs.  2 w00 = 65536 at fx = fy = 0 does not fit 16 bits: v_pk_mad_u16 with clamp saturates it to 65535,
+// and (65535 s + 32768) >> 16 = s for every byte s — the same result (the other three weights are 0 there).
 __device__ __forceinline__ FastTap make_fast_tap(int sx, int sy, int W, int H) {
     FastTap t;
     const int fx = sx & 31, fy = sy & 31, ix = sx >> 5, iy = sy >> 5;
     t.inside = (unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1);
     const uint32_t P = __umul24(fx, 65535u) + 32u;                 // (32 - fx) | fx << 16
-    t.wt = __umul24(P, (uint32_t)(1024 - (fy << 5)));              // w00 | w01 << 16
-    t.wb = __umul24(P, (uint32_t)(fy << 5));                       // w10 | w11 << 16
+    const uint32_t M2 = 0x08000800u - __umul24(fy, 0x00400040u);   // 64 (32 - fy) in both halves
+    asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(t.wt) : "v"(P), "v"(M2));
+    t.wb = __umul24(P, (uint32_t)(fy << 6));                       // 2 w10 | 2 w11 << 16 (no half exceeds 63488)
     t.off = t.inside ? (uint32_t)(__umul24(iy, W) + ix) * 3u : 0u;
     return t;
 }
 
 __device__ __forceinline__ uint32_t blend_fast(const FastTap& t, u2v a, u2v b) {
-    uint32_t out = 0;
+    uint32_t acc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 3) << 16);
         const uint32_t pt = __builtin_amdgcn_perm(a.y, a.x, sel);                // s00 | s01 << 16
         const uint32_t pb = __builtin_amdgcn_perm(b.y, b.x, sel);
-        uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pt), __builtin_bit_cast(us2, t.wt), 16384u, false);
-        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pb), __builtin_bit_cast(us2, t.wb), acc, false);
-        out |= (acc >> 15) << (8 * k);
+        acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pt), __builtin_bit_cast(us2, t.wt), 32768u, false);
+        acc[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pb), __builtin_bit_cast(us2, t.wb), acc[k], false);
     }
-    return out;
+    // byte 2 of each sum (below 2^24) is the channel
+    return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
 }
 
 // raw buffer descriptor over [p, p + bytes): 32-bit offsets straight into the load instruction, no 64-bit address arithmetic
