@@ -51,7 +51,7 @@ __device__ __forceinline__ float pyrdown_elem_patch(const float* __restrict__ pa
                              : (r[2] * 6.f + (r[1] + r[3]) * 4.f + r[0] + r[4]) * s;
 }
 
-constexpr int kD2Tx = 16, kD2Ty = 4;                    // tile of the second destination level, pixels
+constexpr int kD2Tx = 8, kD2Ty = 4;                     // tile of the second destination level, pixels
 constexpr int kD2Ps = (2 * kD2Tx + 3) * 3 + 3;          // B patch row stride in floats (35 px x 3 ch, padded)
 constexpr int kD2Pr = 2 * kD2Ty + 3;                    // B patch rows
 constexpr int kD2As = (4 * kD2Tx + 9) * 3 + 2;          // A patch row stride (73 px x 3 ch, padded)
@@ -155,7 +155,7 @@ __device__ __forceinline__ float pyrup_elem_patch(const float* __restrict__ patc
     return (dy & 1) ? ((r[1] + r[2]) * 4.f) * s : (r[0] + r[1] * 6.f + r[2]) * s;
 }
 
-constexpr int kC2Tx = 32, kC2Ty = 8;                    // tile of the output level, pixels
+constexpr int kC2Tx = 16, kC2Ty = 4;                    // tile of the output level, pixels
 constexpr int kC2Pw = kC2Tx / 2 + 2, kC2Pr = kC2Ty / 2 + 2;      // level k+1 under the tile plus the ring pyrUp reads: 18 x 6 pixels
 constexpr int kC2Ps = kC2Pw * 3 + 2;                    // its row stride in floats (padded)
 constexpr int kC2Nw = kC2Pw / 2 + 3, kC2Nr = kC2Pr / 2 + 3;      // level k+2 under that, plus its ring: 12 x 6 pixels (the region starts at an odd pixel)

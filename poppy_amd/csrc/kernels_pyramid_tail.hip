@@ -117,18 +117,28 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
     __syncthreads();
     TAIL_STAMP(1);
 
+    // A step's first output per thread has its descriptor (and the step's table entry) fetched BEFORE the barrier that ends the
+    // previous step: the kernel is a chain of short dependent steps, and those two reads were at the head of each.
+    auto down_desc = [&](const PyrTailDown& st, int e) { return s_desc[st.desc + (e >= st.c3 ? e - st.c3 : e)]; };       // L and R share the 3-channel descriptors
+    PyrTailDown nst = a.down[0];
+    uint4 nd = a.n_wide > 0 && tid < 2 * nst.c3 + nst.c1 ? down_desc(nst, tid) : uint4{0, 0, 0, 0};
     for (int k = 0; k < a.n_wide; ++k) {
-        const PyrTailDown st = a.down[k];
+        const PyrTailDown st = nst;
+        uint4 d = nd;
+        if (k + 1 < a.n_wide) nst = a.down[k + 1];
         for (int e = tid; e < 2 * st.c3 + st.c1; e += nth) {
+            if (e != tid) d = down_desc(st, e);
             const bool mask = e >= 2 * st.c3, right = e >= st.c3;
-            const uint4 d = s_desc[st.desc + (right ? e - st.c3 : e)];                 // L and R share the 3-channel descriptors
             float* plane = mask ? sM : right ? sR : sL;
             const float v = down_from_desc(plane + (mask ? st.so1 : st.so3), mask ? st.stride1 : st.stride3, d);
             plane[mask ? st.do1 + (e - 2 * st.c3) : st.do3 + (right ? e - st.c3 : e)] = v;
         }
+        if (k + 1 < a.n_wide && tid < 2 * nst.c3 + nst.c1) nd = down_desc(nst, tid);
         __syncthreads();
         TAIL_STAMP(2 + k);
     }
+    PyrTailUp nup = a.n_wide > 0 ? a.up[a.n_wide - 1] : PyrTailUp{0, 0, 0, 0, 0, 0};
+    uint4 nud = tid < nup.cnt ? s_desc[nup.desc + tid] : uint4{0, 0, 0, 0};
 
     if (a.nl >= 0) {
         // single-pixel levels k1 .. k1 + nl; chain values at (o3 + 3 j + channel), (o1 + j)
@@ -186,9 +196,11 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
     TAIL_STAMP(16);
 
     for (int k = a.n_wide - 1; k >= 0; --k) {
-        const PyrTailUp st = a.up[k];
+        const PyrTailUp st = nup;
+        uint4 d = nud;
+        if (k > 0) nup = a.up[k - 1];
         for (int e = tid; e < st.cnt; e += nth) {
-            const uint4 d = s_desc[st.desc + e];
+            if (e != tid) d = s_desc[st.desc + e];
             const unsigned form = d.y >> 22;
             UpForm f;
             f.f0 = form == 0; f.f2 = form == 2; f.f3 = form == 3; f.f4 = form == 4; f.odd = form == 1 || form == 4;
@@ -199,6 +211,7 @@ __global__ void __launch_bounds__(kTailThreads) k_pyr_tail(const float* __restri
             const float uB = up3_from_desc(sB + st.no3, st.nstride, d, f, oddy);
             sB[st.co3 + e] = uB + mix_lr(gl - uL, gr - uR, m);
         }
+        if (k > 0 && tid < nup.cnt) nud = s_desc[nup.desc + tid];
         __syncthreads();
         TAIL_STAMP(17 + k);
     }
