@@ -230,6 +230,10 @@ int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail
  * poppy_radial_gradient: draw_radial_gradiant2 (src/draw.cpp:40-59), host only.                                        */
 int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
 int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
+/* The two Gabor banks (src/util.cpp:31-61: filter2D per angle -> OCV/imgproc/src/templmatch.cpp:566-760, double-precision DFT
+ * correlation) run as tiled double-precision FFTs by default; on != 0 selects the direct double sums instead (same planes up to
+ * ~1e-15 relative before their rounding to float; the tests compare the two). */
+int poppy_hip_set_gabor_direct(poppy_hip_ctx* ctx, int on);
 int poppy_radial_gradient(int width, int height, float* out);
 /* Host only: the plan of the length-n transform dft_detail2's kernels run (pass order, load permutation, float twiddles; see
  * poppy_amd/csrc/dft_exact.cpp).  factors needs room for 34 ints, itab for n ints, wave for 2n floats.  For the test suite. */
@@ -297,6 +301,8 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* pool, int n_pairs, int width, int
 int poppy_hip_pool_set_timing(poppy_hip_pool* pool, int on);
 int poppy_hip_pool_timing_summary(poppy_hip_pool* pool, const char** names, float* total_ms, int* launches, int max);
 int poppy_hip_pool_warp_counts(poppy_hip_pool* pool, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general);
+/* poppy_hip_mask_rider of the pool's contexts (they share settings and geometry) */
+int poppy_hip_pool_mask_rider(poppy_hip_pool* pool);
 /* a poppy_write_pair_cb that only counts, atomically: ++*(long long*)user */
 void poppy_count_pair_frames_cb(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
 int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_settings* settings,

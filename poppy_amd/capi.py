@@ -31,10 +31,10 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
         L.poppy_hip_pair_begin_info.argtypes = [vp, vp, vp]
         L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
         L.poppy_hip_gabor_field.argtypes = [vp, vp, sz, i, i, vp]
+        L.poppy_hip_set_gabor_direct.argtypes = [vp, i]
         L.poppy_radial_gradient.argtypes = [i, i, vp]
         L.poppy_hip_blur_margin.argtypes = [vp, vp, sz, i, i, i, i, vp, sz]
         L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
@@ -101,6 +102,7 @@ def lib():
         L.poppy_dft_plan.argtypes = [i, vp, vp, vp, vp]
         L.poppy_hip_warp_counts.argtypes = [vp, vp, vp, vp]
         L.poppy_hip_mask_rider.argtypes = [vp]
+        L.poppy_hip_pool_mask_rider.argtypes = [vp]
         L.poppy_hip_pool_create.restype = C.c_void_p
         L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
         L.poppy_hip_pool_destroy.argtypes = [vp]
@@ -324,7 +326,7 @@ class Pool:
 
     def mask_rider(self):
         """True when the warp kernel also writes lbmask (else the level-0 blend kernels compute it from m2)."""
-        return lib().poppy_hip_mask_rider(self.h) == 1
+        return lib().poppy_hip_pool_mask_rider(self.h) == 1
 
     def warp_kernel_name(self):
         n = self.warp_counts()
@@ -546,6 +548,10 @@ class Context:
         self._chk(lib().poppy_hip_blur_margin(self.h, _p(a), w * 3, w, h, union_w, union_h, _p(out), union_w * 3), "blur_margin")
         return out
 
+    def set_gabor_direct(self, on=True):
+        """Gabor banks as direct double sums (True) or tiled FFTs (False, the default)."""
+        self._chk(lib().poppy_hip_set_gabor_direct(self.h, int(on)), "set_gabor_direct")
+
     def gabor_field(self, bgr):
         a = np.ascontiguousarray(bgr, np.uint8)
         h, w = a.shape[:2]
@@ -672,6 +678,10 @@ class Context:
         f, a, b = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
         lib().poppy_hip_warp_counts(self.h, C.byref(f), C.byref(a), C.byref(b))
         return f.value, a.value, b.value
+
+    def mask_rider(self):
+        """True when the warp kernel also writes lbmask (else the level-0 blend kernels compute it from m2)."""
+        return lib().poppy_hip_mask_rider(self.h) == 1
 
     def warp_kernel_name(self):
         n = self.warp_counts()

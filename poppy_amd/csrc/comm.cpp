@@ -333,6 +333,11 @@ int poppy_hip_pool_warp_counts(poppy_hip_pool* p, unsigned long long* fused, uns
     return POPPY_OK;
 }
 
+int poppy_hip_pool_mask_rider(poppy_hip_pool* p) {
+    if (!p || p->ctx.empty()) return POPPY_E_ARG;
+    return poppy_hip_mask_rider(p->ctx[0]);
+}
+
 int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings, int n_pairs,
                           int W, int H, double phase, poppy_pair_source_cb source, poppy_write_pair_cb write, void* user,
                           char* err, size_t err_len) {

@@ -34,6 +34,7 @@ public:
     int prepare(int w, int h) { return ensure(w, h); }
     std::string err;
 
+    bool gabor_direct = false;           // run the Gabor banks as direct double sums even when the FFT spectra exist (tests compare the two)
 private:
     int ensure(int w, int h);
     int ensure2(int w, int h);
@@ -42,6 +43,7 @@ private:
     int W2 = 0, H2 = 0, dftN = 0, dftM = 0;
     float *f_a = nullptr, *f_b = nullptr, *f_c = nullptr, *f_d = nullptr, *radial = nullptr, *taps17 = nullptr;
     double *bank31 = nullptr, *bank13 = nullptr;
+    double *fft31 = nullptr, *fft13 = nullptr;      // the banks' paired kernel spectra (kernels_gabor_fft.hip), null: direct sums only
     float *mag = nullptr, *c3_in = nullptr, *c3_out = nullptr;
     void* spec = nullptr;
     unsigned* minmax = nullptr;

@@ -1,0 +1,215 @@
+// kernels_gabor_fft.hip — the 16-orientation Gabor banks (Extractor::keypoints' 31 x 31 bank, gabor_filter's 13 x 13 x 3 bank) by
+// tiled double-precision FFTs instead of 15 376 (2 704) double multiply-adds per pixel.
+//
+//   src/util.cpp:31-61 (gabor_filter: filter2D per angle, clamp to [0, 1], mean of 16), src/extractor.cpp:63-71
+//   OCV/imgproc/src/filter.dispatch.cpp:1291-1292 -> OCV/imgproc/src/templmatch.cpp:566-760 (crossCorr, maxDepth CV_64F)
+//
+// For float images and a kernel this large the reference's filter2D IS an FFT correlation in double precision, rounded to float once
+// at the end; its planes equal the exact correlation sums up to the DFT's noise (~1e-13 relative).  The direct kernel
+// (kernels_prefilter2.hip: k_gabor_bank) forms those sums in double and is bound by the FP64 pipe (1.6 ms per 1080p image, half of the
+// pair set-up's exclusive GPU time together with the second image's).  Here the same sums come from 64 x 64 FFTs, overlap-save:
+//   a workgroup owns a block of B x B output pixels, B = 64 - ks + 1 (34 for the 31 x 31 bank), and the 64 x 64 input patch around it;
+//   forward 2-D FFT of the patch (reflect-101 borders as filter2D's BORDER_DEFAULT);
+//   per PAIR of orientations (a, b): spectrum x (conj K_a^ + i conj K_b^) / 4096, inverse 2-D FFT: the real part is orientation a's
+//   plane, the imaginary part orientation b's (both are real) — 8 inverse transforms serve the 16 orientations;
+//   clamp, accumulate in float in the reference's order (a then b), write mean.
+// A 64-point transform is two passes of 8-point butterflies held in registers (64 = 8 x 8) with the twiddle W64^(n2 k1) between
+// them; a pass reads 8 values of a line from LDS and writes them back in place.  The forward transform leaves frequency
+// k1 + 8 k2 at position 8 k1 + k2; the kernel spectra are stored in that order and the inverse transform consumes it.
+// ~2.3 kFLOP per pixel instead of 30.7 k.  Error: ~1e-15 relative to the magnitude of the sums, two orders below the reference's
+// own DFT noise; the planes are rounded to float afterwards, so the output differs from the direct sums only where an exact sum lies
+// within that distance of a float rounding boundary (none on the fixtures; tests/test_gpu_prefilter2.py compares the two paths).
+#include "kernels_prefilter.h"
+#include "pyramid_device.h"
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace poppy_hip {
+
+namespace {
+
+typedef double cd __attribute__((ext_vector_type(2)));       // (re, im)
+constexpr int kFN = 64;                                       // transform size
+constexpr int kFS = 65;                                       // LDS row stride in elements: lanes that walk 16 consecutive lines hit 16 different 16-byte slots
+constexpr double kSqrtHalf = 0.70710678118654752440;
+
+__constant__ double c_w64[2 * kFN];                           // W64^m = exp(-2 pi i m / 64) as (cos, -sin)
+
+__device__ __forceinline__ cd cmul(cd a, cd w) { return cd{fma(a.x, w.x, -(a.y * w.y)), fma(a.x, w.y, a.y * w.x)}; }
+// multiplication by SIGN * i
+template <int SIGN> __device__ __forceinline__ cd rot90(cd a) { return SIGN < 0 ? cd{a.y, -a.x} : cd{-a.y, a.x}; }
+
+template <int SIGN>
+__device__ __forceinline__ void fft4(cd y0, cd y1, cd y2, cd y3, cd& Y0, cd& Y1, cd& Y2, cd& Y3) {
+    const cd t0 = y0 + y2, t1 = y0 - y2, t2 = y1 + y3, t3 = rot90<SIGN>(y1 - y3);
+    Y0 = t0 + t2; Y2 = t0 - t2; Y1 = t1 + t3; Y3 = t1 - t3;
+}
+// X[k] = sum_n v[n] exp(SIGN 2 pi i n k / 8), natural order in and out
+template <int SIGN>
+__device__ __forceinline__ void fft8(cd (&v)[8]) {
+    cd E[4], O[4];
+    fft4<SIGN>(v[0], v[2], v[4], v[6], E[0], E[1], E[2], E[3]);
+    fft4<SIGN>(v[1], v[3], v[5], v[7], O[0], O[1], O[2], O[3]);
+    const cd w1 = cd{kSqrtHalf, SIGN * kSqrtHalf}, w3 = cd{-kSqrtHalf, SIGN * kSqrtHalf};
+    O[1] = cmul(O[1], w1); O[2] = rot90<SIGN>(O[2]); O[3] = cmul(O[3], w3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = E[k] + O[k]; v[k + 4] = E[k] - O[k]; }
+}
+
+// One pass over all 64 lines of the 64 x 64 array: 512 jobs (line, g), two per thread; a job transforms the 8 elements
+// {8 i + g} (STRIDED) or {8 g + i} of its line in place and, with TWIDDLE, multiplies output i by W64^(SIGN g i).
+// COLS: the lines are the columns.  A wave's 64 lanes are 64 consecutive lines with one g.
+template <int SIGN, bool STRIDED, bool TWIDDLE, bool COLS>
+__device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int q = tid + 256 * s;
+        const int line = q & 63, g = __builtin_amdgcn_readfirstlane(q >> 6);
+        cd v[8];
+        int at[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = STRIDED ? 8 * i + g : 8 * g + i;
+            at[i] = COLS ? idx * kFS + line : line * kFS + idx;
+            v[i] = L[at[i]];
+        }
+        fft8<SIGN>(v);
+        if (TWIDDLE) {
+#pragma unroll
+            for (int i = 1; i < 8; ++i) {
+                const int m = (g * i) & 63;
+                v[i] = cmul(v[i], cd{c_w64[2 * m], SIGN < 0 ? c_w64[2 * m + 1] : -c_w64[2 * m + 1]});
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L[at[i]] = v[i];
+    }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) k_gabor_fft(const float* __restrict__ src, const cd* __restrict__ G, float* __restrict__ dst,
+                                                   int W, int H, int CN, int tiles_x) {
+    constexpr int R = KS / 2, B = kFN - KS + 1, kOut = (B * B + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];      // 64 x 65 complex doubles: just over the static 64 KB limit
+    cd* const L = (cd*)lds_raw;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, ch = blockIdx.y;
+    const int bx = tx * B, by = ty * B;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, y = e >> 6, x = e & 63;
+        const float v = src[((size_t)reflect101(by - R + y, H) * W + reflect101(bx - R + x, W)) * CN + ch];
+        L[y * kFS + x] = cd{(double)v, 0.0};
+    }
+    __syncthreads();
+    fft_pass<-1, true, true, false>(L, tid);  __syncthreads();
+    fft_pass<-1, false, false, false>(L, tid); __syncthreads();
+    fft_pass<-1, true, true, true>(L, tid);   __syncthreads();
+    fft_pass<-1, false, false, true>(L, tid);  __syncthreads();
+    cd P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int e = tid + 256 * i; P[i] = L[(e >> 6) * kFS + (e & 63)]; }
+    float acc[kOut];
+#pragma unroll
+    for (int i = 0; i < kOut; ++i) acc[i] = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        __syncthreads();                                    // the previous pair's planes (or the spectrum) have been read
+        const cd* Gj = G + (size_t)j * (kFN * kFN);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = tid + 256 * i; L[(e >> 6) * kFS + (e & 63)] = cmul(P[i], Gj[e]); }
+        __syncthreads();
+        fft_pass<1, false, true, true>(L, tid);   __syncthreads();
+        fft_pass<1, true, false, true>(L, tid);   __syncthreads();
+        fft_pass<1, false, true, false>(L, tid);  __syncthreads();
+        fft_pass<1, true, false, false>(L, tid);  __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kOut; ++i) {
+            const int o = tid + 256 * i;
+            if (o < B * B) {
+                const int ny = o / B, nx = o - ny * B;
+                const cd c = L[ny * kFS + nx];
+                acc[i] += fminf(fmaxf((float)c.x, 0.f), 1.f);            // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
+                acc[i] += fminf(fmaxf((float)c.y, 0.f), 1.f);            // ... orientation 2 j, then 2 j + 1
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kOut; ++i) {
+        const int o = tid + 256 * i;
+        if (o < B * B) {
+            const int ny = o / B, nx = o - ny * B;
+            const int x = bx + nx, y = by + ny;
+            if (x < W && y < H) dst[((size_t)y * W + x) * CN + ch] = acc[i] * 0.0625f;   // dst /= 16
+        }
+    }
+}
+
+int perm64(int p) { return (p >> 3) + 8 * (p & 7); }         // the frequency held at position p after the forward transform
+
+}  // namespace
+
+// Spectra of the 16 kernels of a bank (`bank`: [orientation][ks * ks] floats, tap (dy, dx) multiplies the pixel at (x + dx - ks/2,
+// y + dy - ks/2)), paired, conjugated (correlation), scaled by 1/4096 and stored in the transform's position order:
+// 8 x 4096 complex doubles.  Computed once per context on the host, in long double.
+std::vector<double> gabor_fft_tables(const std::vector<float>& bank, int ks) {
+    std::vector<double> out((size_t)8 * kFN * kFN * 2);
+    std::vector<long double> cs(kFN), sn(kFN);
+    for (int m = 0; m < kFN; ++m) { cs[m] = cosl(2.0L * M_PIl * m / kFN); sn[m] = sinl(2.0L * M_PIl * m / kFN); }
+    std::vector<long double> hr((size_t)16 * kFN * kFN), hi((size_t)16 * kFN * kFN);
+    std::vector<long double> rr((size_t)ks * kFN), ri((size_t)ks * kFN);
+    for (int o = 0; o < 16; ++o) {
+        const float* K = &bank[(size_t)o * ks * ks];
+        for (int dy = 0; dy < ks; ++dy)                       // along x first
+            for (int kc = 0; kc < kFN; ++kc) {
+                long double a = 0, b = 0;
+                for (int dx = 0; dx < ks; ++dx) { const int m = (kc * dx) & (kFN - 1); a += (long double)K[dy * ks + dx] * cs[m]; b -= (long double)K[dy * ks + dx] * sn[m]; }
+                rr[(size_t)dy * kFN + kc] = a; ri[(size_t)dy * kFN + kc] = b;
+            }
+        for (int kr = 0; kr < kFN; ++kr)
+            for (int kc = 0; kc < kFN; ++kc) {
+                long double a = 0, b = 0;
+                for (int dy = 0; dy < ks; ++dy) {
+                    const int m = (kr * dy) & (kFN - 1);
+                    const long double c = cs[m], s = -sn[m], xr = rr[(size_t)dy * kFN + kc], xi = ri[(size_t)dy * kFN + kc];
+                    a += xr * c - xi * s; b += xr * s + xi * c;
+                }
+                hr[((size_t)o * kFN + kr) * kFN + kc] = a; hi[((size_t)o * kFN + kr) * kFN + kc] = b;
+            }
+    }
+    const long double scale = 1.0L / (kFN * kFN);
+    for (int j = 0; j < 8; ++j)
+        for (int r = 0; r < kFN; ++r)
+            for (int c = 0; c < kFN; ++c) {
+                const size_t f = (size_t)perm64(r) * kFN + perm64(c);
+                const long double ar = hr[(size_t)(2 * j) * kFN * kFN + f], ai = -hi[(size_t)(2 * j) * kFN * kFN + f];          // conj
+                const long double br = hr[(size_t)(2 * j + 1) * kFN * kFN + f], bi = -hi[(size_t)(2 * j + 1) * kFN * kFN + f];
+                // conj(Ka) + i conj(Kb)
+                out[(((size_t)j * kFN + r) * kFN + c) * 2] = (double)((ar - bi) * scale);
+                out[(((size_t)j * kFN + r) * kFN + c) * 2 + 1] = (double)((ai + br) * scale);
+            }
+    return out;
+}
+
+constexpr size_t kFftLds = (size_t)kFN * kFS * sizeof(cd);
+
+bool gabor_fft_prepare() {                                     // the twiddle table and the kernels' LDS limit on this device (idempotent)
+    double w[2 * kFN];
+    for (int m = 0; m < kFN; ++m) { w[2 * m] = (double)cosl(2.0L * M_PIl * m / kFN); w[2 * m + 1] = (double)-sinl(2.0L * M_PIl * m / kFN); }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_w64), w, sizeof(w)) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_gabor_fft<31>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLds) != hipSuccess) return false;
+    return hipFuncSetAttribute((const void*)k_gabor_fft<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLds) == hipSuccess;
+}
+
+void launch_gabor_fft31(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s) {
+    constexpr int B = kFN - 31 + 1;
+    const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
+    hipLaunchKernelGGL(k_gabor_fft<31>, dim3(tiles_x * tiles_y, 1), dim3(256), kFftLds, s, src, (const cd*)d_tables, dst, w, h, 1, tiles_x);
+}
+void launch_gabor_fft13_c3(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s) {
+    constexpr int B = kFN - 13 + 1;
+    const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
+    hipLaunchKernelGGL(k_gabor_fft<13>, dim3(tiles_x * tiles_y, 3), dim3(256), kFftLds, s, src, (const cd*)d_tables, dst, w, h, 3, tiles_x);
+}
+
+}  // namespace poppy_hip

@@ -1,6 +1,7 @@
 // kernels_prefilter.h — launch wrappers of kernels_prefilter.hip (Extractor::foreground, src/extractor.cpp:136-229).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
@@ -46,6 +47,12 @@ void launch_unsharp1_gray(const uint8_t* gf, float* f32, float* tmp, float* diff
 // 31x31 on one channel, 13x13 on three
 void launch_gabor_bank31(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s);
 void launch_gabor_bank13_c3(const float* src, const double* d_bank, float* dst, int w, int h, hipStream_t s);
+// The same banks by tiled 64 x 64 double-precision FFTs (kernels_gabor_fft.hip).  gabor_fft_tables: the paired, conjugated kernel
+// spectra of a bank ([orientation][ks * ks] floats), 8 x 4096 complex doubles, computed on the host; gabor_fft_prepare: per device.
+std::vector<double> gabor_fft_tables(const std::vector<float>& bank, int ks);
+bool gabor_fft_prepare();
+void launch_gabor_fft31(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s);
+void launch_gabor_fft13_c3(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s);
 void launch_u8_to_f32(const uint8_t* src, float* dst, int n, hipStream_t s);
 // out = equalizeHist(u8(gb * us * radial * 255))
 void launch_orb_input(const float* gb, const float* us, const float* radial, uint8_t* tmp_u8, unsigned* hist, uint8_t* lut, uint8_t* out,

@@ -346,6 +346,13 @@ int poppy_hip_orb_input(poppy_hip_ctx* c, const uint8_t* good_features, int W, i
     return POPPY_OK;
 }
 
+// 1: the Gabor banks as direct double-precision sums (kernels_prefilter2.hip), 0 (default): by tiled FFTs (kernels_gabor_fft.hip)
+int poppy_hip_set_gabor_direct(poppy_hip_ctx* c, int on) {
+    if (!c) return POPPY_E_ARG;
+    c->foreground.gabor_direct = c->foreground_b.gabor_direct = on != 0;
+    return POPPY_OK;
+}
+
 // gabor_filter(bgr / 255) with the default arguments (host in / out, f32x3)
 int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, float* out) {
     if (!c || !bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return POPPY_E_ARG;

@@ -101,6 +101,31 @@ def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
     assert np.array_equal(r["gb"].view(np.uint32), gb.view(np.uint32))             # both: exact products, double sums, one rounding
 
 
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 5), (1001, 333, 6), (1920, 1080, 7)])
+def test_gabor_banks_fft_vs_direct_sums(ctx, w, h, seed):
+    """The two forms of the Gabor banks (tiled double-precision FFTs, the default; direct double sums) give the same float planes:
+    both evaluate the reference's double-precision correlation, ~1e-15 apart before the one rounding to float (the reference's own
+    DFT noise is ~1e-13).  A plane value differs by one float ulp where the exact sum sits within that distance of a rounding
+    boundary: measured 1 value in 1.3e8 over these three sizes (the 13 x 13 bank at 1920x1080), so: at most 3 per 1e8 values, each at
+    most one ulp of a plane (2^-24) / 16 in the mean, and the quantised image that follows (ORB input) identical."""
+    from poppy_amd import synth
+    gf = synth.textured_gray(w, h, seed)
+    bgr = synth.textured_bgr(w, h, seed + 100)
+    try:
+        ctx.set_gabor_direct(False)
+        a, fa = ctx.orb_input(gf), ctx.gabor_field(bgr)
+        ctx.set_gabor_direct(True)
+        b, fb = ctx.orb_input(gf), ctx.gabor_field(bgr)
+    finally:
+        ctx.set_gabor_direct(False)
+    n31 = int((a["gb"].view(np.uint32) != b["gb"].view(np.uint32)).sum())
+    n13 = int((fa.view(np.uint32) != fb.view(np.uint32)).sum())
+    d31, d13 = float(np.abs(a["gb"] - b["gb"]).max()), float(np.abs(fa - fb).max())
+    assert n31 <= max(1, 3e-8 * 16 * a["gb"].size) and n13 <= max(1, 3e-8 * 16 * fa.size), (n31, n13, d31, d13)
+    assert d31 <= 2.0 ** -24 / 16 and d13 <= 2.0 ** -24 / 16, (n31, n13, d31, d13)
+    assert np.array_equal(a["g"], b["g"])
+
+
 @pytest.mark.parametrize("case", sorted(G.make_inputs.DETAIL))
 def test_dft_detail2_exact(ctx, case):
     """dft_detail2 is the RMS of raw float bytes of the spectrum: only cv::dft's exact operation order reproduces it."""

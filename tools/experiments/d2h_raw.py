@@ -6,7 +6,8 @@ n = 1920 * 1080 * 3
 def mk():
     d = ctypes.c_void_p(); h = ctypes.c_void_p(); s = ctypes.c_void_p()
     assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(n)) == 0
-    assert hip.hipHostMalloc(ctypes.byref(h), ctypes.c_size_t(n), 0) == 0
+    import os
+    assert hip.hipHostMalloc(ctypes.byref(h), ctypes.c_size_t(n), int(os.environ.get("D2H_HOST_FLAGS", "0"))) == 0
     assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
     return d, h, s
 A, B = mk(), mk()
