@@ -22,7 +22,9 @@ One JSON line on rank 0 (driver contract) with
   roofline      the dominant kernel (fused create_map + remap of both sources): algorithmic bytes per launch = 16 B/px (SURVEY.md
                 8d, faithful path: id 4 + src 3 + 3 in, warped 3 + 3 out) x pixels, / the kernel's average launch duration
                 measured live with HIP events attached to the dispatch on the library's stream (one launch in seven of the timed
-                region); `frac_with_rider` adds the 8 B/px of the lbmask the kernel also produces (m2 in, mask out);
+                region).  The kernel moves LESS than the contract counts: no id map (the raster reaches it as per-tile row masks,
+                ~1.3 B/px) and no blend mask (the level-0 blend kernels derive it from m2) — 12 B/px of images; `moved_*` states
+                that.  Only when the mask rider is on (POPPY_HIP_LBMASK_RIDER) `frac_with_rider` adds its 8 B/px;
   cpu_baseline  oracle/ (CPU restatement, "port", 1 thread) on 20 chained frames of pair 0 from the GPU's own pair state;
   parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected);
   cfg3_4k       configs[2]: one 3840x2160 pair, 120 phase-mode frames, set-up and writer hand-off included, with its own roofline.
@@ -52,7 +54,7 @@ WARP_RIDER_B_PER_PX = 8.0      # m2 in, lbmask out (the kernel computes the blen
 
 # algorithmic HBM bytes per frame of each kernel group, per full-resolution pixel
 ALGO_BYTES_PER_PX = {
-    "upload+clear": 0.0, "raster": 4.0, "warp": WARP_CONTRACT_B_PER_PX + WARP_RIDER_B_PER_PX,
+    "upload+clear": 0.0, "raster": 4.0, "warp": WARP_CONTRACT_B_PER_PX,
     "pyrdown": (6 + 4) + (24 + 4) / 4 * (4 / 3), "pyr_tail": 0.0,
     "collapse": (6 + 4 + 12) + (36 / 4) * (4 / 3) + 12 * (1 / 3), "unsharp": 12 + 3,
 }
@@ -77,7 +79,7 @@ def measured_traffic(kernel, w, h):
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
             return None, "no counter pass for this kernel / size in profiles/r02_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_k_pmc.md)"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_t_pmc.md)"
     except (OSError, ValueError, KeyError):
         return None, "profiles/r02_warp_pmc.json missing"
 
@@ -86,15 +88,22 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
     per_launch_ms = warp_ms / max(warp_n, 1)
     P = w * h
     contract = WARP_CONTRACT_B_PER_PX * P
-    ach = contract / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-    ach_r = (WARP_CONTRACT_B_PER_PX + WARP_RIDER_B_PER_PX) * P / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": ctx.warp_kernel_name() + " (fused create_map + remap of both sources; also emits lbmask)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "algo_bytes_per_launch": int(contract), "algo_bytes_note": "16 B/px x pixels (SURVEY.md 8d faithful path)",
-            "achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4),
-            "avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
-            "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
-            **dict(zip(("traffic", "traffic_source"), measured_traffic(ctx.warp_kernel_name(), w, h)))}
+    rate = lambda b: b / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    ach = rate(contract)
+    rider = bool(ctx.mask_rider())
+    out = {"bound": "hbm", "kernel": ctx.warp_kernel_name() + " (fused create_map + remap of both sources" + ("; also emits lbmask)" if rider else ")"),
+           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+           "algo_bytes_per_launch": int(contract), "algo_bytes_note": "16 B/px x pixels (SURVEY.md 8d faithful path: id 4 + src 3 + 3 in, warped 3 + 3 out)"}
+    if rider:
+        ach_r = rate((WARP_CONTRACT_B_PER_PX + WARP_RIDER_B_PER_PX) * P)
+        out.update({"achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4)})
+    else:
+        out.update({"moved_image_bytes_per_launch": int(12 * P), "moved_GBps": round(rate(12.0 * P), 1),
+                    "moved_note": "what the kernel itself reads and writes: c1 3 + c2 3 in, tr1 3 + tr2 3 out = 12 B/px (+ ~1.3 B/px of raster row masks and records); no id map, no blend mask"})
+    out.update({"avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
+                "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
+                **dict(zip(("traffic", "traffic_source"), measured_traffic(ctx.warp_kernel_name(), w, h)))})
+    return out
 
 
 def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):

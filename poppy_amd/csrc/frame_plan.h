@@ -60,7 +60,8 @@ int plan_frame(int w, int h, const std::vector<P2f>& src1, const std::vector<P2f
 // An all-zero matrix (singular triangle, lapack.cpp:1044-1045) gets h8 = 1e-5f, which is what create_map substitutes for
 // its z = 0 (algo.cpp:166-167).  Returns false when some matrix could take the kernel's bare division sequence outside the
 // range where it equals IEEE division (non-finite or > 2^40 entries, or a denominator h6*x + h7*y + h8 that can leave
-// [2^-20, 2^20] in magnitude or change sign over the image); such frames use the general kernel.
+// [2^-20, 2^20] in magnitude or change sign over the pixels that use the record: the bounding box of the triangle's integer
+// corners `tri_xy`, or the whole image without them); such frames use the general kernel.
 constexpr int kWarpRecordFloats = 20;
 bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, int h, float* records, const int* tri_xy = nullptr);
 
