@@ -207,6 +207,7 @@ __device__ __forceinline__ void med_update(char* __restrict__ lane_base, uint32_
 // lane reads its window row as plain unaligned dwords without clamping; rows are clamped through the row pointer.
 constexpr int kMedPad = 48;                                 // >= 44 (ksize 89) + 3 spare bytes for the last dword
 constexpr int kMedMaxDw = 23;                               // dwords covering 89 bytes: the largest instantiation
+constexpr int kMedWavesLong = 4;                            // waves per histogram set for rows of 4 dwords and more (1 / 2 / 4 measured per ksize: profiles/r02_notes.md 6.9)
 
 __global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
     const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -216,37 +217,43 @@ __global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ sr
 }
 
 // NDW = dwords per window row, a template parameter (ksize = 8 i + 1 -> NDW = 2 i + 1, one byte used of the last dword): with
-// a run-time count the unrolled update loops are chopped into basic blocks by uniform branches, and a kernel that runs ONE wave
-// per SIMD (LDS capacity) needs its ~12 instructions per value interleaved across values to hide their latencies.
-template <int NDW>
-__global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
-                                                         int ksize, int rows_per_block) {
-    __shared__ uint32_t hist[kMedWords * kMedLanes];
-    const int lane = threadIdx.x;
+// a run-time count the unrolled update loops are chopped into basic blocks by uniform branches.
+// NW = waves that SHARE one set of 64 histograms (a workgroup of NW waves): wave w applies the dwords i = w (mod NW) of every
+// window row, all waves search (wave 0 writes).  The kernel is bound by LDS capacity to 4 histogram sets per CU; with one wave
+// per set a SIMD holds a single wave, which pays the full latency of every instruction it issues (its time follows its
+// instruction count: without the coarse-histogram atomic 30-36 % less, with three more vector instructions per value 25 % more,
+// profiles/r02_notes.md 6.7).  Two waves per set put two waves on every SIMD, each with half the updates; the price is two
+// workgroup barriers per row step (updates | search | updates) and the search done twice.  Counts cannot go negative whatever the
+// order of the two waves' atomics: a value removed in a step is in the window at its start.
+template <int NDW, int NW, int WV>
+__device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
+                                            int ksize, int rows_per_block) {
+    const int lane = threadIdx.x & (kMedLanes - 1);
     const int x = blockIdx.x * kMedLanes + lane;
     const int y_begin = blockIdx.y * rows_per_block, y_end = min(y_begin + rows_per_block, H);
     const int r = ksize >> 1, half = (ksize * ksize) >> 1;
     const int Wp = W + 2 * kMedPad;
-    for (int b = 0; b < kMedWords; ++b) hist[b * kMedLanes + lane] = 0;
+    for (int b = WV; b < kMedWords; b += NW) hist[b * kMedLanes + lane] = 0;
+    if (NW > 1) __syncthreads();
     char* const hist_b = reinterpret_cast<char*>(hist);
     char* const lane_base = hist_b + (lane & 31) * 4;         // the dword lanes l and l + 32 share, in bin 0
     const uint32_t unit = 1u << ((lane >> 5) << 4);           // +1 in this lane's half of it
     auto count_of = [&](int bin) {
         return (int)*reinterpret_cast<const uint16_t*>(hist_b + bin * kMedBinBytes + (lane & 31) * 4 + (lane >> 5) * 2);
     };
-    const bool live = x < W;                                  // lanes past the right edge idle along (no barriers in here)
+    const bool live = x < W;                                  // lanes past the right edge idle along
     const int xc = live ? x : W - 1;
     constexpr int ndw = NDW;                                  // dwords per window row (the last one is partly used)
     const int tail = ksize - 4 * (ndw - 1);                   // bytes used of the last dword (1 for the ksizes of the chain)
     auto row_ptr = [&](int yy) { return srcp + (size_t)min(max(yy, 0), H - 1) * Wp + (kMedPad + xc - r); };
-    auto load_row = [&](const uint8_t* p, uint32_t* regs) {
+    auto load_row = [&](const uint8_t* p, uint32_t* regs) {   // this wave's dwords of the row
 #pragma unroll
-        for (int i = 0; i < NDW; ++i)
+        for (int i = WV; i < NDW; i += NW)
             __builtin_memcpy(&regs[i], p + 4 * i, 4);
     };
     auto apply_row = [&](const uint32_t* regs, bool add) {
 #pragma unroll
-        for (int i = 0; i < NDW; ++i) {
+        for (int i = WV; i < NDW; i += NW) {
             {
                 const int nb = (i == ndw - 1) ? tail : 4;
 #pragma unroll
@@ -261,12 +268,13 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
     for (int yy = y_begin - r; yy <= y_begin + r; ++yy) {
         uint32_t cur[NDW];
 #pragma unroll
-        for (int i = 0; i < NDW; ++i) cur[i] = ra[i];
+        for (int i = WV; i < NDW; i += NW) cur[i] = ra[i];
         if (yy < y_begin + r) load_row(row_ptr(yy + 1), ra);
         apply_row(cur, true);
     }
     if (y_begin + 1 < y_end) { load_row(row_ptr(y_begin + r + 1), ra); load_row(row_ptr(y_begin - r), rs); }
     for (int y = y_begin; y < y_end; ++y) {
+        if (NW > 1) __syncthreads();                          // every wave's updates of this window are in
         int s = 0, cb = 0, below = 0;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {                        // first coarse bin whose cumulative count exceeds `half`
@@ -282,16 +290,30 @@ __global__ void __launch_bounds__(kMedLanes) k_median_u8(const uint8_t* __restri
             s += count_of(cb * 16 + k);
             fb += (s > half) ? 0 : 1;
         }
-        if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
+        if (live && WV == 0) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
+        if (NW > 1) __syncthreads();                          // every wave has read the window's counts
         if (y + 1 < y_end) {
             uint32_t ca[NDW], cs[NDW];
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) { ca[i] = ra[i]; cs[i] = rs[i]; }
+            for (int i = WV; i < NDW; i += NW) { ca[i] = ra[i]; cs[i] = rs[i]; }
             if (y + 2 < y_end) { load_row(row_ptr(y + r + 2), ra); load_row(row_ptr(y + 1 - r), rs); }   // rows of the NEXT step
             apply_row(ca, true);
             apply_row(cs, false);
         }
     }
+}
+
+template <int NDW, int NW>
+__global__ void __launch_bounds__(kMedLanes * NW) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
+                                                              int ksize, int rows_per_block) {
+    __shared__ uint32_t hist[kMedWords * kMedLanes];
+    static_assert(NW == 1 || NW == 2 || NW == 4, "waves per histogram set");
+    static_assert(NW <= NDW, "every wave needs a dword of the row");
+    const int wv = threadIdx.x >> 6;
+    if (NW == 1 || wv == 0) median_body<NDW, NW, 0>(hist, srcp, dst, W, H, ksize, rows_per_block);
+    else if (NW == 2 || wv == 1) median_body<NDW, NW, 1 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
+    else if (wv == 2) median_body<NDW, NW, 2 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
+    else median_body<NDW, NW, 3 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
 }
 void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
     const int wp = w + 2 * kMedPad;
@@ -304,12 +326,17 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
     const int ndw = (ksize + 3) >> 2;
-#define MED(N) case N: hipLaunchKernelGGL(k_median_u8<N>, dim3(col_blocks, segs), dim3(kMedLanes), 0, s, padded_tmp, dst, w, h, ksize, rows); break;
+    // waves per histogram set: POPPY_MED_WAVES forces 1 / 2 / 4 (experiments); default by row length
+    static const int forced = getenv("POPPY_MED_WAVES") ? atoi(getenv("POPPY_MED_WAVES")) : 0;
+    const int nw = forced == 1 || ndw < 2 ? 1 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 4 ? kMedWavesLong : 1);
+#define MEDW(N, NWV) hipLaunchKernelGGL((k_median_u8<N, NWV>), dim3(col_blocks, segs), dim3(kMedLanes * NWV), 0, s, padded_tmp, dst, w, h, ksize, rows)
+#define MED(N) case N: if (nw == 4) MEDW(N, (N >= 4 ? 4 : 1)); else if (nw == 2) MEDW(N, (N >= 2 ? 2 : 1)); else MEDW(N, 1); break;
     switch (ndw) {
         MED(1) MED(2) MED(3) MED(4) MED(5) MED(6) MED(7) MED(8) MED(9) MED(10) MED(11) MED(12) MED(13) MED(14) MED(15) MED(16)
         MED(17) MED(18) MED(19) MED(20) MED(21) MED(22) MED(23)
         default: static_assert(kMedMaxDw == 23, "instantiations cover 1..23"); break;   // ksize > 89 is rejected by the caller
     }
+#undef MEDW
 #undef MED
 }
 size_t median_padded_bytes(int w, int h) { return (size_t)(w + 2 * kMedPad) * h + 16; }
