@@ -95,62 +95,95 @@ __device__ __forceinline__ bool run9(unsigned m) {       // 16-bit circular mask
     return (a & 0xFFFFu) != 0;
 }
 
+constexpr int kFastRows = 4;      // rows of one level per block: the grid spans the LARGEST level, so most blocks of the small levels fall outside their
+                                  // level and only cost their dispatch; fewer, taller blocks cut that four-fold
+
 __global__ void __launch_bounds__(256) k_fast_score(const uint8_t* __restrict__ atlas, OrbLevelSet S, uint8_t* __restrict__ scores, int threshold) {
     const OrbLevel L = S.lv[blockIdx.z];
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= L.w || y >= L.h) return;
-    uint8_t result = 0;
-    if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-        const uint8_t* c = atlas + L.offset + (size_t)(y + kOrbBorder) * L.stride + (x + kOrbBorder);
-        int v = c[0];
-        int d[16];
-        unsigned dark = 0, bright = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            d[k] = v - (int)c[c_ring[k][1] * (int)L.stride + c_ring[k][0]];
-            dark |= (unsigned)(d[k] > threshold) << k;          // ring < v - t
-            bright |= (unsigned)(d[k] < -threshold) << k;       // ring > v + t
-        }
-        if (run9(dark) || run9(bright)) {
-            int best_min = -1000, best_max = 1000;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= L.w) return;
+    for (int rr = 0; rr < kFastRows; ++rr) {
+        const int y = blockIdx.y * kFastRows + rr;
+        if (y >= L.h) return;
+        uint8_t result = 0;
+        if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+            const uint8_t* c = atlas + L.offset + (size_t)(y + kOrbBorder) * L.stride + (x + kOrbBorder);
+            int v = c[0];
+            int d[16];
+            unsigned dark = 0, bright = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                int mn = d[k], mx = d[k];
-#pragma unroll
-                for (int j = 1; j < 9; ++j) { int e = d[(k + j) & 15]; mn = min(mn, e); mx = max(mx, e); }
-                best_min = max(best_min, mn);
-                best_max = min(best_max, mx);
+                d[k] = v - (int)c[c_ring[k][1] * (int)L.stride + c_ring[k][0]];
+                dark |= (unsigned)(d[k] > threshold) << k;          // ring < v - t
+                bright |= (unsigned)(d[k] < -threshold) << k;       // ring > v + t
             }
-            result = (uint8_t)(max(best_min, -best_max) - 1);
+            if (run9(dark) || run9(bright)) {
+                int best_min = -1000, best_max = 1000;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    int mn = d[k], mx = d[k];
+#pragma unroll
+                    for (int j = 1; j < 9; ++j) { int e = d[(k + j) & 15]; mn = min(mn, e); mx = max(mx, e); }
+                    best_min = max(best_min, mn);
+                    best_max = min(best_max, mx);
+                }
+                result = (uint8_t)(max(best_min, -best_max) - 1);
+            }
         }
+        scores[L.score_offset + (size_t)y * L.w + x] = result;
     }
-    scores[L.score_offset + (size_t)y * L.w + x] = result;
 }
 
-// strict 3x3 maximum + border filter; survivors appended unordered: (level, y*w + x, score)
+// strict 3x3 maximum + border filter; survivors appended unordered: (level, y*w + x, score).
+// A block takes 256 columns x kNmsRows rows of a level and claims its survivors' slots with ONE atomic: ~10^5 survivors per 1080p image
+// on the eight per-level counters were the kernel (one atomic per wave: 343 us; per block: the kernel is its ~3 MB of score reads).
+constexpr int kNmsRows = 8;
+
 __global__ void __launch_bounds__(256) k_fast_nms(const uint8_t* __restrict__ scores, OrbLevelSet S, int edge, int* __restrict__ counters,
                                                   int* __restrict__ cand, int cap) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
     const int lvl = blockIdx.z;
     const OrbLevel L = S.lv[lvl];
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (L.w <= 2 * edge || L.h <= 2 * edge) return;
-    if (x < edge || x >= L.w - edge || y < edge || y >= L.h - edge) return;
-    const uint8_t* p = scores + L.score_offset + (size_t)y * L.w + x;
-    int s = p[0];
-    int W = L.w;
-    const bool keep = s != 0 && s > p[-1] && s > p[1] && s > p[-W - 1] && s > p[-W] && s > p[-W + 1] && s > p[W - 1] && s > p[W] && s > p[W + 1];
-    // one atomic per WAVE: the survivors of a wave take consecutive slots (the order inside a level is restored on the host anyway);
-    // ~10^5 survivors per image on one counter were the whole kernel (363 us at 1080p)
-    const unsigned long long vote = __builtin_amdgcn_ballot_w64(keep);
-    if (vote == 0) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __builtin_ctzll(vote)) base = atomicAdd(&counters[lvl], __builtin_popcountll(vote));
-    base = __shfl(base, __builtin_ctzll(vote));
-    if (keep) {
-        const int slot = base + __builtin_popcountll(vote & ((1ull << lane) - 1ull));
-        if (slot < cap) { cand[((size_t)lvl * cap + slot) * 2] = y * W + x; cand[((size_t)lvl * cap + slot) * 2 + 1] = s; }
+    const int W = L.w;
+    if (W <= 2 * edge || L.h <= 2 * edge) return;                         // uniform
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * kNmsRows;
+    if (y0 >= L.h - edge || y0 + kNmsRows <= edge || (int)(blockIdx.x * blockDim.x) >= W - edge) return;       // uniform: nothing of this block can survive
+    const bool col_ok = x >= edge && x < W - edge;
+    unsigned keep = 0;                                                   // bit r: row y0 + r survives
+    int sc[kNmsRows];
+#pragma unroll
+    for (int r = 0; r < kNmsRows; ++r) {
+        const int y = y0 + r;
+        sc[r] = 0;
+        if (col_ok && y >= edge && y < L.h - edge) {
+            const uint8_t* p = scores + L.score_offset + (size_t)y * W + x;
+            const int v = p[0];
+            sc[r] = v;
+            if (v != 0 && v > p[-1] && v > p[1] && v > p[-W - 1] && v > p[-W] && v > p[-W + 1] && v > p[W - 1] && v > p[W] && v > p[W + 1]) keep |= 1u << r;
+        }
     }
+    // slots: exclusive prefix of the threads' survivor counts inside the block
+    const int mine = __builtin_popcount(keep);
+    int incl = mine;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total ? atomicAdd(&counters[lvl], total) : 0;
+    }
+    __syncthreads();
+    int slot = s_base + incl - mine;
+    for (int w = 0; w < wv; ++w) slot += s_wave[w];
+#pragma unroll
+    for (int r = 0; r < kNmsRows; ++r)
+        if (keep & (1u << r)) {
+            if (slot < cap) { cand[((size_t)lvl * cap + slot) * 2] = (y0 + r) * W + x; cand[((size_t)lvl * cap + slot) * 2 + 1] = sc[r]; }
+            ++slot;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,9 +422,10 @@ void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8
 }
 
 void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, hipStream_t s) {
-    dim3 grid((S.lv[0].w + 255) / 256, S.lv[0].h, S.n);
-    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, atlas, S, scores, threshold);
-    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, scores, S, edge, counters, cand, cap);
+    const dim3 grid_score((S.lv[0].w + 255) / 256, (S.lv[0].h + kFastRows - 1) / kFastRows, S.n);
+    const dim3 grid_nms((S.lv[0].w + 255) / 256, (S.lv[0].h + kNmsRows - 1) / kNmsRows, S.n);
+    hipLaunchKernelGGL(k_fast_score, grid_score, dim3(256), 0, s, atlas, S, scores, threshold);
+    hipLaunchKernelGGL(k_fast_nms, grid_nms, dim3(256), 0, s, scores, S, edge, counters, cand, cap);
 }
 
 void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s) {
