@@ -100,6 +100,11 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     launch_acc_flow(acc[cur], flows, n, acc_scale, s);
     stage_out(0, flows); stage_out(1, acc[cur]);
     for (int i = 0; i < 12; ++i) {
+        if (!(dbg && dbg->stages)) {                          // accumulate + blur in one launch; the staged form below also shows the sum before the blur
+            launch_acc_gauss23(acc[cur], flows + (size_t)(i + 1) * P, acc[cur ^ 1], w, h, acc_scale, s);
+            cur ^= 1;
+            continue;
+        }
         launch_acc_flow(acc[cur], flows + (size_t)(i + 1) * P, n, acc_scale, s);
         stage_out(2 + 4 * i, inputs[i + 1]); stage_out(3 + 4 * i, flows + (size_t)(i + 1) * P); stage_out(4 + 4 * i, acc[cur]);
         launch_gauss23_u8(acc[cur], tmp16, acc[cur ^ 1], w, h, s);

@@ -27,6 +27,8 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
 
 // GaussianBlur(src, dst, 23x23, sigma 1) on 8 bit (the fixed-point path); tmp = w*h uint16
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);
+// dst = GaussianBlur23(acc + sat(round(flow * scale))) in one launch (acc is not modified)
+void launch_acc_gauss23(const uint8_t* acc, const uint8_t* flow, uint8_t* dst, int w, int h, float acc_scale, hipStream_t s);
 
 // mask = log(fg/255*19 + 1)/log(20); masked = u8(grey/255 * mask * 255); out = equalizeHist(masked).
 // d_logtab: 512 floats (see foreground.cpp); hist: 256 unsigned; lut: 256 bytes; dbg (optional): 3*n_px floats lin, logged, mask.

@@ -363,6 +363,48 @@ __global__ void __launch_bounds__(256) k_gauss23_v(const uint16_t* __restrict__ 
     const uint32_t v = (s + (1u << 15)) >> 16;
     dst[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
 }
+// fgMask += flow * scale; GaussianBlur(fgMask, 23 x 23, sigma 1) in one launch (src/extractor.cpp:150-154): a workgroup owns 64 x 16 outputs,
+// stages the accumulated values of the tile and its halo of 3 in LDS (the accumulation is per pixel, so halo values are simply
+// recomputed), runs the row pass into LDS and the column pass to the output.  Same integer arithmetic as k_acc_flow + k_gauss23_h / _v
+// (3 launches, 47 us per step at 1080p, 12 dependent steps per image).
+constexpr int kAgTx = 64, kAgTy = 16, kAgW = kAgTx + 6, kAgH = kAgTy + 6;
+__global__ void __launch_bounds__(256) k_acc_gauss23(const uint8_t* __restrict__ acc, const uint8_t* __restrict__ flow, uint8_t* __restrict__ dst,
+                                                     int W, int H, float acc_scale) {
+    __shared__ uint8_t tile[kAgH * kAgW];
+    __shared__ uint16_t hs[kAgH * kAgTx];
+    const int tx0 = blockIdx.x * kAgTx, ty0 = blockIdx.y * kAgTy, tid = threadIdx.x;
+    for (int i = tid; i < kAgH * kAgW; i += 256) {
+        const int r = i / kAgW, c = i - r * kAgW;
+        const size_t p = (size_t)reflect101(ty0 - 3 + r, H) * W + reflect101(tx0 - 3 + c, W);
+        int t = cv_round_x86((float)flow[p] * acc_scale + 0.f);
+        t = t < 0 ? 0 : t > 255 ? 255 : t;
+        const int sum = acc[p] + t;
+        tile[i] = (uint8_t)(sum > 255 ? 255 : sum);
+    }
+    __syncthreads();
+    for (int i = tid; i < kAgH * kAgTx; i += 256) {
+        const int r = i / kAgTx, c = i - r * kAgTx;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sum += (uint32_t)c_g7[k] * tile[r * kAgW + c + k];
+        hs[i] = (uint16_t)sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < kAgTy * kAgTx; i += 256) {
+        const int r = i / kAgTx, c = i - r * kAgTx;
+        const int x = tx0 + c, y = ty0 + r;
+        if (x >= W || y >= H) continue;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sum += (uint32_t)c_g7[k] * hs[(r + k) * kAgTx + c];
+        const uint32_t v = (sum + (1u << 15)) >> 16;
+        dst[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+void launch_acc_gauss23(const uint8_t* acc, const uint8_t* flow, uint8_t* dst, int w, int h, float acc_scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_acc_gauss23, dim3((w + kAgTx - 1) / kAgTx, (h + kAgTy - 1) / kAgTy), dim3(256), 0, s, acc, flow, dst, w, h, acc_scale);
+}
+
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s) {
     dim3 grid((w + 255) / 256, h);
     hipLaunchKernelGGL(k_gauss23_h, grid, dim3(256), 0, s, src, tmp, w, h);
