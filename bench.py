@@ -173,7 +173,7 @@ def run_cfg3_4k(capi, torch, dev, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the configs[2] (3840x2160 x 120) object")
@@ -396,6 +396,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
 
     for _ in range(args.warmup):
         step()
+    ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch (one launch in seven), as at N = 1; rank 0's launches are reported
     fence()
     t0 = time.perf_counter()
     n = 0
@@ -403,6 +404,8 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
         n += step()
     fence()
     dt = time.perf_counter() - t0
+    warp_ms, warp_n = next(((ms, c) for nm, ms, c in ctx.timing_summary() if nm == "warp"), (0.0, 0))
+    ctx.set_timing(0)
     assert n == args.steps * FRAMES
     dt_max = link.max_time(dt)
     # steady state: the broadcast pair resident, frames only (in HBM)
@@ -444,6 +447,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
                                    f"one broadcast of the pair state ({link.how}), then {FRAMES} frames per GPU handed to a writer",
                        "frames_per_gpu": FRAMES, "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
                        "broadcast_bytes": link.nbytes},
+            "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
             "frames_only_fps": round(args.steps * total / dt_f, 1),
             "cfg4_note": "value = configs[3] (one %d-frame morph sharded by frame range)" % total,
             "cfg5_pairs": {"workload": f"BASELINE.json configs[4]: {ppg * world} independent {W}x{H} pairs x {FRAMES} chained frames, {ppg} pairs per GPU on "
