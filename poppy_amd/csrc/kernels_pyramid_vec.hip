@@ -291,44 +291,37 @@ __device__ __forceinline__ void collapse_body(int bx, int by, const void* __rest
         const float4 q = *(const float4*)(gM + (size_t)(2 * sy + r) * w + 4 * t);
         m[r][0] = fn(q.x); m[r][1] = fn(q.y); m[r][2] = fn(q.z); m[r][3] = fn(q.w);
     }
-    {   // A = (G_L - up(nL)) * m
+    // The three upsampled images one after the other in a loop that is NOT unrolled: unrolled, the scheduler hoists all 36 three-dword
+    // loads of the three images together and the kernel needs 206 VGPRs (2 waves per SIMD).
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        const float* n = k == 0 ? nL : k == 1 ? nR : nB;
         float up[2][4][3];
-        up_2x4(nL, nrow, sy, t, up);
+        up_2x4(n, nrow, sy, t, up);
+        if (k < 2) {                                         // A = (G_L - up(nL)) * m;  + (G_R - up(nR)) * (1 - m)
+            const void* g_img = k == 0 ? gL : gR;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float g[12];
-            load_g12<U8>(gL, (size_t)(2 * sy + r) * orow + 12 * t, g);
+            for (int r = 0; r < 2; ++r) {
+                float g[12];
+                load_g12<U8>(g_img, (size_t)(2 * sy + r) * orow + 12 * t, g);
 #pragma unroll
-            for (int e = 0; e < 12; ++e) res[r][e] = (g[e] - up[r][e / 3][e % 3]) * m[r][e / 3];
-        }
-    }
-    {   // + (G_R - up(nR)) * (1 - m)
-        float up[2][4][3];
-        up_2x4(nR, nrow, sy, t, up);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float g[12];
-            load_g12<U8>(gR, (size_t)(2 * sy + r) * orow + 12 * t, g);
-#pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                const float anti = 1.f - m[r][e / 3];
-                const float b = (g[e] - up[r][e / 3][e % 3]) * anti;
-                res[r][e] = res[r][e] + b;
+                for (int e = 0; e < 12; ++e) {
+                    const float wgt = k == 0 ? m[r][e / 3] : 1.f - m[r][e / 3];
+                    const float b = (g[e] - up[r][e / 3][e % 3]) * wgt;
+                    res[r][e] = k == 0 ? b : res[r][e] + b;
+                }
             }
-        }
-    }
-    {   // out = up(nB) + res
-        float up[2][4][3];
-        up_2x4(nB, nrow, sy, t, up);
+        } else {                                             // out = up(nB) + res
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float o[12];
+            for (int r = 0; r < 2; ++r) {
+                float o[12];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) o[e] = up[r][e / 3][e % 3] + res[r][e];
-            float4* d = (float4*)(outB + (size_t)(2 * sy + r) * orow + 12 * t);
-            d[0] = make_float4(o[0], o[1], o[2], o[3]);
-            d[1] = make_float4(o[4], o[5], o[6], o[7]);
-            d[2] = make_float4(o[8], o[9], o[10], o[11]);
+                for (int e = 0; e < 12; ++e) o[e] = up[r][e / 3][e % 3] + res[r][e];
+                float4* d = (float4*)(outB + (size_t)(2 * sy + r) * orow + 12 * t);
+                d[0] = make_float4(o[0], o[1], o[2], o[3]);
+                d[1] = make_float4(o[4], o[5], o[6], o[7]);
+                d[2] = make_float4(o[8], o[9], o[10], o[11]);
+            }
         }
     }
 }
