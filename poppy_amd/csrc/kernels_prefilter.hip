@@ -322,7 +322,13 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
     // serial instruction stream and 35 KB of LDS limits a CU to 4 of them, so the time is that of ONE segment as long as
     // there are no more than ~1000: aim for that many, never shorter than ksize / 2 rows.
     const int col_blocks = (w + kMedLanes - 1) / kMedLanes;
-    int segs = std::max(1, 1024 / col_blocks);              // (512 .. 1024 waves per launch measured the same, fewer slower: profiles/r02_notes.md)
+    // Histogram sets per launch (4 fit a CU, 1024 the GPU).  The two images of a pair run their chains side by side on two streams, so
+    // a launch that asks for all 1024 only queues behind the other image's; and a set pays a ksize-row warm-up, so longer segments are
+    // less work.  Measured per launch, both images interleaved (us at 1024 / 768 / 512 / 384 sets): ksize 17: 75 / 78 / 81 / 104; 41: 142 / 148 /
+    // 140 / 174; 65: 259 / 245 / 224 / 273; 89: 373 / 345 / 251 / 356.  POPPY_MED_SETS forces a number.
+    static const int forced_sets = getenv("POPPY_MED_SETS") ? std::max(64, atoi(getenv("POPPY_MED_SETS"))) : 0;
+    const int seg_target = forced_sets ? forced_sets : (ksize >= 41 ? 512 : 1024);
+    int segs = std::max(1, seg_target / col_blocks);
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
     const int ndw = (ksize + 3) >> 2;
