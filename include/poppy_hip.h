@@ -344,6 +344,10 @@ int poppy_hip_set_debug(poppy_hip_ctx* ctx, int on);
 int poppy_hip_last_warp_kind(poppy_hip_ctx* ctx);
 /* frames rendered by each of the three since the context was created */
 int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* fused, unsigned long long* tiled, unsigned long long* general);
+/* Measurement aid: relaunches the last frame's fused raster + warp kernel (create_map + remap, src/algo.cpp:146-176,230-238) `reps`
+ * times back to back with nothing else running; *ms_per_launch = time between two events around the batch / reps.  POPPY_E_STATE when
+ * the last frame did not take that kernel. */
+int poppy_hip_time_last_warp(poppy_hip_ctx* ctx, int reps, float* ms_per_launch);
 /* 1 when the warp kernel of this pair also writes the blend mask (lbmask = clamp((1 - mr) - m2 * mr), src/algo.cpp:262-263) beside the
  * two warped images, 0 when the level-0 blend kernels compute it from the pair's m2 field on the values they load (the normal case:
  * 8 B/px per frame less; POPPY_HIP_LBMASK_RIDER=1 or a geometry the wide blend kernels do not take select the former).           */

@@ -96,6 +96,9 @@ struct poppy_hip_ctx {
     AutoAligner aligner;
     uint8_t* d_align = nullptr; size_t d_align_bytes = 0;      // staging image of the host-facing align entry points
     unsigned long long n_warp_fast = 0, n_warp_general = 0, n_warp_bin = 0;   // frames by warp kernel since create: tiled (id map), general, fused raster
+    // the arguments of the last fused raster + warp launch (poppy_hip_time_last_warp relaunches it)
+    struct LastWarp { const float* rec = nullptr; const void* tile_data = nullptr; size_t tile_bytes = 0; const int* toff = nullptr; int tile_w = 0;
+                      const uint8_t* c1 = nullptr; const uint8_t* c2 = nullptr; uint8_t* tr1 = nullptr; uint8_t* tr2 = nullptr; WarpExtras ex; bool valid = false; } last_warp;
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)

@@ -133,6 +133,29 @@ int poppy_hip_warp_counts(poppy_hip_ctx* c, unsigned long long* fused, unsigned 
     if (general) *general = c->n_warp_general;
     return POPPY_OK;
 }
+// Relaunches the last frame's fused raster + warp kernel `reps` times back to back on the context's stream, nothing else running, and
+// returns the average time per launch between two events around the batch (milliseconds) — the kernel's duration as the kernel traces
+// show it, without the per-dispatch stamps' overhead.  The relaunches write the same warped images again.
+int poppy_hip_time_last_warp(poppy_hip_ctx* c, int reps, float* ms_per_launch) {
+    if (!c || reps < 1 || !ms_per_launch) return POPPY_E_ARG;
+    if (!c->last_warp.valid) return fail(c, POPPY_E_STATE, "no fused raster + warp launch to repeat");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = drain_frames(c); if (rc) return rc; }
+    const auto& w = c->last_warp;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    launch_warp_bin(w.rec, w.tile_data, w.tile_bytes, w.toff, w.tile_w, w.c1, w.c2, w.tr1, w.tr2, c->W, c->H, w.ex, c->stream);      // warm
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) launch_warp_bin(w.rec, w.tile_data, w.tile_bytes, w.toff, w.tile_w, w.c1, w.c2, w.tr1, w.tr2, c->W, c->H, w.ex, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / (float)reps;
+    return POPPY_OK;
+}
+
 int poppy_hip_mask_rider(poppy_hip_ctx* c) { return c ? (c->lazy_mask ? 0 : 1) : POPPY_E_ARG; }
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
@@ -652,6 +675,11 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
+    if (bin_warp) {
+        c->last_warp.rec = d_rec; c->last_warp.tile_data = f.tile_data; c->last_warp.tile_bytes = c->bins_cap * warp_bin_entry_bytes();
+        c->last_warp.toff = d_toff; c->last_warp.tile_w = c->plan.tile_w; c->last_warp.c1 = c->cur1; c->last_warp.c2 = c->c2;
+        c->last_warp.tr1 = f.tr1; c->last_warp.tr2 = f.tr2; c->last_warp.ex = ex; c->last_warp.valid = true;
+    } else c->last_warp.valid = false;
     // The frame's completion event rides on its last dispatch when the kernels are launched one by one: an event record of
     // its own behind the last kernel leaves the stream idle for ~6 us before the next frame's first kernel.
     static const bool done_packet = getenv("POPPY_HIP_DONE_PACKET") != nullptr;
