@@ -229,24 +229,25 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ void k_ic_angle(const uint8_t* __restrict__ atlas, OrbLevelSet S, const int* __restrict__ kp, int n, float* __restrict__ angle) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per keypoint: lane = patch row v = lane - 15 (31 rows), integer moments reduced across the wave (the sums are integers: any
+// order gives the reference's m01 / m10, orb.cpp:181-215)
+__global__ void __launch_bounds__(64) k_ic_angle(const uint8_t* __restrict__ atlas, OrbLevelSet S, const int* __restrict__ kp, int n, float* __restrict__ angle) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     const OrbLevel L = S.lv[kp[3 * i]];
     const int st = (int)L.stride;
     const uint8_t* c = atlas + L.offset + (size_t)(kp[3 * i + 2] + kOrbBorder) * L.stride + (kp[3 * i + 1] + kOrbBorder);
     int m01 = 0, m10 = 0;
-    for (int u = -15; u <= 15; ++u) m10 += u * (int)c[u];
-    for (int v = 1; v <= 15; ++v) {
-        int vsum = 0, d = c_umax[v];
-        for (int u = -d; u <= d; ++u) {
-            int p = c[u + v * st], m = c[u - v * st];
-            vsum += p - m;
-            m10 += u * (p + m);
-        }
-        m01 += v * vsum;
+    if (lane < 31) {
+        const int v = lane - 15, d = c_umax[v < 0 ? -v : v];
+        const uint8_t* row = c + v * st;
+        int rsum = 0;
+        for (int u = -d; u <= d; ++u) { const int p = row[u]; rsum += p; m10 += u * p; }
+        m01 = v * rsum;
     }
-    angle[i] = fast_atan2_deg((float)m01, (float)m10);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m01 += __shfl_down(m01, o); m10 += __shfl_down(m10, o); }
+    if (lane == 0) angle[i] = fast_atan2_deg((float)m01, (float)m10);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +433,7 @@ void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, in
     if (n > 0) hipLaunchKernelGGL(k_harris, dim3((n + 63) / 64), dim3(64), 0, s, atlas, S, kp, n, resp);
 }
 void launch_ic_angle(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* angle, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_ic_angle, dim3((n + 63) / 64), dim3(64), 0, s, atlas, S, kp, n, angle);
+    if (n > 0) hipLaunchKernelGGL(k_ic_angle, dim3(n), dim3(64), 0, s, atlas, S, kp, n, angle);
 }
 
 }  // namespace poppy_hip

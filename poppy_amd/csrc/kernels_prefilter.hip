@@ -491,18 +491,28 @@ __global__ void __launch_bounds__(256) k_fg_mask(const uint8_t* __restrict__ gre
 }
 
 // lut[i] = saturate(round(sum_{first < j <= i} hist[j] * 255 / (total - hist[first]))); a constant image maps to itself
-__global__ void k_equalize_lut(const unsigned* __restrict__ hist, int total, uint8_t* __restrict__ lut) {
-    if (threadIdx.x != 0) return;
-    int i = 0;
-    while (!hist[i]) ++i;
-    if ((int)hist[i] == total) { for (int k = 0; k < 256; ++k) lut[k] = (uint8_t)i; return; }
-    const float scale = __fdiv_rn(256 - 1.f, (float)(total - (int)hist[i]));
-    for (int k = 0; k <= i; ++k) lut[k] = 0;
-    int sum = 0;
-    for (++i; i < 256; ++i) {
-        sum += (int)hist[i];
-        lut[i] = sat_u8(cv_round_x86((float)sum * scale));
+__global__ void __launch_bounds__(256) k_equalize_lut(const unsigned* __restrict__ hist, int total, uint8_t* __restrict__ lut) {
+    __shared__ int s_h[256];
+    __shared__ int s_first;
+    const int t = threadIdx.x;
+    const int h = (int)hist[t];
+    s_h[t] = h;
+    if (t == 0) s_first = 255;
+    __syncthreads();
+    if (h) atomicMin(&s_first, t);                         // first non-empty bin
+    __syncthreads();
+    const int first = s_first, hf = s_h[first];
+    if (hf == total) { lut[t] = (uint8_t)first; return; }  // a constant image maps to itself
+    // inclusive prefix sums of the 256 counts (Hillis-Steele in LDS; integer sums: the reference's running sum)
+    for (int d = 1; d < 256; d <<= 1) {
+        const int add = t >= d ? s_h[t - d] : 0;
+        __syncthreads();
+        s_h[t] += add;
+        __syncthreads();
     }
+    const float scale = __fdiv_rn(256 - 1.f, (float)(total - hf));
+    const int sum = s_h[t] - s_h[first];                   // sum over first < j <= t
+    lut[t] = t <= first ? (uint8_t)0 : sat_u8(cv_round_x86((float)sum * scale));
 }
 __global__ void __launch_bounds__(256) k_apply_lut(const uint8_t* __restrict__ src, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int n) {
     __shared__ uint8_t l[256];
@@ -512,7 +522,7 @@ __global__ void __launch_bounds__(256) k_apply_lut(const uint8_t* __restrict__ s
 }
 void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t* lut, uint8_t* out, int n_px, hipStream_t s) {
     const int blocks = std::min((n_px + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(64), 0, s, hist, n_px, lut);
+    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(256), 0, s, hist, n_px, lut);
     hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, src, lut, out, n_px);
 }
 void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
@@ -520,7 +530,7 @@ void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logta
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);
     const int blocks = std::min((n_px + 255) / 256, 2048);
     hipLaunchKernelGGL(k_fg_mask, dim3(blocks), dim3(256), 0, s, grey, fg, d_logtab, masked, hist, dbg_or_null, n_px);
-    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(64), 0, s, hist, n_px, lut);
+    hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(256), 0, s, hist, n_px, lut);
     hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, masked, lut, out, n_px);
 }
 
