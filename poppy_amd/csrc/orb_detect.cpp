@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace poppy_hip {
 
@@ -113,7 +114,10 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
 
     std::vector<Cand> all, k;
     int counts[kOrbLevels];
-    for (int l = 0; l < kOrbLevels; ++l) {
+    // The levels are independent up to here: each one's counting sort + retainBest runs on its own host thread (level 0 holds
+    // ~45 % of the ~10^5 candidates of a 1080p image: 0.9 -> 0.5 ms of host time per image).
+    std::vector<Cand> per_level[kOrbLevels];
+    auto level_job = [&](int l) {
         const int n = h_counts[l], lw = S.lv[l].w;
         const int* c = h_cand + (size_t)l * cap * 2;
         // raster order = FAST's emission order (fast.cpp:271-290).  The kernel emits candidates in whatever order its
@@ -130,11 +134,20 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
             for (int y = 0; y < lh; ++y)
                 if (row_at[y + 1] - row_at[y] > 1) std::sort(keyed.begin() + row_at[y], keyed.begin() + row_at[y + 1]);
         }
-        k.resize(n);
-        for (int i = 0; i < n; ++i) k[i] = Cand{keyed[i].first % lw, keyed[i].first / lw, l, (float)keyed[i].second};
-        retain_best(k, 2 * quota[l]);
-        counts[l] = (int)k.size();
-        all.insert(all.end(), k.begin(), k.end());
+        std::vector<Cand>& kl = per_level[l];
+        kl.resize(n);
+        for (int i = 0; i < n; ++i) kl[i] = Cand{keyed[i].first % lw, keyed[i].first / lw, l, (float)keyed[i].second};
+        retain_best(kl, 2 * quota[l]);
+    };
+    {
+        std::vector<std::thread> workers;
+        for (int l = 1; l < kOrbLevels; ++l) if (h_counts[l] > 2000) workers.emplace_back(level_job, l);
+        for (int l = 0; l < kOrbLevels; ++l) if (l == 0 || h_counts[l] <= 2000) level_job(l);
+        for (auto& t : workers) t.join();
+    }
+    for (int l = 0; l < kOrbLevels; ++l) {
+        counts[l] = (int)per_level[l].size();
+        all.insert(all.end(), per_level[l].begin(), per_level[l].end());
     }
     if (all.empty()) return 0;
     if ((int)all.size() > kp_cap) { err = "keypoint buffer overflow"; return -1; }
