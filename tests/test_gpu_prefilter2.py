@@ -101,6 +101,24 @@ def test_orb_input_ragged_vs_oracle(ctx, w, h, seed):
     assert np.array_equal(r["gb"].view(np.uint32), gb.view(np.uint32))             # both: exact products, double sums, one rounding
 
 
+@pytest.mark.parametrize("w,h,seed", [(20, 12, 3), (9, 40, 4), (35, 34, 8)])
+def test_gabor_banks_fft_small_images(ctx, w, h, seed):
+    """Images smaller than the kernel radius / the 34-pixel FFT block: the patch is reflected several times (reflect-101, as
+    filter2D's borderInterpolate does); both forms of the banks must agree there too."""
+    from poppy_amd import synth
+    gf = synth.textured_gray(w, h, seed)
+    bgr = synth.textured_bgr(w, h, seed + 100)
+    try:
+        ctx.set_gabor_direct(False)
+        a, fa = ctx.orb_input(gf), ctx.gabor_field(bgr)
+        ctx.set_gabor_direct(True)
+        b, fb = ctx.orb_input(gf), ctx.gabor_field(bgr)
+    finally:
+        ctx.set_gabor_direct(False)
+    assert np.abs(a["gb"] - b["gb"]).max() <= 2.0 ** -24 / 16 and np.abs(fa - fb).max() <= 2.0 ** -24 / 16
+    assert np.array_equal(a["g"], b["g"])
+
+
 @pytest.mark.parametrize("w,h,seed", [(640, 480, 5), (1001, 333, 6), (1920, 1080, 7)])
 def test_gabor_banks_fft_vs_direct_sums(ctx, w, h, seed):
     """The two forms of the Gabor banks (tiled double-precision FFTs, the default; direct double sums) give the same float planes:
