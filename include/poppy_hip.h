@@ -235,6 +235,13 @@ int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride,
  * ~1e-15 relative before their rounding to float; the tests compare the two). */
 int poppy_hip_set_gabor_direct(poppy_hip_ctx* ctx, int on);
 int poppy_radial_gradient(int width, int height, float* out);
+/* Host-side tables behind two device kernels, exposed for tests that run without a GPU (no reference counterpart):
+ * poppy_gabor_tables: the 16 kernels of a Gabor bank as cv::getGaborKernel returns them (which = 31: src/extractor.cpp:63-64, 13:
+ * src/util.hpp:95; 16 * which^2 floats) and their paired, conjugated 64 x 64 spectra (8 * 4096 complex doubles) for the FFT form;
+ * poppy_pyr_tail_plan: the tap table of the pyramid tail kernel for a frame geometry (info: first tail level, multi-pixel level
+ * steps, single-pixel reductions, descriptors, LDS bytes, usable; desc: 4 words per descriptor). */
+int poppy_gabor_tables(int which, float* bank, double* spectra);
+int poppy_pyr_tail_plan(int width, int height, int pyramid_levels, int tail_px, int* info, unsigned* desc);
 /* Host only: the plan of the length-n transform dft_detail2's kernels run (pass order, load permutation, float twiddles; see
  * poppy_amd/csrc/dft_exact.cpp).  factors needs room for 34 ints, itab for n ints, wave for 2n floats.  For the test suite. */
 int poppy_dft_plan(int n, int* factors, int* n_factors, int* itab, float* wave);

@@ -34,7 +34,7 @@ SYMBOLS = [
     "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_radial_gradient", "poppy_hip_blur_margin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_radial_gradient", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
 
@@ -92,6 +92,8 @@ def lib():
         L.poppy_hip_gabor_field.argtypes = [vp, vp, sz, i, i, vp]
         L.poppy_hip_set_gabor_direct.argtypes = [vp, i]
         L.poppy_radial_gradient.argtypes = [i, i, vp]
+        L.poppy_gabor_tables.argtypes = [i, vp, vp]
+        L.poppy_pyr_tail_plan.argtypes = [i, i, i, i, vp, vp]
         L.poppy_hip_blur_margin.argtypes = [vp, vp, sz, i, i, i, i, vp, sz]
         L.poppy_hip_orb_describe.argtypes = [vp, vp, sz, i, i, vp, i, vp]
         L.poppy_hip_hamming_match.argtypes = [vp, vp, i, vp, i, vp, vp]
@@ -202,6 +204,27 @@ def perspective_from4(src4, dst4):
     if rc:
         raise PoppyError(f"poppy_perspective_from4: {rc}")
     return m
+
+
+def gabor_tables(which):
+    """(bank [16, ks, ks] float32, spectra [8, 64, 64] complex128 in the FFT kernel's position order) of the 31 / 13 tap Gabor bank (host only)."""
+    bank = np.zeros((16, which, which), np.float32); spec = np.zeros((8, 64, 64, 2), np.float64)
+    rc = lib().poppy_gabor_tables(int(which), _p(bank), _p(spec))
+    if rc:
+        raise PoppyError(f"poppy_gabor_tables: {rc}")
+    return bank, spec[..., 0] + 1j * spec[..., 1]
+
+
+def pyr_tail_plan(w, h, levels=64, tail_px=600):
+    """(info dict, descriptors [n, 4] uint32) of the pyramid tail's tap table for a w x h frame (host only)."""
+    info = (C.c_int * 6)()
+    rc = lib().poppy_pyr_tail_plan(w, h, levels, tail_px, info, None)
+    if rc:
+        raise PoppyError(f"poppy_pyr_tail_plan: {rc}")
+    desc = np.zeros((max(info[3], 1), 4), np.uint32)
+    lib().poppy_pyr_tail_plan(w, h, levels, tail_px, info, _p(desc))
+    keys = ("first", "wide_steps", "single_pixel_reductions", "descriptors", "lds_bytes", "ok")
+    return dict(zip(keys, list(info))), desc[:info[3]]
 
 
 def radial_gradient(w, h):

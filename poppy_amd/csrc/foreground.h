@@ -18,6 +18,8 @@ struct ForegroundDebugOut {          // host pointers, each may be null
 
 // draw_radial_gradiant2 (src/draw.cpp:40-59), host
 void radial_gradient(int width, int height, std::vector<float>& out);
+// the 16 kernels of gabor_filter's bank, [orientation][ks * ks] floats (src/util.cpp:31-61, OCV/imgproc/src/gabor.cpp:50-95)
+void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank);
 
 class ForegroundFilter {
 public:

@@ -42,7 +42,7 @@ static void gabor_kernel(int ks, double sigma, double theta, double lambd, doubl
         }
 }
 // gabor_filter's bank: theta_i = i * float(180 / numAngles) used as radians (src/util.cpp:40-47)
-static void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank) {
+void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank) {
     bank.resize((size_t)16 * ks * ks);
     const float step = (float)(180 / 16);
     for (int i = 0; i < 16; ++i) gabor_kernel(ks, sigma, (double)(i * step), lambd, gamma, psi, &bank[(size_t)i * ks * ks]);

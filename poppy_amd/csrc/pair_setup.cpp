@@ -418,6 +418,33 @@ int poppy_dft_plan(int n, int* factors, int* n_factors, int* itab, float* wave) 
     return POPPY_OK;
 }
 
+// Host-side tables of the device code, for tests that run without a GPU.
+// which = 31: Extractor::keypoints' bank (sigma 5, lambda 2), 13: gabor_filter's default bank (sigma 5, lambda 10).  bank: 16 * ks * ks floats
+// (the kernels as getGaborKernel returns them); spectra: 8 * 4096 * 2 doubles = what kernels_gabor_fft.hip multiplies the patch spectrum with.
+int poppy_gabor_tables(int which, float* bank, double* spectra) {
+    if (which != 31 && which != 13) return POPPY_E_ARG;
+    std::vector<float> b;
+    gabor_bank(which, 5, which == 31 ? 2 : 10, 0.04, M_PI / 4, b);
+    if (bank) memcpy(bank, b.data(), b.size() * 4);
+    if (spectra) { const std::vector<double> t = gabor_fft_tables(b, which); memcpy(spectra, t.data(), t.size() * 8); }
+    return POPPY_OK;
+}
+// The tap table of the pyramid tail (kernels.h: PyrTailPlan) of a width x height frame: info[0..5] = first level of the tail, multi-pixel
+// level steps, single-pixel reductions (-1: none), descriptors, LDS bytes, usable (0 / 1); desc (optional, room for info[3] * 4 words).
+int poppy_pyr_tail_plan(int width, int height, int pyramid_levels, int tail_px, int* info, unsigned* desc) {
+    if (width < 1 || height < 1 || pyramid_levels < 1 || pyramid_levels > 256 || !info) return POPPY_E_ARG;
+    std::vector<PyrLevel> lv(pyramid_levels + 1);
+    size_t o3 = 0, o1 = 0;
+    int w = width, h = height;
+    for (int i = 0; i <= pyramid_levels; ++i) { lv[i] = PyrLevel{w, h, o3, o1}; o3 += (size_t)w * h * 3; o1 += (size_t)w * h; w = (w + 1) / 2; h = (h + 1) / 2; }
+    int first = pyramid_levels;
+    for (int i = 1; i <= pyramid_levels; ++i) if ((size_t)lv[i].w * lv[i].h <= (size_t)tail_px) { first = i; break; }
+    const PyrTailPlan p = build_pyr_tail_plan(lv.data(), first, pyramid_levels);
+    info[0] = first; info[1] = p.args.n_wide; info[2] = p.args.nl; info[3] = p.args.n_desc; info[4] = (int)p.lds_bytes; info[5] = p.ok ? 1 : 0;
+    if (desc && !p.desc.empty()) memcpy(desc, p.desc.data(), p.desc.size() * 4);
+    return POPPY_OK;
+}
+
 int poppy_radial_gradient(int W, int H, float* out) {
     if (W <= 0 || H <= 0 || !out) return POPPY_E_ARG;
     std::vector<float> r;
