@@ -74,6 +74,7 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
 }
 
 static void free_pair(poppy_hip_ctx* c) {
+    c->last_warp.valid = false;                     // its pointers go with the pair's buffers
     void* bufs[] = {c->arena, c->c2_raw, c->gabor2, c->d_levels};
     for (void* b : bufs) if (b) (void)hipFree(b);
     c->arena = nullptr; c->arena_bytes = 0;
@@ -170,6 +171,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     if (need <= c->max_tris) return POPPY_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    c->last_warp.valid = false;                     // the plan blobs and tile entries it points into are reallocated below
     // worst case every triangle spans the whole image height
     const size_t items = (size_t)need * ((size_t)c->H / kRasterChunkRows + 3);
     const int tw = warp_bin_tile_width(c->W, c->H), th = 1024 / tw;
