@@ -275,22 +275,24 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
     if (y_begin + 1 < y_end) { load_row(row_ptr(y_begin + r + 1), ra); load_row(row_ptr(y_begin - r), rs); }
     for (int y = y_begin; y < y_end; ++y) {
         if (NW > 1) __syncthreads();                          // every wave's updates of this window are in
-        int s = 0, cb = 0, below = 0;
+        if (WV == 0) {                                        // one wave searches; the others wait at the barrier below
+            int s = 0, cb = 0, below = 0;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {                        // first coarse bin whose cumulative count exceeds `half`
-            s += count_of(256 + c);
-            const bool hit = s > half;
-            cb += hit ? 0 : 1;
-            below = hit ? below : s;
-        }
-        int fb = 0;
-        s = below;
+            for (int c = 0; c < 16; ++c) {                    // first coarse bin whose cumulative count exceeds `half`
+                s += count_of(256 + c);
+                const bool hit = s > half;
+                cb += hit ? 0 : 1;
+                below = hit ? below : s;
+            }
+            int fb = 0;
+            s = below;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            s += count_of(cb * 16 + k);
-            fb += (s > half) ? 0 : 1;
+            for (int k = 0; k < 16; ++k) {
+                s += count_of(cb * 16 + k);
+                fb += (s > half) ? 0 : 1;
+            }
+            if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
         }
-        if (live && WV == 0) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
         if (NW > 1) __syncthreads();                          // every wave has read the window's counts
         if (y + 1 < y_end) {
             uint32_t ca[NDW], cs[NDW];
