@@ -497,6 +497,7 @@ class Context:
         a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
         h, w = a.shape[:2]
         self._chk(lib().poppy_hip_pair_begin(self.h, _p(a), w * 3, _p(b), w * 3, w, h), "pair_begin")
+        self.w, self.h_ = w, h
         nf = C.c_int(0); d = (C.c_double * 2)()
         lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), d)
         return nf.value, (d[0], d[1])

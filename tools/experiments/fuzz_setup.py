@@ -1,0 +1,42 @@
+"""Differential fuzz of the whole pair set-up (foreground x2, dft_detail2, ORB inputs, ORB detect, matcher, gabor2) against the oracle on
+small random images of ragged sizes: nfeatures, the prepared point pairs and gabor2, bit for bit.
+   python tools/experiments/fuzz_setup.py [cases] [seed]        (the oracle's set-up costs seconds per case at these sizes)"""
+import sys, time, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import oracle_lib as O
+from poppy_amd import capi, synth
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0; t0 = time.time()
+for i in range(cases):
+    w = int(rng.integers(96, 260)); h = int(rng.integers(80, 200))
+    if rng.random() < 0.5: w &= ~3
+    s = int(rng.integers(1, 10000))
+    if rng.random() < 0.5:
+        a, b = synth.gen_pair(w, h, seed=s)
+    else:
+        a, b = synth.textured_bgr(w, h, s), synth.textured_bgr(w, h, s + 1)
+    c = capi.Context(0, number_of_frames=4)
+    try:
+        nf, det = c.pair_begin(a, b)
+        p1, p2 = c.pair_points()
+        g = c.fetch("gabor2")
+    except capi.PoppyError as e:
+        lerr = str(e); p1 = p2 = g = None; nf = -1
+    try:
+        st = O.pair_setup(a, b)
+    except Exception as e:
+        st = None; oerr = str(e)
+    c.close()
+    if st is None or p1 is None:
+        ok = (st is None) == (p1 is None)
+        print(f"case {i} {w}x{h}: oracle {'error: ' + oerr if st is None else 'ok'}, library {'error: ' + lerr if p1 is None else 'ok'}")
+    else:
+        ok = (nf == st["nfeatures"] and p1.shape == st["points1"].shape and np.array_equal(p1.view(np.uint32), st["points1"].view(np.uint32))
+              and np.array_equal(p2.view(np.uint32), st["points2"].view(np.uint32)) and np.array_equal(g.view(np.uint32), st["gabor2"].view(np.uint32)))
+        if not ok:
+            print(f"case {i} {w}x{h} seed {s}: MISMATCH nfeatures {nf} vs {st['nfeatures']}, points {p1.shape} vs {st['p1'].shape}, "
+                  f"gabor2 differing {(g.view(np.uint32) != st['gabor2'].view(np.uint32)).sum() if g.shape == st['gabor2'].shape else 'shape'}")
+    bad += 0 if ok else 1
+print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
