@@ -30,10 +30,6 @@ One JSON line on rank 0 (driver contract) with
   parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected);
   cfg3_4k       configs[2]: one 3840x2160 pair, 120 phase-mode frames, set-up and writer hand-off included, with its own roofline.
 """
-import os
-# hardware queues the HIP runtime spreads its streams over (read when the runtime initialises, i.e. before torch touches the GPU):
-# with the default of 4 a context's download stream can share a queue with its rendering stream (poppy_hip.cpp, DESIGN.md)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import ctypes
 import json
@@ -191,7 +187,7 @@ def run_cfg3_4k(capi, torch, dev, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=45)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the configs[2] (3840x2160 x 120) object")

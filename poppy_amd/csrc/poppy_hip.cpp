@@ -21,14 +21,15 @@
 
 static std::string g_create_error;
 
-namespace {
-// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one run
-// in order: with the default a context's download stream can land on its rendering stream's queue, and every frame copy then
-// sits IN the chained frame loop instead of beside it (21.8 vs 12.7 ms per 60 frames at 1080p).  The variable is read when the
-// runtime initialises, so this only helps when the library is loaded before the first HIP call of the process; a host
-// application that initialises HIP earlier sets it itself.
-__attribute__((constructor)) void poppy_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-}  // namespace
+// Streams and hardware queues.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable
+// says otherwise); streams that share a queue run in order, and queues are handed out — and spread over the command processor's
+// pipes — in the order the streams are created.  Which queue the frame-download stream gets decides what the writer hand-off costs:
+// created lazily as a context's fifth stream it got, with 5 or more queues allowed, a queue of its own that delayed EVERY dispatch of
+// the rendering stream by ~40 us while a copy was pending (chained 1080p loop with writer: 3.9k frames/s against 5.9k; kernels of 8 us
+// show up as 45 us in the trace), and with fewer than 4 it shared the rendering stream's queue (4.7k).  So a context creates its three
+// hot streams first and in this order — rendering, plan upload, frame download — and the library leaves the queue count alone:
+// 5.7-6.0k frames/s with 4, 5, 8 or 16 queues, with the image's runtime (downloads on the SDMA engines) and with the one bundled in
+// the torch wheel (blit kernels).  Measurements: profiles/r02_notes.md section 7, tools/experiments/hwq_matrix.sh, hwq_sweep.sh, hwq_sweep4.sh, writer_gap.py.
 
 
 extern "C" {
@@ -56,6 +57,9 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     if (settings) c->cfg = *settings; else poppy_settings_default(&c->cfg);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
+    if (hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
+    for (hipEvent_t& e : c->dl_done)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { g_create_error = "hipEventCreate failed"; delete c; return nullptr; }
     (void)hipEventCreateWithFlags(&c->inputs_ready, hipEventDisableTiming);
     int k = 4;                                             // frames in flight
     if (const char* e = getenv("POPPY_HIP_SLOTS")) k = atoi(e);
@@ -395,21 +399,17 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     const size_t row = (size_t)W * 3, frame_bytes = row * H;
     static const int ring_pref = getenv("POPPY_HIP_RING") ? std::max(1, atoi(getenv("POPPY_HIP_RING"))) : 3;
     const int R = std::min({poppy_hip_ctx::kStageRing, ring_pref, (int)c->slots.size()});
+    const size_t slot_bytes = (frame_bytes + 255) & ~(size_t)255;     // ring slots start on 256-byte boundaries
     int written = 0;
-    if (write) {
-        rc = stage_host(c, frame_bytes * R);
-        if (rc == POPPY_OK && !c->dl_stream) {
-            if (hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipStreamCreate failed");
-            for (int k = 0; k < poppy_hip_ctx::kStageRing && rc == POPPY_OK; ++k)
-                if (hipEventCreateWithFlags(&c->dl_done[k], hipEventDisableTiming) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipEventCreate failed");
-        }
-    }
+    if (write) rc = stage_host(c, slot_bytes * R);
     // Frame hand-off.  The download of a frame runs on its own stream into a ring of R pinned buffers while the GPU renders the
     // frames behind it, and the writer gets frames in order, R - 1 downloads behind.  A copy whose start depends on an event of
     // ANOTHER stream is launched by the runtime's asynchronous-event thread when that event fires; with two contexts rendering and
     // downloading at once those launches crawled (22 GB/s together against 52 GB/s for copies without a dependency:
     // tools/experiments/d2h_raw.py, overlap_probe.py).  So the host waits for frame j-1 itself — frame j is already queued, the GPU
-    // never idles for it — and then issues a copy that depends on nothing.  (POPPY_HIP_DL_DEVWAIT=1: the dependent form.)
+    // never idles for it — and then issues a copy that depends on nothing.  (POPPY_HIP_DL_DEVWAIT=1: the dependent form.)  The copy is
+    // the runtime's: a kernel of ours storing the frame into the mapped ring costs the frame kernels beside it far more (3.7k frames/s
+    // against 5.8k, whatever its geometry: shader stores over PCIe hold up the other kernels' stores, profiles/r02_notes.md section 7).
     static const bool dev_wait = getenv("POPPY_HIP_DL_DEVWAIT") != nullptr;
     std::vector<int> slot_of(n, -1);
     int issued = 0;                                               // downloads queued so far (frames 0 .. issued-1)
@@ -417,7 +417,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         FrameSlot& f = c->slots[slot_of[k]];
         const int r = k % R;
         hipError_t e = dev_wait ? hipStreamWaitEvent(c->dl_stream, f.done, 0) : hipEventSynchronize(f.done);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * frame_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * slot_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(f.downloaded, c->dl_stream);          // the slot's own: ring events are re-recorded every R frames
         f.dl_pending = true;
@@ -427,7 +427,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     auto deliver = [&](int k) -> bool {
         const int rr = k % R;
         if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; return false; }
-        write(user, c->h_stage + (size_t)rr * frame_bytes, W, H, row);
+        write(user, c->h_stage + (size_t)rr * slot_bytes, W, H, row);
         ++written;
         return true;
     };

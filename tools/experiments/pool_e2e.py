@@ -4,7 +4,6 @@
 on the HIP / HSA runtime bundled in the torch wheel, under which every frame download is a blit kernel on the CUs; without it the
 image's runtime sends them to the SDMA engines.   python tools/experiments/pool_e2e.py [steps] [contexts]"""
 import ctypes, os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from poppy_amd import capi, synth
