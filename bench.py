@@ -63,22 +63,22 @@ def synth_pair(w, h, k):
 
 
 def measured_traffic(kernel, w, h):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_warp_pmc.json) — only when those passes were
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_xarp_pmc.json) — only when those passes were
     taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
     import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_xarp_pmc.json")))
         hsh = hashlib.sha256()
         for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
             hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
         if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
-            return None, "profiles/r02_warp_pmc.json was taken from other kernel sources: not quoted"
+            return None, "profiles/r02_xarp_pmc.json was taken from other kernel sources: not quoted"
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
-            return None, "no counter pass for this kernel / size in profiles/r02_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_w_pmc.md)"
+            return None, "no counter pass for this kernel / size in profiles/r02_xarp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_xarp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_x_pmc.md)"
     except (OSError, ValueError, KeyError):
-        return None, "profiles/r02_warp_pmc.json missing"
+        return None, "profiles/r02_xarp_pmc.json missing"
 
 
 def roofline_of(ctx, warp_ms, warp_n, w, h):
