@@ -63,22 +63,22 @@ def synth_pair(w, h, k):
 
 
 def measured_traffic(kernel, w, h):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_xarp_pmc.json) — only when those passes were
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_warp_pmc.json) — only when those passes were
     taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
     import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_xarp_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
         hsh = hashlib.sha256()
         for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
             hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
         if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
-            return None, "profiles/r02_xarp_pmc.json was taken from other kernel sources: not quoted"
+            return None, "profiles/r02_warp_pmc.json was taken from other kernel sources: not quoted"
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
-            return None, "no counter pass for this kernel / size in profiles/r02_xarp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_xarp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_x_pmc.md)"
+            return None, "no counter pass for this kernel / size in profiles/r02_warp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_x_pmc.md)"
     except (OSError, ValueError, KeyError):
-        return None, "profiles/r02_xarp_pmc.json missing"
+        return None, "profiles/r02_warp_pmc.json missing"
 
 
 def roofline_of(ctx, warp_ms, warp_n, w, h):
@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts (host threads) the step's pairs are spread over at N = 1")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 2 (4 measured +3 % at N = 1, at the price of a lower in-bench roofline fraction: more kernels compete)")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
     if args.width and args.height:
@@ -213,6 +213,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.contexts <= 0:
+        args.contexts = 2
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turns the raw outputs of tools/profile_round.sh <tag> (gpurun_out/<tag>_*) into the files kept under profiles/:
-#   profiles/<tag>_trace.md, profiles/<tag>_pmc.md, profiles/<tag>_bench.json, profiles/r02_xarp_pmc.json
+#   profiles/<tag>_trace.md, profiles/<tag>_pmc.md, profiles/<tag>_bench.json, profiles/r02_warp_pmc.json
 # Usage (in the build container, after `gpurun -- bash tools/profile_round.sh <tag>`):  bash tools/make_profile_docs.sh <tag>
 tag=${1:?tag}
 cd "$(dirname "$0")/.."
@@ -15,7 +15,7 @@ T=profiles/${tag}_trace.md
 python tools/pmc_json.py ${tag} > /tmp/pmc_json.out
 P=profiles/${tag}_pmc.md
 { echo "# Round 2, final build: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; separate passes, --pmc only)"; echo
-  echo "Command per pass: \`rocprofv3 --pmc <counter> -- python3 tools/experiments/frames_only.py W H 60 chain 1\` (\`tools/profile_round.sh ${tag}\`).  FETCH_SIZE is doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes; the in-run calibration row is \`k_gray_inv\` (reads exactly 12 B/px, writes 4: raw 6.00 / x2 12.00 / 4.00).  \`profiles/r02_xarp_pmc.json\` (written by \`tools/pmc_json.py ${tag}\`) holds the per-launch bytes \`bench.py\` quotes as \`roofline.traffic\`, with a hash of the kernel sources they were taken from."; echo
+  echo "Command per pass: \`rocprofv3 --pmc <counter> -- python3 tools/experiments/frames_only.py W H 60 chain 1\` (\`tools/profile_round.sh ${tag}\`).  FETCH_SIZE is doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes; the in-run calibration row is \`k_gray_inv\` (reads exactly 12 B/px, writes 4: raw 6.00 / x2 12.00 / 4.00).  \`profiles/r02_warp_pmc.json\` (written by \`tools/pmc_json.py ${tag}\`) holds the per-launch bytes \`bench.py\` quotes as \`roofline.traffic\`, with a hash of the kernel sources they were taken from."; echo
   for sz in "1920 1080" "3840 2160"; do set -- $sz
     echo "## $1x$2"; echo
     python tools/pmc_traffic.py gpurun_out/${tag}_fetch_$1/f_results.db gpurun_out/${tag}_write_$1/w_results.db --px $1*$2 | grep -v "$F"; echo
