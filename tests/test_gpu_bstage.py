@@ -175,6 +175,31 @@ def test_phase_frames_in_flight_and_downloads_match_single_frames():
     c.close()
 
 
+@pytest.mark.parametrize("chain", [False, True])
+def test_ragged_frames_through_the_download_ring(chain):
+    """A frame size whose byte count is no multiple of the ring's slot alignment (317 x 211 x 3 = 200 661 bytes): the ring slots
+    are padded, the writer must still see exactly the frame — in phase mode against singly rendered frames, in chained mode
+    against the same chain walked one frame at a time."""
+    w, h, n, N = 317, 211, 36, 7
+    c1 = synth.textured_bgr(w, h, 71); c2 = synth.textured_bgr(w, h, 72)
+    g = synth.unit_field(w, h, 19)
+    p1, p2 = synth.point_pairs(w, h, n, seed=17, dup=0, oob=0)
+    c = capi.Context(0, number_of_frames=N)
+    c.pair_load(c1, c2, g, p1, p2)
+    shapes = (np.array([capi.lib().poppy_frame_ratio(j, N, -1.0) for j in range(N)]) if chain
+              else np.array([(j + 1) / float(N + 1) for j in range(N)]))
+    got = []
+    c.render_many(shapes, chain=chain, write=lambda f: got.append(f.copy()))
+    assert len(got) == N and got[0].shape == (h, w, 3)
+    c.reset()
+    for j in range(N):
+        if not chain:
+            c.reset()
+        one = c.render(float(shapes[j]), float(shapes[j]), chain=chain)
+        _same(f"{'chained' if chain else 'phase'} frame {j}", got[j], one)
+    c.close()
+
+
 def test_two_pairs_concurrently_match_sequential():
     """Independent contexts driven from two host threads (the batched configuration) give the frames of a lone run."""
     import threading
