@@ -4,8 +4,8 @@
 // Why a second form: the per-element kernels in kernels_frame.hip issue one 4-byte (or 1-byte) access per lane
 // and walk 3-channel rows with a stride of 3 elements, so a wave needs ~10x more memory instructions than the
 // bytes justify and the address pipeline, not HBM, sets the pace (profiles/r01_c_pmc_4k.md).  Here every thread
-// owns 4 horizontally adjacent OUTPUT pixels of one row (12 floats = three 16-byte stores), pulls its inputs with
-// 16-/12-byte loads and keeps the stencil in registers.  Each output is the same expression tree as in the
+// owns a small block of OUTPUT pixels (pyrDown: 2 x 2, collapse: 4 of one row = three 16-byte stores), pulls its inputs
+// with 16-byte loads and keeps the stencil in registers.  Each output is the same expression tree as in the
 // per-element form (pyrdown_elem / pyrup_elem / mix_lr), so results stay bit-identical; threads whose stencil
 // touches an image border, where the reference switches formulas, call the per-element functions.
 #include "kernels.h"
@@ -61,65 +61,76 @@ __device__ __forceinline__ void collapse_border_body(int block, const void* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// pyrDown, 3 channels.  Thread (t, y): output pixels 4t..4t+3 of output row y.
-// source pixels 8t-2 .. 8t+8 (11 pixels = 33 elements) of rows 2y-2 .. 2y+2.
+// pyrDown, 3 channels.  Thread (t, yb): output pixels 2t, 2t+1 of output rows 2yb and 2yb+1, from source pixels 4t-2 .. 4t+4 (21 elements,
+// read as six dwords / six float4 from element 12t-8) of source rows 4yb-2 .. 4yb+4.  The two output rows share three of their five source
+// rows, so a thread runs the row pass over 7 rows instead of 10.  Measured against the earlier form (4 pixels of ONE row per thread, 88 / 112
+// VGPRs): 62 / 74 VGPRs, 8 / 6 waves per SIMD, 16 % fewer vector instructions; level 0 15.3 -> 14.3 us at 1080p and 43.5 -> 41.0 us at 4K,
+// the float levels 8.3 -> 7.4 us and 16.3 -> 14.8 us.  (Row pairs with 4 pixels per thread — 102-112 VGPRs, half the threads — and 2 pixels of
+// one row — 27 % more source elements converted per output — both measured slower: profiles/r02_notes.md section 8.)  Same expression trees
+// as pyrdown_elem, same interior rectangle (pixels 4 .. 4 t1 + 3 of rows 1 .. y1) as the border blocks enumerate.
 // ------------------------------------------------------------------------------------------------
+// row pass of source row `row` for the 6 output elements of thread t
 template <bool U8>
-__device__ __forceinline__ void load_row33(const void* src, size_t row_elems, int row, int t, float* v /*36: elements 24t-8 .. 24t+27*/) {
+__device__ __forceinline__ void pyrdown3_row2(const void* __restrict__ src, size_t srow, int row, int t, const DownGeom& g, float* r /*6*/) {
+    float v[24];
     if (U8) {
-        const uint32_t* p = (const uint32_t*)((const uint8_t*)src + (size_t)row * row_elems + (size_t)(24 * t - 8));
-        uint32_t w[9];
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)src + (size_t)row * srow + (size_t)(12 * t - 8));
+        uint32_t w[6];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) w[i] = p[i];
+        for (int i = 0; i < 6; ++i) w[i] = p[i];
 #pragma unroll
-        for (int i = 0; i < 36; ++i) v[i] = (float)((w[i >> 2] >> (8 * (i & 3))) & 255u) * kInv255;
+        for (int i = 0; i < 24; ++i) v[i] = (float)((w[i >> 2] >> (8 * (i & 3))) & 255u) * kInv255;
     } else {
-        const float4* p = (const float4*)((const float*)src + (size_t)row * row_elems + (size_t)(24 * t - 8));
+        const float4* p = (const float4*)((const float*)src + (size_t)row * srow + (size_t)(12 * t - 8));
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+        for (int i = 0; i < 6; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int j = e / 3, c = e - 3 * j;
+        const int bb = 2 + 6 * j + c;
+        const float t0 = v[bb], t1 = v[bb + 3], t2 = v[bb + 6], t3 = v[bb + 9], t4 = v[bb + 12];
+        const int xe = 6 * t + e;
+        const bool hBody = (xe >= 3) && (xe < g.hBodyEnd);
+        r[e] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
+                     : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
     }
 }
-
-template <bool U8>
-__device__ __forceinline__ void pyrdown3_body(int bx, int by, const void* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b) {
-    const int t = bx * 64 + threadIdx.x;
-    const int y = by * 4 + threadIdx.y;
-    const int nt = g.dw >> 2;
-    if (t >= nt || y >= g.dh) return;
-    const int dwe = g.dw * 3;
-    const size_t srow = (size_t)g.sw * 3;
-    // interior: every tap inside the image (columns 8t-2 >= 0 and 8t+8 <= sw-1 plus the 2 spare elements of the
-    // aligned window; rows 2y-2 >= 0 and 2y+2 <= sh-1)
-    if (!(t >= 1 && t <= b.t1 && y >= 1 && y <= b.y1)) return;        // border outputs: k_pyrdown_border
-    float r[5][12];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        float v[36];
-        load_row33<U8>(src, srow, 2 * y - 2 + k, t, v);
-        // element e of output pixel j: taps at source elements (8t + 2j - 2 + m)*3 + c  ->  window index 2 + 6j + 3m + c
-#pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            const int j = e / 3, c = e - 3 * j;
-            const int b = 2 + 6 * j + c;
-            const float t0 = v[b], t1 = v[b + 3], t2 = v[b + 6], t3 = v[b + 9], t4 = v[b + 12];
-            const int xe = 12 * t + e;
-            const bool hBody = (xe >= 3) && (xe < g.hBodyEnd);
-            r[k][e] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
-                            : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
-        }
-    }
+__device__ __forceinline__ void pyrdown3_store2(float* __restrict__ dst, int dwe, int y, int t, const DownGeom& g,
+                                                const float* r0, const float* r1, const float* r2, const float* r3, const float* r4) {
     const float s = 1.f / 256;
-    float o[12];
+    float o[6];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        const int xe = 12 * t + e;
-        o[e] = (xe < g.vBodyEnd) ? ((r[1][e] + r[3][e] + r[2][e]) * 4.f + (r[0][e] + r[4][e] + (r[2][e] + r[2][e]))) * s
-                                 : (r[2][e] * 6.f + (r[1][e] + r[3][e]) * 4.f + r[0][e] + r[4][e]) * s;
+    for (int e = 0; e < 6; ++e) {
+        const int xe = 6 * t + e;
+        o[e] = (xe < g.vBodyEnd) ? ((r1[e] + r3[e] + r2[e]) * 4.f + (r0[e] + r4[e] + (r2[e] + r2[e]))) * s
+                                 : (r2[e] * 6.f + (r1[e] + r3[e]) * 4.f + r0[e] + r4[e]) * s;
     }
-    float4* d = (float4*)(dst + (size_t)y * dwe + 12 * t);
-    d[0] = make_float4(o[0], o[1], o[2], o[3]);
-    d[1] = make_float4(o[4], o[5], o[6], o[7]);
-    d[2] = make_float4(o[8], o[9], o[10], o[11]);
+    float2* d = (float2*)(dst + (size_t)y * dwe + 6 * t);
+    d[0] = make_float2(o[0], o[1]); d[1] = make_float2(o[2], o[3]); d[2] = make_float2(o[4], o[5]);
+}
+// thread (t, yb): output pixels 2t, 2t+1 of output rows 2yb and 2yb+1 — 7 source rows of 7 source pixels
+template <bool U8>
+__device__ __forceinline__ void pyrdown3_body2(int bx, int by, const void* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b) {
+    const int t = bx * 64 + threadIdx.x;
+    const int y = (by * 4 + threadIdx.y) * 2;
+    if (y >= g.dh) return;
+    if (!(t >= 2 && t <= 2 * b.t1 + 1)) return;                        // border outputs: k_pyrdown_border
+    const size_t srow = (size_t)g.sw * 3;
+    const bool in0 = y >= 1 && y <= b.y1, in1 = y + 1 <= b.y1;
+    if (in0 && in1) {
+        float r[7][6];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pyrdown3_row2<U8>(src, srow, 2 * y - 2 + k, t, g, r[k]);
+        pyrdown3_store2(dst, g.dw * 3, y, t, g, r[0], r[1], r[2], r[3], r[4]);
+        pyrdown3_store2(dst, g.dw * 3, y + 1, t, g, r[2], r[3], r[4], r[5], r[6]);
+    } else if (in0 || in1) {
+        const int yy = in0 ? y : y + 1;
+        float r[5][6];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) pyrdown3_row2<U8>(src, srow, 2 * yy - 2 + k, t, g, r[k]);
+        pyrdown3_store2(dst, g.dw * 3, yy, t, g, r[0], r[1], r[2], r[3], r[4]);
+    }
 }
 
 // pyrDown, 1 channel (mask).  Thread (t, y): output pixels 4t..4t+3; source pixels 8t-2 .. 8t+8 of rows 2y-2 .. 2y+2,
@@ -167,15 +178,23 @@ template <bool U8, typename F>
 __device__ __forceinline__ void pyrdown_level_body(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
                                                    float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
                                                    const DownGeom& g3, const DownGeom& g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1, F fn) {
-    const int nbi = gx * gy;
+    // L and R in the 2 x 2 form (gx2 block columns, gy2 block rows), the mask in the 4-pixel form
+    const int gx2 = (g3.dw / 2 + 63) / 64;
+    const int gy2 = (gy + 1) / 2;
+    const int nbi3 = gx2 * gy2, nbi1 = gx * gy;
     int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {                 // border blocks come first: their load chains are the longest
         blk -= nborder;
-        const int which = blk / nbi; blk -= which * nbi;
-        const int by = blk / gx, bx = blk - by * gx;
-        if (which == 0)      pyrdown3_body<U8>(bx, by, srcL, dstL, g3, b);
-        else if (which == 1) pyrdown3_body<U8>(bx, by, srcR, dstR, g3, b);
-        else                 pyrdown1_body(bx, by, srcM, dstM, g1, b, fn);
+        if (blk < 2 * nbi3) {
+            const int which = blk / nbi3; blk -= which * nbi3;
+            const int by = blk / gx2, bx = blk - by * gx2;
+            pyrdown3_body2<U8>(bx, by, which ? srcR : srcL, which ? dstR : dstL, g3, b);
+        } else {
+            blk -= 2 * nbi3;
+            if (blk >= nbi1) return;
+            const int by = blk / gx, bx = blk - by * gx;
+            pyrdown1_body(bx, by, srcM, dstM, g1, b, fn);
+        }
     } else {
         pyrdown_border_body<U8>(blk, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, x0, x1, y0, y1, fn);
     }
@@ -215,7 +234,7 @@ bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, b
     const int gx = (g3.dw / 4 + 63) / 64, gy = (g3.dh + 3) / 4;
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
-    const int nborder = (nb * 7 + 255) / 256, blocks = 3 * gx * gy + nborder;
+    const int nborder = (nb * 7 + 255) / 256, blocks = 2 * ((g3.dw / 2 + 63) / 64) * ((gy + 1) / 2) + gx * gy + nborder;
     if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
     else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
     return true;
