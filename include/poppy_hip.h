@@ -42,7 +42,7 @@ typedef struct {
     double match_tolerance;  /* 1.0 */
     int max_keypoints;       /* 300 */
     int pyramid_levels;      /* 64  */
-    int enable_radial_mask;  /* 0   */
+    int enable_radial_mask;  /* 0: Extractor::foreground multiplies its mask with draw_radial_gradiant's (src/extractor.cpp:178-197; pinned by restatement only) */
     int enable_auto_align;   /* 0: Matcher::autoAlign on corrected2 and its points before matching (src/matcher.cpp:29-32) */
 } poppy_settings;
 
@@ -227,7 +227,8 @@ int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail
 /* Pieces of the chain, host in / host out, for tests and for callers that cache intermediates:
  * poppy_hip_orb_input: goodFeatures (w*h) -> g = the ORB input image; optional us (grey of the unsharp-masked image), gb (Gabor
  * mean), detail (dft_detail2).  poppy_hip_gabor_field: gabor_filter(bgr / 255) with the default arguments -> f32x3.
- * poppy_radial_gradient: draw_radial_gradiant2 (src/draw.cpp:40-59), host only.                                        */
+ * poppy_radial_gradient: draw_radial_gradiant2 (src/draw.cpp:40-59), host only.  poppy_radial_mask: draw_radial_gradiant + the
+ * conversion to float of src/extractor.cpp:181-183 (src/draw.cpp:21-38): the mask enable_radial_mask multiplies in, host only.      */
 int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
 int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
 /* The two Gabor banks (src/util.cpp:31-61: filter2D per angle -> OCV/imgproc/src/templmatch.cpp:566-760, double-precision DFT
@@ -235,6 +236,7 @@ int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride,
  * ~1e-15 relative before their rounding to float; the tests compare the two). */
 int poppy_hip_set_gabor_direct(poppy_hip_ctx* ctx, int on);
 int poppy_radial_gradient(int width, int height, float* out);
+int poppy_radial_mask(int width, int height, float* out);
 /* Host-side tables behind two device kernels, exposed for tests that run without a GPU (no reference counterpart):
  * poppy_gabor_tables: the 16 kernels of a Gabor bank as cv::getGaborKernel returns them (which = 31: src/extractor.cpp:63-64, 13:
  * src/util.hpp:95; 16 * which^2 floats) and their paired, conjugated 64 x 64 spectra (8 * 4096 complex doubles) for the FFT form;

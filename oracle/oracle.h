@@ -166,6 +166,8 @@ void orb_unsharp_gray(const ImageU8& gf, ImageF& us);
 void gaussian_blur_fx_u8(const ImageU8& src, int ksize, double sigma, ImageU8& dst);
 // ---- detail.cpp ------------------------------------------------------------------------------
 double dft_detail2(const ImageU8& gray);                                     // src/experiments.hpp:305-318 (cv::dft restated bit for bit)
+void radial_mask(int width, int height, ImageF& out);                        // draw_radial_gradiant as Extractor::foreground uses it, src/draw.cpp:21-38
+void set_radial_mask(bool on);                                               // Settings::enable_radial_mask for foreground()
 void radial_gradient(int width, int height, ImageF& out);                    // draw_radial_gradiant2, src/draw.cpp:40-59
 void orb_input_image(const ImageU8& good_features, ImageU8& g);              // Extractor::keypoints up to the detector, src/extractor.cpp:50-76
 void gaussian_taps_fx(int n, double sigma, std::vector<int>& taps);          // 8.8 fixed-point taps of the 8-bit GaussianBlur (sigma <= 0: OpenCV's defaults)

@@ -172,6 +172,8 @@ void orc_gabor_filter_direct(const float* src, int w, int h, int c, int ks, cons
 
 double orc_dft_detail2(const uint8_t* gray, int w, int h) { return dft_detail2(wrap_u8(gray, w, h, 1)); }
 void orc_radial_gradient(int w, int h, float* out) { ImageF o; radial_gradient(w, h, o); put_img(out, o); }
+void orc_radial_mask(int w, int h, float* out) { ImageF o; radial_mask(w, h, o); put_img(out, o); }
+void orc_set_radial_mask(int on) { set_radial_mask(on != 0); }
 void orc_orb_input(const uint8_t* gf, int w, int h, uint8_t* g) { ImageU8 o; orb_input_image(wrap_u8(gf, w, h, 1), o); put_img(g, o); }
 void orc_gaussian_taps_fx(int n, double sigma, int* out) { std::vector<int> t; gaussian_taps_fx(n, sigma, t); memcpy(out, t.data(), t.size() * sizeof(int)); }
 void orc_dissolve(const uint8_t* a, const uint8_t* b, int w, int h, int c, double phase, uint8_t* d) {

@@ -251,6 +251,39 @@ void equalize_hist(const ImageU8& src, ImageU8& dst) {
     for (size_t p = 0; p < src.d.size(); ++p) dst.d[p] = (uint8_t)lut[src.d[p]];
 }
 
+// draw_radial_gradiant (src/draw.cpp:21-38) as Extractor::foreground uses it with Settings::enable_radial_mask (src/extractor.cpp:178-185):
+// float image of pow(sin(sin(d * pi/2) * pi/2), 12), d = distance to cv::Point(cols / 2.0, rows / 2.0) (the doubles truncate to int) over
+// hypot(cols / 2, rows / 2); normalize(0, 255, NORM_MINMAX, CV_8U) = convertTo(CV_8U, scale, shift) with scale = 255 / (max - min) and
+// shift = -min * scale as doubles, applied as floats (cvt_32f: v * a + b, unfused, cvRound, saturate); bitwise_not; convertTo(CV_32F, 1/255).
+// PARITY UNPINNED: no reference-run fixture exists for this option (the survey-stage OpenCV build is gone from the container); every
+// primitive used here is the one pinned by the draw_radial_gradiant2 fixture in detail.cpp.
+void radial_mask(int width, int height, ImageF& out) {
+    const int ccx = (int)(width / 2.0), ccy = (int)(height / 2.0);
+    const double max_dist = std::hypot(width / 2.0, height / 2.0);
+    std::vector<float> g((size_t)width * height);
+    float mn = INFINITY, mx = -INFINITY;
+    for (int row = 0; row < height; ++row)
+        for (int col = 0; col < width; ++col) {
+            const double dist = std::hypot((double)(ccx - col), (double)(ccy - row)) / max_dist;
+            const float v = (float)std::pow(std::sin(std::sin(dist * (M_PI / 2)) * (M_PI / 2)), 12);
+            g[(size_t)row * width + col] = v;
+            mn = std::min(mn, v); mx = std::max(mx, v);
+        }
+    const double smin = mn, smax = mx;
+    const double scale = 255.0 * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0), shift = 0.0 - smin * scale;
+    const float fs = (float)scale, fb = (float)shift;
+    out = ImageF(width, height, 1);
+    for (size_t i = 0; i < g.size(); ++i) {
+        int v = cv_round_f(g[i] * fs + fb);
+        v = v < 0 ? 0 : v > 255 ? 255 : v;
+        const uint8_t inv = (uint8_t)~(uint8_t)v;
+        out.d[i] = (float)inv * (float)(1.0 / 255.0) + 0.f;
+    }
+}
+
+static bool g_radial_mask = false;                              // Settings::enable_radial_mask of the restatement
+void set_radial_mask(bool on) { g_radial_mask = on; }
+
 void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg) {
     ImageU8 grey, fgMask;
     bgr_to_gray_u8(bgr, grey);
@@ -258,6 +291,11 @@ void foreground(const ImageU8& bgr, ImageU8& fg, ForegroundDebug* dbg) {
     ImageF greyF, maskF;
     u8_to_f32(grey, greyF);
     u8_to_f32(fgMask, maskF);
+    if (g_radial_mask) {                                        // multiply(fgMaskFloat, radialMaskFloat, finalMaskFloat), src/extractor.cpp:195-197
+        ImageF radial;
+        radial_mask(maskF.w, maskF.h, radial);
+        for (size_t i = 0; i < maskF.d.size(); ++i) maskF.d[i] = maskF.d[i] * radial.d[i];
+    }
     const float ln20 = cv_log32f(20.f);
     ImageF lin(maskF.w, maskF.h, 1), logged(maskF.w, maskF.h, 1), fin(maskF.w, maskF.h, 1), masked(maskF.w, maskF.h, 1);
     for (size_t i = 0; i < maskF.d.size(); ++i) {

@@ -23,10 +23,10 @@ ForegroundFilter::~ForegroundFilter() {
 }
 
 void ForegroundFilter::release() {
-    void* bufs[] = {padded, d_bgr, grey, meds, acc[0], acc[1], flows, masked, out, lut, tmp16, dbgf, hist};
+    void* bufs[] = {padded, d_bgr, grey, meds, acc[0], acc[1], flows, masked, out, lut, tmp16, dbgf, hist, radial12};
     for (void* b : bufs) if (b) (void)hipFree(b);
     d_bgr = grey = meds = acc[0] = acc[1] = flows = masked = out = lut = nullptr;
-    tmp16 = nullptr; padded = nullptr; dbgf = nullptr; hist = nullptr;
+    tmp16 = nullptr; padded = nullptr; dbgf = nullptr; hist = nullptr; radial12 = nullptr;
     W = H = 0;
 }
 
@@ -116,7 +116,13 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
         if (!dbgf) chk(hipMalloc((void**)&dbgf, P * 12), "hipMalloc");
         dbg_floats = dbgf;
     }
-    launch_fg_tail(grey, acc[cur], logtab, masked, hist, lut, out, dbg_floats, n, s);
+    if (radial_mask_on && !radial12) {                          // once per geometry: ~0.1 us per pixel of host libm, on threads
+        std::vector<float> rad;
+        radial_mask(w, h, rad);
+        chk(hipMalloc((void**)&radial12, P * 4), "hipMalloc");
+        if (radial12) chk(hipMemcpy(radial12, rad.data(), P * 4, hipMemcpyHostToDevice), "radial mask upload");
+    }
+    launch_fg_tail(grey, acc[cur], logtab, radial_mask_on ? radial12 : nullptr, masked, hist, lut, out, dbg_floats, n, s);
     if (dbg) {
         if (dbg->grey) chk(hipMemcpyAsync(dbg->grey, grey, P, hipMemcpyDeviceToHost, s), "copy");
         if (dbg->masked) chk(hipMemcpyAsync(dbg->masked, masked, P, hipMemcpyDeviceToHost, s), "copy");

@@ -20,6 +20,8 @@ struct ForegroundDebugOut {          // host pointers, each may be null
 void radial_gradient(int width, int height, std::vector<float>& out);
 // the 16 kernels of gabor_filter's bank, [orientation][ks * ks] floats (src/util.cpp:31-61, OCV/imgproc/src/gabor.cpp:50-95)
 void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, std::vector<float>& bank);
+// draw_radial_gradiant as Extractor::foreground uses it under Settings::enable_radial_mask (src/draw.cpp:21-38, src/extractor.cpp:178-185), host
+void radial_mask(int width, int height, std::vector<float>& out);
 
 class ForegroundFilter {
 public:
@@ -36,6 +38,7 @@ public:
     int prepare(int w, int h) { return ensure(w, h); }
     std::string err;
 
+    bool radial_mask_on = false;         // Settings::enable_radial_mask (src/extractor.cpp:178-197): set before the first run of a geometry or any time after
     bool gabor_direct = false;           // run the Gabor banks as direct double sums even when the FFT spectra exist (tests compare the two)
 private:
     int ensure(int w, int h);
@@ -60,7 +63,7 @@ private:
     uint8_t *masked = nullptr, *out = nullptr, *lut = nullptr;
     uint16_t* tmp16 = nullptr;
     uint8_t* padded = nullptr;           // median source with replicated side columns
-    float *logtab = nullptr, *dbgf = nullptr;
+    float *logtab = nullptr, *dbgf = nullptr, *radial12 = nullptr;      // radial12: the radial mask of the current geometry, built on first use
     unsigned* hist = nullptr;
     bool prepared = false;
 };

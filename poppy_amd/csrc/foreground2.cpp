@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace poppy_hip {
@@ -46,6 +47,42 @@ void gabor_bank(int ks, double sigma, double lambd, double gamma, double psi, st
     bank.resize((size_t)16 * ks * ks);
     const float step = (float)(180 / 16);
     for (int i = 0; i < 16; ++i) gabor_kernel(ks, sigma, (double)(i * step), lambd, gamma, psi, &bank[(size_t)i * ks * ks]);
+}
+
+// draw_radial_gradiant (src/draw.cpp:21-38) + convertTo(CV_32F, 1/255) (src/extractor.cpp:181-183): pow(sin(sin(d pi/2) pi/2), 12) as float ->
+// normalize(0, 255, NORM_MINMAX, CV_8U), i.e. convertTo(CV_8U, 255 / (max - min), -min * scale) with both doubles applied as floats
+// (convert_scale.simd.hpp cvt_32f: v * a + b unfused, cvRound, saturate) -> bitwise_not -> / 255.  Rows on host threads (libm pow / sin).
+// No reference-run fixture pins this option; the primitives are those of draw_radial_gradiant2 below, which one does.
+void radial_mask(int width, int height, std::vector<float>& out) {
+    const int ccx = (int)(width / 2.0), ccy = (int)(height / 2.0);
+    const double maxDist = std::hypot(width / 2.0, height / 2.0);
+    std::vector<float> g((size_t)width * height);
+    const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    std::vector<float> mns(nt, INFINITY), mxs(nt, -INFINITY);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            float mn = INFINITY, mx = -INFINITY;
+            for (int row = t; row < height; row += nt)
+                for (int col = 0; col < width; ++col) {
+                    const double dist = std::hypot((double)(ccx - col), (double)(ccy - row)) / maxDist;
+                    const float v = (float)std::pow(std::sin(std::sin(dist * (M_PI / 2)) * (M_PI / 2)), 12);
+                    g[(size_t)row * width + col] = v;
+                    mn = std::min(mn, v); mx = std::max(mx, v);
+                }
+            mns[t] = mn; mxs[t] = mx;
+        });
+    for (auto& t : th) t.join();
+    const double smin = *std::min_element(mns.begin(), mns.end()), smax = *std::max_element(mxs.begin(), mxs.end());
+    const double scale = (255.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0), shift = 0.0 - smin * scale;
+    const float fs = (float)scale, fb = (float)shift;
+    out.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        int v = (int)std::nearbyintf(g[i] * fs + fb);
+        v = v < 0 ? 0 : v > 255 ? 255 : v;
+        const uint8_t inv = (uint8_t)~(uint8_t)v;
+        out[i] = (float)inv * (float)(1.0 / 255.0) + 0.f;
+    }
 }
 
 // draw_radial_gradiant2 (src/draw.cpp:40-59): pow(sin(sin(d pi/2) pi/2), 32) -> u8 -> min-max normalise -> invert -> / 255

@@ -31,8 +31,9 @@ void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, i
 void launch_acc_gauss23(const uint8_t* acc, const uint8_t* flow, uint8_t* dst, int w, int h, float acc_scale, hipStream_t s);
 
 // mask = log(fg/255*19 + 1)/log(20); masked = u8(grey/255 * mask * 255); out = equalizeHist(masked).
-// d_logtab: 512 floats (see foreground.cpp); hist: 256 unsigned; lut: 256 bytes; dbg (optional): 3*n_px floats lin, logged, mask.
-void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
+// d_logtab: 512 floats (see foreground.cpp); hist: 256 unsigned; lut: 256 bytes; dbg (optional): 3*n_px floats lin, logged, mask;
+// radial (optional, n_px floats): the radial mask the foreground mask is multiplied with first (Settings::enable_radial_mask).
+void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, const float* radial_or_null, uint8_t* masked, unsigned* hist, uint8_t* lut,
                     uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s);
 
 // GaussianBlur (8-bit fixed-point path, n taps in 8.8) of the strip (rx, ry, rw, rh) of a 3-channel canvas of width cw, read from

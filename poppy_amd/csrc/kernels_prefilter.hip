@@ -469,7 +469,8 @@ __device__ __forceinline__ float cv_log32f(float x, const float* __restrict__ ta
 }
 
 __global__ void __launch_bounds__(256) k_fg_mask(const uint8_t* __restrict__ grey, const uint8_t* __restrict__ fg, const float* __restrict__ tab,
-                                                 uint8_t* __restrict__ masked, unsigned* __restrict__ hist, float* __restrict__ dbg, int n) {
+                                                 const float* __restrict__ radial, uint8_t* __restrict__ masked, unsigned* __restrict__ hist,
+                                                 float* __restrict__ dbg, int n) {
     __shared__ unsigned lh[256];
     __shared__ float ltab[512];
     lh[threadIdx.x] = 0;
@@ -478,7 +479,8 @@ __global__ void __launch_bounds__(256) k_fg_mask(const uint8_t* __restrict__ gre
     const float ln20 = cv_log32f(20.f, ltab);
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const float g = (float)grey[p] * kInv255 + 0.f;        // convertTo(CV_32F, 1/255)
-        const float m = (float)fg[p] * kInv255 + 0.f;
+        float m = (float)fg[p] * kInv255 + 0.f;
+        if (radial) m = m * radial[p];                         // Settings::enable_radial_mask: multiply(fgMaskFloat, radialMaskFloat), src/extractor.cpp:195-197
         const float lin = m * 19.f + 1.f;                      // convertTo(CV_32F, 19, 1)
         const float lg = cv_log32f(lin, ltab);
         const float fin = __fdiv_rn(lg, ln20);
@@ -527,11 +529,11 @@ void launch_equalize_from_hist(const uint8_t* src, const unsigned* hist, uint8_t
     hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(256), 0, s, hist, n_px, lut);
     hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, src, lut, out, n_px);
 }
-void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, uint8_t* masked, unsigned* hist, uint8_t* lut,
+void launch_fg_tail(const uint8_t* grey, const uint8_t* fg, const float* d_logtab, const float* radial_or_null, uint8_t* masked, unsigned* hist, uint8_t* lut,
                     uint8_t* out, float* dbg_or_null, int n_px, hipStream_t s) {
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), s);
     const int blocks = std::min((n_px + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_fg_mask, dim3(blocks), dim3(256), 0, s, grey, fg, d_logtab, masked, hist, dbg_or_null, n_px);
+    hipLaunchKernelGGL(k_fg_mask, dim3(blocks), dim3(256), 0, s, grey, fg, d_logtab, radial_or_null, masked, hist, dbg_or_null, n_px);
     hipLaunchKernelGGL(k_equalize_lut, dim3(1), dim3(256), 0, s, hist, n_px, lut);
     hipLaunchKernelGGL(k_apply_lut, dim3(blocks), dim3(256), 0, s, masked, lut, out, n_px);
 }

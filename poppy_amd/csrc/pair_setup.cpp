@@ -453,4 +453,12 @@ int poppy_radial_gradient(int W, int H, float* out) {
     return POPPY_OK;
 }
 
+int poppy_radial_mask(int W, int H, float* out) {
+    if (W <= 0 || H <= 0 || !out) return POPPY_E_ARG;
+    std::vector<float> r;
+    radial_mask(W, H, r);
+    memcpy(out, r.data(), r.size() * 4);
+    return POPPY_OK;
+}
+
 }  // extern "C"

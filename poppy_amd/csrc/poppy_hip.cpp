@@ -55,6 +55,7 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
     poppy_hip_ctx* c = new poppy_hip_ctx();
     c->device = device;
     if (settings) c->cfg = *settings; else poppy_settings_default(&c->cfg);
+    c->foreground.radial_mask_on = c->foreground_b.radial_mask_on = c->cfg.enable_radial_mask != 0;      // src/extractor.cpp:178-197
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }

@@ -430,6 +430,18 @@ def radial_gradient(w, h):
     return o
 
 
+def radial_mask(w, h):
+    """draw_radial_gradiant as Extractor::foreground uses it under Settings::enable_radial_mask (float, 0..1)."""
+    o = np.zeros((h, w), np.float32)
+    lib().orc_radial_mask(w, h, _vp(o))
+    return o
+
+
+def set_radial_mask(on):
+    """Settings::enable_radial_mask for the oracle's foreground() (and everything built on it); remember to switch it off again."""
+    lib().orc_set_radial_mask(int(bool(on)))
+
+
 def orb_input(good_features):
     gf = np.ascontiguousarray(good_features, np.uint8); o = np.zeros_like(gf)
     lib().orc_orb_input(_vp(gf), gf.shape[1], gf.shape[0], _vp(o))

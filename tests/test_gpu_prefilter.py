@@ -50,3 +50,48 @@ def test_foreground_1080p_vs_oracle_final(ctx):
     got = ctx.foreground(img)
     want = O.foreground(img)["foreground"]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 120, 5), (97, 61, 6)])
+def test_foreground_with_radial_mask_vs_oracle(w, h, seed):
+    """Settings::enable_radial_mask (src/extractor.cpp:178-197): the foreground mask times draw_radial_gradiant's mask before the
+    log curve.  Every stage against the oracle's restatement (no reference-run fixture exists for this option: DESIGN.md section 2)."""
+    import oracle_lib as O
+    from poppy_amd import capi, synth
+    img = synth.textured_bgr(w, h, seed)
+    plain = O.foreground(img)
+    O.set_radial_mask(True)
+    try:
+        want = O.foreground(img)
+    finally:
+        O.set_radial_mask(False)
+    assert not np.array_equal(want["foreground"], plain["foreground"])          # the option does something
+    c = capi.Context(0, enable_radial_mask=1)
+    got = c.foreground(img, debug=True)
+    for name in ORDER:
+        a, b = got[name], want[name]
+        same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+        assert same.all(), f"{w}x{h} {name}: {np.count_nonzero(~same)} elements differ"
+    assert np.array_equal(c.foreground(img), want["foreground"])
+    c.close()
+    c0 = capi.Context(0)                                                        # and off by default
+    assert np.array_equal(c0.foreground(img), plain["foreground"])
+    c0.close()
+
+
+def test_pair_begin_with_radial_mask_vs_oracle():
+    """The option end to end: nfeatures and the prepared point pairs of a raw pair with enable_radial_mask, against the oracle's set-up."""
+    import oracle_lib as O
+    from poppy_amd import capi, synth
+    a, b = synth.gen_pair(200, 152, seed=77)
+    O.set_radial_mask(True)
+    try:
+        want = O.pair_setup(a, b)
+    finally:
+        O.set_radial_mask(False)
+    c = capi.Context(0, enable_radial_mask=1)
+    nf, det = c.pair_begin(a, b)
+    assert nf == want["nfeatures"] and det == want["detail"]
+    p1, p2 = c.pair_points()
+    assert np.array_equal(p1, want["points1"]) and np.array_equal(p2, want["points2"])
+    c.close()

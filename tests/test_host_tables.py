@@ -107,3 +107,40 @@ def test_pyr_tail_plan_matches_the_reference_addressing(w, h, levels, tail_px):
                 if form in (0, 1, 2):
                     assert got["cp"] == cp * 3 + c
     assert at == info["descriptors"]
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (317, 211), (64, 49), (33, 150)])
+def test_radial_mask_table_vs_oracle_and_known_answers(w, h):
+    """The mask Settings::enable_radial_mask multiplies into Extractor::foreground (draw_radial_gradiant, src/draw.cpp:21-38; the
+    conversion of src/extractor.cpp:181-183): the library's host table against the oracle's restatement, and what the formula says
+    without running it: 1 at the centre pixel, 0 at the pixel farthest from it, multiples of 1/255, symmetric about the centre."""
+    import oracle_lib as O
+    from poppy_amd import capi
+    a = capi.radial_mask(w, h)
+    b = O.radial_mask(w, h)
+    assert a.dtype == np.float32 and a.shape == (h, w)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    cx, cy = int(w / 2.0), int(h / 2.0)
+    assert a[cy, cx] == 1.0 and a.min() == 0.0 and a.max() == 1.0
+    k = np.rint(a.astype(np.float64) * 255.0)
+    assert np.array_equal((k.astype(np.float32) * np.float32(1.0 / 255.0)), a)
+    d2 = (np.arange(w)[None, :] - cx) ** 2 + (np.arange(h)[:, None] - cy) ** 2
+    assert a.ravel()[np.argmax(d2)] == 0.0
+    n = min(cx, w - 1 - cx)
+    assert np.array_equal(a[:, cx - n:cx][:, ::-1], a[:, cx + 1:cx + 1 + n])       # mirror columns about the centre column
+
+
+def test_oracle_foreground_radial_mask_only_lowers_the_mask():
+    """With the radial mask on, the log-curve input is fgMask * radial <= fgMask, so finalMask can only go down, pixel by pixel."""
+    import oracle_lib as O
+    from poppy_amd import synth
+    img = synth.textured_bgr(96, 64, 9)
+    plain = O.foreground(img)
+    O.set_radial_mask(True)
+    try:
+        rad = O.foreground(img)
+    finally:
+        O.set_radial_mask(False)
+    assert np.array_equal(rad["acc12"], plain["acc12"]) and np.array_equal(rad["blur12"], plain["blur12"])
+    assert (rad["finalMask"] <= plain["finalMask"]).all() and (rad["finalMask"] < plain["finalMask"]).any()
+    assert np.array_equal(O.foreground(img)["foreground"], plain["foreground"])    # the switch is off again
