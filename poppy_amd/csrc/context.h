@@ -86,6 +86,7 @@ struct poppy_hip_ctx {
     // blob layout: [header 64 B: f32 unsharp amount][warp records (T+1)*20 f32][tri_xy T*6 i32][inv1 T*9 f32][inv2 T*9 f32]
     //              [RasterTri T][work 2*n i32]
     size_t blob_bytes = 0; size_t bins_cap = 0;       // bins_cap: most per-tile triangle-list entries a plan blob has room for
+    size_t tile_bytes = 0;                            // size of every slot's tile_data (kernels.h: warp_bin_data_bytes)
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
     OrbDetector orb, orb_b;

@@ -389,7 +389,11 @@ bool build_tile_bins(FramePlan& plan, int w, int h, int tile_w, int tile_h, size
         total += (size_t)(box[t].tx1 - box[t].tx0 + 1) * (box[t].ty1 - box[t].ty0 + 1);
         if (total > max_entries) return false;
     }
-    for (size_t i = 1; i < plan.tile_off.size(); ++i) plan.tile_off[i] += plan.tile_off[i - 1];
+    plan.max_tile_entries = 0;
+    for (size_t i = 1; i < plan.tile_off.size(); ++i) {
+        plan.max_tile_entries = std::max(plan.max_tile_entries, plan.tile_off[i]);
+        plan.tile_off[i] += plan.tile_off[i - 1];
+    }
     plan.tile_tris.resize(total);
     std::vector<int> fill(plan.tile_off.begin(), plan.tile_off.end() - 1);
     for (int t = 0; t < T; ++t)                            // ascending t: every tile's list comes out in painter's order

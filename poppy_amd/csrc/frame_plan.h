@@ -42,6 +42,7 @@ struct FramePlan {
     std::vector<uint16_t> tile_tris;
     int tile_w = 0, tile_h = 0;
     bool bins_ok = false;            // build_tile_bins succeeded for (tile_w, tile_h)
+    int max_tile_entries = 0;        // longest tile list
     int n_tris = 0;
 };
 // Bins the triangles of `plan` into tile_w x tile_h tiles of the w x h image (every tile a triangle's bounding box touches).

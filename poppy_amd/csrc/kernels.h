@@ -53,12 +53,14 @@ void launch_warp_fast(int32_t* triMap, const float* records, int n_records, cons
                       int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // paint_triangles + create_map + remap without an id map in HBM (kernels_warp_bin.hip).  launch_tile_expand turns the host plan's
-// fill-edge tables (RasterTri), outline segments (OutlineSeg) and per-tile triangle lists into per-tile entries — a coverage bit mask
-// per tile row plus the triangle's warp record, warp_bin_entry_bytes() each — and depends on the plan only (it runs on the plan-upload
-// stream); launch_warp_bin resolves every pixel's triangle from those masks and warps.  Same geometries as launch_warp_fast;
+// fill-edge tables (RasterTri), outline segments (OutlineSeg) and per-tile triangle lists into one byte per pixel — the number of the
+// last covering entry of the pixel's tile — plus the tile's warp records in fixed slots, and depends on the plan only (it runs on the
+// plan-upload stream); launch_warp_bin warps from those.  Same geometries as launch_warp_fast;
 // tile_w = warp_bin_tile_width(w, h) is also what the host bins with.
 int warp_bin_tile_width(int w, int h);
 size_t warp_bin_entry_bytes();
+int warp_bin_max_tile_entries();                                   // a tile's list may not be longer (ids are bytes)
+size_t warp_bin_data_bytes(size_t n_tiles, size_t max_entries);    // size of the tile_data allocation
 void launch_tile_expand(const float* records, const void* raster_tris, const void* outline, const int* tile_off, const uint16_t* tile_tris,
                         void* tile_data, int tile_w, int w, int h, hipStream_t s);
 void launch_warp_bin(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,

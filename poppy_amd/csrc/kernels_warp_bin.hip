@@ -7,19 +7,22 @@
 // after another), i.e. the largest covering index.  The host bins the triangles by 1024-pixel tile (64 x 16 or 128 x 8;
 // frame_plan.cpp: build_tile_bins, ascending order) and hands every triangle's fill-edge table (RasterTri) and its three outline
 // segments, already clipped and ordered as Line() walks them (OutlineSeg).  Two kernels:
-//   k_tile_expand   one thread per (triangle of a tile's list, row of the tile) evaluates that row of the raster in closed form —
-//                   the fill span from the two edge chains (one 64-bit multiply-add each), the pixels of the three Bresenham
-//                   outlines that fall on the row (an interval per segment: a shallow segment puts a run on a row, a steep one a
-//                   single pixel) — and writes a coverage BIT MASK of the tile row; it also copies the triangle's warp record
-//                   next to the masks.  A tile's entries are contiguous (208 bytes each: 128 of masks + the 80-byte record).
-//                   This kernel depends on the plan only, not on any image: it runs on the plan-upload stream, off the chained
-//                   frames' critical path.  8 bits of mask per pixel-row-triangle instead of a 32-bit id per pixel.
-//   k_warp_bin      a workgroup owns a tile: every thread loads the masks of ITS row for the tile's triangles (independent
-//                   8-byte loads, all in flight together with the record staging into LDS), walks them in painter's order
-//                   keeping the last covering entry for each of its 4 pixels, and continues as k_warp_tile's second half
-//                   (warp_fast_device.h): records from LDS, packed map arithmetic, aligned footprint loads, v_dot2 blends.
-// Compared with k_raster + k_warp_tile this removes 4 B/px written and 4 B/px read, the atomics and the frame tags, and the
-// warp kernel's dependent memory round trips drop from three (ids -> records -> footprints) to two.
+//   k_tile_expand   a workgroup per tile.  One thread per (triangle of the tile's list, row of the tile) evaluates that row of the
+//                   raster in closed form — the fill span from the two edge chains (one 64-bit multiply-add each), the pixels of
+//                   the three Bresenham outlines that fall on the row (an interval per segment: a shallow segment puts a run on a
+//                   row, a steep one a single pixel) — as a coverage BIT MASK of the tile row in LDS; then every thread walks the
+//                   masks of ITS four pixels in painter's order (one v_perm per entry) and writes ONE BYTE per pixel: the number
+//                   of the last covering entry of the tile's list.  The entries' 80-byte warp records go into the tile's 32 fixed
+//                   record slots.  This kernel depends on the plan only, not on any image: it runs on the plan-upload stream, off
+//                   the chained frames' critical path.
+//   k_warp_bin      a workgroup owns a tile: a thread's four ids are one coalesced dword, the tile's record slots go through LDS,
+//                   both at addresses that follow from the tile number alone (no list offsets to wait for), then k_warp_tile's
+//                   second half (warp_fast_device.h): records from LDS, packed map arithmetic, aligned footprint loads, v_dot2
+//                   blends.
+// Compared with k_raster + k_warp_tile this removes 3 B/px written and 3 B/px read of id map, the atomics and the frame tags, and
+// the warp kernel's dependent memory round trips drop from three (ids -> records -> footprints) to two.  (Round 2 handed the row
+// masks themselves to the warp kernel — 208 bytes per entry behind a tile_off lookup — and resolved painter's order there: timing
+// builds showed that kernel's front end, not its arithmetic, to be what its duration followed: profiles/r03_notes.md.)
 #include "warp_fast_device.h"
 #include <climits>
 #include <cstdlib>
@@ -92,23 +95,53 @@ __device__ __forceinline__ void add_interval(Interval iv, int tx0, uint64_t& m0,
 
 }  // namespace
 
-// bytes of one tile entry: the masks of the tile's rows (8 x 16 or 16 x 8 bytes) and the triangle's 80-byte warp record
-constexpr int kEntryBytes = 208;
-constexpr int kEntryMaskBytes = 128;
+// What k_tile_expand leaves for k_warp_bin, in one allocation (warp_bin_data_bytes):
+//   ids      1 byte per pixel, tile after tile (1024 bytes each, row-major inside the tile): 0 = no triangle, e + 1 = entry e of
+//            the tile's list — painter's order is resolved HERE, off the chained frames' critical path;
+//   slots    32 x 80 bytes per tile: slot 0 the identity record, slot e + 1 the warp record of entry e (e < 31).  The warp kernel
+//            loads a tile's ids and slots at fixed addresses: nothing in its front end waits for a tile_off lookup;
+//   overflow the records of ALL entries of tiles with more than 31 of them, tile_off-indexed, 80 bytes each (rare: the warp
+//            kernel reads tile_off only on that path).
+constexpr int kEntryBytes = 80;
+constexpr int kSlots = 32;
+constexpr int kTileSlotBytes = kSlots * kEntryBytes;
+constexpr int kTileIdBytes = 1024;
+constexpr int kMaxTileEntries = 255;                      // an id is a byte
 
 template <int kTileW>
 __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ rec, const RasterTriDev* __restrict__ tris,
                                                      const int4* __restrict__ outline, const int* __restrict__ tile_off,
                                                      const uint16_t* __restrict__ tile_tris, uint8_t* __restrict__ tile_data,
-                                                     int W, int tiles_x) {
-    constexpr int kTileH = 1024 / kTileW, kPass = 256 / kTileH, kWords = kTileW / 64;
+                                                     int W, int tiles_x, int n_tiles) {
+    constexpr int kTileH = 1024 / kTileW, kPass = 256 / kTileH, kWords = kTileW / 64, kTileTx = kTileW / 4;
+    __shared__ __attribute__((aligned(16))) uint64_t s_mask[kPass * kTileH * kWords];     // [entry of the pass][row][word]
     const int tid = threadIdx.x, tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tx0 = tx * kTileW, ty0 = ty * kTileH;
     const int off0 = tile_off[tile], nb = tile_off[tile + 1] - off0;
-    const int ji = tid / kTileH, jr = tid % kTileH;              // this thread's job: (entry ji of the pass, tile row jr)
+    uint8_t* const slots = tile_data + (size_t)n_tiles * kTileIdBytes + (size_t)tile * kTileSlotBytes;
+    uint8_t* const overflow = tile_data + (size_t)n_tiles * (kTileIdBytes + kTileSlotBytes);
+    // the records: slots for the warp kernel's LDS stage, the whole list once more when it does not fit them
+    if (tid < kSlots * 5) {
+        const int slot = tid / 5, part = tid - slot * 5;
+        if (slot <= nb) {
+            const int t1 = slot ? tile_tris[off0 + slot - 1] + 1 : 0;
+            *(float4*)(slots + tid * 16) = rec[(size_t)t1 * 5 + part];
+        }
+    }
+    if (nb >= kSlots)
+        for (int i = tid; i < nb * 5; i += 256) {
+            const int e = i / 5, part = i - e * 5;
+            *(float4*)(overflow + (size_t)(off0 + e) * kEntryBytes + part * 16) = rec[(size_t)(tile_tris[off0 + e] + 1) * 5 + part];
+        }
+    const int ji = tid / kTileH, jr = tid % kTileH;              // raster job: (entry ji of the pass, tile row jr)
+    const int row = tid / kTileTx, xg = tid % kTileTx;           // resolve job: pixels (4 xg .. 4 xg + 3, row) of the tile
+    const int mdword = row * kWords * 2 + ((xg * 4) >> 5), shift = (xg * 4) & 31;
+    const uint32_t* s_mask32 = (const uint32_t*)s_mask;
+    uint32_t ids = 0;                                            // the four pixels' entry numbers, one per byte
     for (int base = 0; base < nb; base += kPass) {
         const int n_here = min(kPass, nb - base);
+        if (base) __syncthreads();                               // the previous pass's masks have been read
         if (ji < n_here) {
             const int t = tile_tris[off0 + base + ji];
             const RasterTriDev r = tris[t];
@@ -117,16 +150,20 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
             add_interval<kTileW>(fill_row(r, yy, W), tx0, m0, m1);
 #pragma unroll
             for (int e = 0; e < 3; ++e) add_interval<kTileW>(outline_row(outline[t * 3 + e], yy), tx0, m0, m1);
-            uint64_t* dst = (uint64_t*)(tile_data + (size_t)(off0 + base + ji) * kEntryBytes) + jr * kWords;
+            uint64_t* dst = s_mask + (ji * kTileH + jr) * kWords;
             dst[0] = m0;
             if (kWords > 1) dst[kWords - 1] = m1;
         }
-        if (tid < n_here * 5) {                                  // the entries' records
-            const int e = tid / 5, part = tid - e * 5;
-            const int t1 = tile_tris[off0 + base + e] + 1;
-            *(float4*)(tile_data + (size_t)(off0 + base + e) * kEntryBytes + kEntryMaskBytes + part * 16) = rec[(size_t)t1 * 5 + part];
+        __syncthreads();
+        // painter's order, a later entry overwrites: an entry's four coverage bits become the byte selector of one v_perm between
+        // the old bytes and the entry's number
+        for (int i = 0; i < n_here; ++i) {
+            const uint32_t bits = (s_mask32[i * kTileH * kWords * 2 + mdword] >> shift) & 15u;
+            const uint32_t spread = __umul24(bits, 0x204081u) & 0x01010101u;          // bit k of `bits` -> bit 0 of byte k
+            ids = __builtin_amdgcn_perm((uint32_t)(base + i + 1) * 0x01010101u, ids, (spread << 2) | 0x03020100u);
         }
     }
+    ((uint32_t*)tile_data)[(size_t)tile * 256 + tid] = ids;
 }
 
 template <int kTileW>
@@ -135,15 +172,12 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
                                                   const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                   uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
                                                   int tiles_x, uint32_t data_bytes, WarpExtras ex) {
-    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4, kWords = kTileW / 64;
-    constexpr int kCached = 31;                                  // entries whose records are staged in LDS (slot 0: the identity)
-    constexpr int kChunk = 32;                                   // entries whose row masks are staged in LDS per pass: 32 x 128 bytes
-    __shared__ float4 s_rec[(kCached + 1) * 5];
-    __shared__ __attribute__((aligned(16))) uint64_t s_mask[kChunk * 16];
-    __shared__ u4v s_ids[256];
+    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
+    __shared__ float4 s_rec[kSlots * 5];
+    __shared__ uint32_t s_ids[256];
 
     const int tid = threadIdx.x;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x), n_tiles = (int)gridDim.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int row = tid / kTileTx, xg = tid % kTileTx;           // this thread's pixels: (tx0 + 4 xg .. + 3, ty0 + row)
     const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
@@ -154,49 +188,18 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
     const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
 
-    const int off0 = tile_off[tile], nb = tile_off[tile + 1] - off0;          // uniform: scalar loads
-    const uint32_t ebase = (uint32_t)off0 * (uint32_t)kEntryBytes;
-    // ONE round trip brings everything the tile needs: the row masks of its entries (thread t: 16 bytes of entry t / 8), the
-    // entries' records (slot 0 = record 0 = the identity of "no triangle") and this thread's four m2 values
-    const int n_cached = min(nb, kCached);
-    const bool stages = tid < (n_cached + 1) * 5;
+    // ONE round trip, at addresses that depend on the tile number only: this thread's four ids, the tile's record slots (through
+    // LDS) and, when the mask rides along, four m2 values
+    const uint32_t ids = __builtin_amdgcn_raw_buffer_load_b32(rdata, (uint32_t)tile * kTileIdBytes + (uint32_t)tid * 4u, 0, 0);
+    const bool stages = tid < kSlots * 5;
     float4 staged = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (stages) {
-        const int slot = tid / 5, part = tid - slot * 5;
-        staged = slot ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ebase + (uint32_t)(slot - 1) * kEntryBytes + kEntryMaskBytes + part * 16, 0, 0))
-                      : rec[part];
-    }
+    if (stages)
+        staged = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rdata, (uint32_t)n_tiles * kTileIdBytes + (uint32_t)tile * kTileSlotBytes + (uint32_t)tid * 16u, 0, 0));
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active && ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
-    int id[4] = {0, 0, 0, 0};                                    // entry index + 1 of the last covering triangle per pixel
-    // the thread's four coverage bits never straddle a dword: (x offset in the tile) is a multiple of 4
-    const int mdword = row * kWords * 2 + ((xg * 4) >> 5), shift = (xg * 4) & 31;
-    const uint32_t* s_mask32 = (const uint32_t*)s_mask;
-    for (int base = 0; base < nb || base == 0; base += kChunk) {
-        const int n_here = min(kChunk, nb - base);
-        if (base) __syncthreads();                               // the previous pass's masks have been read
-        if (tid < n_here * 8) {
-            const u4v mv = __builtin_amdgcn_raw_buffer_load_b128(rdata, ebase + (uint32_t)(base + (tid >> 3)) * kEntryBytes + (uint32_t)(tid & 7) * 16u, 0, 0);
-            *(u4v*)(s_mask + tid * 2) = mv;
-        }
-        if (base == 0 && stages) s_rec[tid] = staged;
-        __syncthreads();
-        // painter's order, a later entry overwrites: the four pixels' entry numbers of this pass (1..32) ride in the four bytes of
-        // one register; an entry's four coverage bits become the byte selector of one v_perm between the old bytes and the entry's
-        // number — five vector instructions per entry for the thread's four pixels
-        uint32_t packed = 0;
-        for (int i = 0; i < n_here; ++i) {
-            const uint32_t bits = (s_mask32[i * 32 + mdword] >> shift) & 15u;
-            const uint32_t spread = __umul24(bits, 0x204081u) & 0x01010101u;          // bit k of `bits` -> bit 0 of byte k
-            packed = __builtin_amdgcn_perm((uint32_t)(i + 1) * 0x01010101u, packed, (spread << 2) | 0x03020100u);
-        }
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            const int e = (int)((packed >> (8 * px)) & 255u);
-            id[px] = e ? base + e : id[px];
-        }
-        if (nb == 0) break;
-    }
+    if (stages) s_rec[tid] = staged;
+    __syncthreads();
     if (active && ex.m2) {                                       // the lbmask rider
         const float4 o = make_float4(mask_value(m2v.x, ex.alpha, ex.beta), mask_value(m2v.y, ex.alpha, ex.beta),
                                      mask_value(m2v.z, ex.alpha, ex.beta), mask_value(m2v.w, ex.alpha, ex.beta));
@@ -204,20 +207,21 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
     }
     if (!active) return;
     // the ids are only needed again by the rare border path: parked in LDS so that they do not count against the footprint phase
-    s_ids[tid] = u4v{(unsigned)id[0], (unsigned)id[1], (unsigned)id[2], (unsigned)id[3]};
+    s_ids[tid] = ids;
 
     const float fy = (float)y;
     FastTap t[2][4];
+    const uint32_t over_base = (uint32_t)n_tiles * (kTileIdBytes + kTileSlotBytes);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        const int li = (int)((ids >> (8 * k)) & 255u);
         float4 A, B, C, D; f2 E;
-        if (id[k] <= kCached) {
-            const int li = id[k];
+        if (li < kSlots) {
             A = s_rec[li * 5]; B = s_rec[li * 5 + 1]; C = s_rec[li * 5 + 2]; D = s_rec[li * 5 + 3];
             const float4 e4 = s_rec[li * 5 + 4];
             E = f2{e4.x, e4.y};
-        } else {                                                 // a tile with more triangles than the LDS stage holds
-            const uint32_t ro = ebase + (uint32_t)(id[k] - 1) * kEntryBytes + kEntryMaskBytes;
+        } else {                                                 // a tile with more triangles than the slots hold
+            const uint32_t ro = over_base + (uint32_t)(tile_off[tile] + li - 1) * kEntryBytes;
             A = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro, 0, 0));
             B = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 16, 0, 0));
             C = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 32, 0, 0));
@@ -227,9 +231,10 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
         warp_taps(A, B, C, D, E, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
     }
     warp_fetch_blend_store(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {
-        const u4v ids = s_ids[tid];
-        const unsigned e = k == 0 ? ids.x : k == 1 ? ids.y : k == 2 ? ids.z : ids.w;
-        return e ? (const float*)(tile_data + (size_t)(off0 + (int)e - 1) * kEntryBytes + kEntryMaskBytes) : (const float*)rec;
+        const unsigned e = (s_ids[tid] >> (8 * k)) & 255u;
+        if (e == 0) return (const float*)rec;
+        if (e < (unsigned)kSlots) return (const float*)(tile_data + (size_t)n_tiles * kTileIdBytes + (size_t)tile * kTileSlotBytes + (size_t)e * kEntryBytes);
+        return (const float*)(tile_data + (size_t)over_base + (size_t)(tile_off[tile] + (int)e - 1) * kEntryBytes);
     });
 }
 
@@ -239,12 +244,14 @@ int warp_bin_tile_width(int w, int h) {
     return (long long)w * h >= 4000000 ? 128 : 64;
 }
 size_t warp_bin_entry_bytes() { return kEntryBytes; }
+int warp_bin_max_tile_entries() { return kMaxTileEntries; }
+size_t warp_bin_data_bytes(size_t n_tiles, size_t max_entries) { return n_tiles * (kTileIdBytes + kTileSlotBytes) + max_entries * kEntryBytes + 256; }
 
 void launch_tile_expand(const float* records, const void* raster_tris, const void* outline, const int* tile_off, const uint16_t* tile_tris,
                         void* tile_data, int tile_w, int w, int h, hipStream_t s) {
 #define LE(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
     hipLaunchKernelGGL(k_tile_expand<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, (const float4*)records, (const RasterTriDev*)raster_tris, \
-                       (const int4*)outline, tile_off, tile_tris, (uint8_t*)tile_data, w, tiles_x); }
+                       (const int4*)outline, tile_off, tile_tris, (uint8_t*)tile_data, w, tiles_x, tiles_x * tiles_y); }
     if (tile_w == 128) LE(128) else LE(64)
 #undef LE
 }

@@ -182,6 +182,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     const int tw = warp_bin_tile_width(c->W, c->H), th = 1024 / tw;
     const size_t ntiles = (size_t)((c->W + tw - 1) / tw) * ((c->H + th - 1) / th);
     c->bins_cap = 64 * (size_t)need + 16 * ntiles;
+    c->tile_bytes = warp_bin_data_bytes(ntiles, c->bins_cap);
     const size_t bytes = ((kBlobHeader + (size_t)(need + 1) * kWarpRecordFloats * 4 +
                           (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 +
                           (size_t)need * 3 * sizeof(OutlineSeg) + (ntiles + 1) * 4 + c->bins_cap * 2 + 64 + 15) / 16) * 16;
@@ -191,7 +192,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
         if (f.d_blob) (void)hipFree(f.d_blob);
         if (f.tile_data) (void)hipFree(f.tile_data);
         f.h_blob = f.d_blob = f.tile_data = nullptr;
-        HIPCHK(c, hipMalloc((void**)&f.tile_data, c->bins_cap * warp_bin_entry_bytes() + 256));
+        HIPCHK(c, hipMalloc((void**)&f.tile_data, c->tile_bytes));
         HIPCHK(c, hipHostMalloc((void**)&f.h_blob, bytes, hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer(&f.h_blob_dev, f.h_blob, 0));
         HIPCHK(c, hipMalloc((void**)&f.d_blob, bytes));
@@ -571,7 +572,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const size_t n_toff = c->plan.tile_off.size(), n_ttri = c->plan.tile_tris.size();
     uint16_t* h_ttri = (uint16_t*)(h_toff + n_toff);
     static const bool idmap_only = getenv("POPPY_HIP_IDMAP") != nullptr;
-    const bool bins = c->plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap &&
+    const bool bins = c->plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap && c->plan.max_tile_entries <= warp_bin_max_tile_entries() &&
                       c->plan.tile_w == warp_bin_tile_width(W, H);
     const size_t used = kBlobHeader + rec_bytes + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + work_ints * 4 +
                         (bins ? (size_t)T * 3 * sizeof(OutlineSeg) + n_toff * 4 + n_ttri * 2 : 0);
@@ -668,18 +669,18 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         static const int stride = getenv("POPPY_HIP_WARP_STAMP_STRIDE") ? std::max(1, atoi(getenv("POPPY_HIP_WARP_STAMP_STRIDE"))) : kWarpStampStride;
         const bool stamp = (c->warp_seq++ % (unsigned)stride) == 0;
         hipEvent_t t0 = stamp ? tm.take(nullptr) : nullptr, t1 = stamp ? tm.take("warp") : nullptr;
-        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->bins_cap * warp_bin_entry_bytes(), d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
         else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
     } else {
         if (!all_marks) tm.mark(nullptr);
-        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->bins_cap * warp_bin_entry_bytes(), d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
     if (bin_warp) {
-        c->last_warp.rec = d_rec; c->last_warp.tile_data = f.tile_data; c->last_warp.tile_bytes = c->bins_cap * warp_bin_entry_bytes();
+        c->last_warp.rec = d_rec; c->last_warp.tile_data = f.tile_data; c->last_warp.tile_bytes = c->tile_bytes;
         c->last_warp.toff = d_toff; c->last_warp.tile_w = c->plan.tile_w; c->last_warp.c1 = c->cur1; c->last_warp.c2 = c->c2;
         c->last_warp.tr1 = f.tr1; c->last_warp.tr2 = f.tr2; c->last_warp.ex = ex; c->last_warp.valid = true;
     } else c->last_warp.valid = false;
