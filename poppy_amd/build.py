@@ -18,6 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-result", "-I" + os.path.join(HERE, "..", "include")]
 
 
+# kernels whose inner loops the SLP vectoriser turns into packed fp32 instructions + the moves that pair their operands: a packed
+# instruction costs its two scalar halves on gfx950 (profiles/r03_notes.md section 1), the moves come on top
+PER_FILE_FLAGS = {"kernels_unsharp_stream.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
@@ -44,7 +49,7 @@ def build(force=False, verbose=True):
                 os.path.getmtime(src), *[os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))],
                 os.path.getmtime(os.path.join(HERE, "..", "include", "poppy_hip.h"))):
             continue
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -140,6 +140,14 @@ void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, fl
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
                     int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done = nullptr);
 
+// The streaming form (kernels_unsharp_stream.hip: a wave per 60-pixel column strip, rows kept in registers); launch_unsharp uses it
+// for frames of 4 Mpx and more among the geometries it takes (w % 4 == 0, w >= 64, h >= 16) unless POPPY_UNSHARP_TILE is set;
+// POPPY_UNSHARP_STREAM forces it for all of them.  norm2_min: see launch_unsharp.
+bool unsharp_stream_takes(int w, int h);
+bool unsharp_stream_eligible(int w, int h);
+void launch_unsharp_stream(const float* src, uint8_t* out_u8, float* out_f32_or_null, int w, int h, float amount, const float* d_amount,
+                           double norm2_min, hipStream_t s, hipEvent_t done);
+
 // u8 cross-dissolve fallback (src/poppy.hpp:129)
 void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s);
 

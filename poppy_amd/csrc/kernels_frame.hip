@@ -759,6 +759,8 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (x > 0 && std::sqrt(std::nextafter(x, 0.0)) >= t) x = std::nextafter(x, 0.0);
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
+        static const bool tile_only = getenv("POPPY_UNSHARP_TILE") != nullptr;
+        if (!tile_only && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done); return; }
         dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
         hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
         return;

@@ -303,3 +303,21 @@ def test_id_map_is_not_cleared_between_frames(w, h):
         if j in check:
             _same(f"{w}x{h} frame {j}", got, want[k])
     c.close()
+
+
+def test_unsharp_kernel_forms_on_every_geometry():
+    """launch_unsharp picks the streaming kernel (kernels_unsharp_stream.hip) from 4 Mpx up and the tile kernel below; the switches
+    POPPY_UNSHARP_STREAM / POPPY_UNSHARP_TILE force one of them (read once per process).  The fixture, 1080p, ragged-size and chained
+    tests of this file once more with the streaming kernel forced, and the 4K frame of the reference with the tile kernel forced."""
+    import subprocess
+    import sys
+    if os.environ.get("POPPY_UNSHARP_STREAM") or os.environ.get("POPPY_UNSHARP_TILE"):
+        pytest.skip("a kernel form is already forced in this process")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bstage.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "fixtures or 1080p or ragged or chained_sequence"], env=dict(os.environ, POPPY_UNSHARP_STREAM="1"),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_sequences.py"), "-q", "-x", "-m", "gpu", "-k", "cfg3_4k"],
+                       env=dict(os.environ, POPPY_UNSHARP_TILE="1"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
