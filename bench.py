@@ -11,12 +11,13 @@ taken through the WHOLE of poppy::morph (src/poppy.hpp:46-248) by the library:
 per-frame operator alone on a resident pair with the frames left in HBM (what round 1 reported as `value`) is the extra key
 `resident_pair_fps`.
 
-N > 1 (configs[3]): ONE 60*N-frame phase-mode morph of one pair (N = 8 -> the 480-frame morph): rank 0 runs the pair set-up,
-the pair state (both images, the mask field's grey complement, the point sets) goes to every rank in one broadcast over
-RCCL/xGMI, rank r renders frames [60r, 60r + 60) with t_j = j / (60 N) — each equal to morph(img1, img2, ..., phase = t_j) with
-number_of_frames = 1 — and hands them to its writer.  No data-path collective afterwards; per-GPU work is fixed => "weak".
-The N = 1 point of THAT workload is the extra key `scaling_baseline` of the N = 1 line (a 60-frame phase-mode morph incl.
-set-up), so an N-sweep is read against it and not against the chained headline.
+N > 1 (configs[3]): ONE 480-frame phase-mode morph of one pair for EVERY N (`--total-frames`, default 480: north_star's "480-frame 1080p
+morph"): rank 0 runs the pair set-up, the pair state (both images, the mask field's grey complement, the point sets) goes to every rank
+in one broadcast over RCCL/xGMI, rank r renders the r-th contiguous share of the frames t_j = j / 480 — each equal to
+morph(img1, img2, ..., phase = t_j) with number_of_frames = 1 — and hands them to its writer.  No data-path collective afterwards; the
+total work is fixed => "strong".  The N = 1 point of THAT job is the extra key `scaling_baseline_480` of the N = 1 line (the same
+480-frame morph on one GPU, set-up and writer inside), so an N-sweep is read against it and not against the chained headline; every
+N > 1 line carries its own measured serial part (`amdahl`: set-up, broadcast, frames).
 
 One JSON line on rank 0 (driver contract) with
   roofline      (`isolated` inside it: the same kernel's launches with nothing else on the GPU, measured after the timed region)
@@ -26,8 +27,11 @@ One JSON line on rank 0 (driver contract) with
                 region).  The kernel moves LESS than the contract counts: no id map (the raster reaches it as per-tile row masks,
                 ~1.3 B/px) and no blend mask (the level-0 blend kernels derive it from m2) — 12 B/px of images; `moved_*` states
                 that.  Only when the mask rider is on (POPPY_HIP_LBMASK_RIDER) `frac_with_rider` adds its 8 B/px;
-  cpu_baseline  oracle/ (CPU restatement, "port", 1 thread) on 20 chained frames of pair 0 from the GPU's own pair state;
-  parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected);
+  cpu_baseline  oracle/ (CPU restatement, "port"): 20 chained 1080p frames of pair 0 from the GPU's own pair state on 1 thread (`value`),
+                the same operator on every host thread at once (`all_cores`), and one whole morph incl. the oracle's pair set-up at
+                512x512x30 (`end_to_end`: BASELINE.json configs[0], so that a CPU figure covers the same work as `value`);
+  parity_check  the 20th frame of that oracle run against the 20th frame the GPU wrote (bit-exact expected); `cfg3_4k.parity_check`:
+                the last frame of the 120-frame 4K sequence against the oracle;
   cfg3_4k       configs[2]: one 3840x2160 pair, 120 phase-mode frames, set-up and writer hand-off included, with its own roofline.
 """
 import argparse
@@ -63,22 +67,32 @@ def synth_pair(w, h, k):
 
 
 def measured_traffic(kernel, w, h):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_warp_pmc.json) — only when those passes were
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r03_warp_pmc.json) — only when those passes were
     taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
     import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_warp_pmc.json")))
         hsh = hashlib.sha256()
         for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
             hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
         if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
-            return None, "profiles/r02_warp_pmc.json was taken from other kernel sources: not quoted"
+            return None, "profiles/r03_warp_pmc.json was taken from other kernel sources: not quoted"
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
-            return None, "no counter pass for this kernel / size in profiles/r02_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r02_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r02_x_pmc.md)"
+            return None, "no counter pass for this kernel / size in profiles/r03_warp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r03_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r03_x_pmc.md)"
     except (OSError, ValueError, KeyError):
-        return None, "profiles/r02_warp_pmc.json missing"
+        return None, "profiles/r03_warp_pmc.json missing"
+
+
+def profile_facts(kernel, w, h):
+    """What the committed profiles say about `kernel` at this size (profiles/r03_warp_facts.json, written by tools/warp_facts.py from the
+    round's rocprofv3 kernel trace and from the kernel's ISA): the trace's average duration and the kernel's vector-issue bound."""
+    try:
+        f = json.load(open(os.path.join(ROOT, "profiles", "r03_warp_facts.json")))
+        return f.get(f"{w}x{h}", {}).get(kernel)
+    except (OSError, ValueError):
+        return None
 
 
 def roofline_of(ctx, warp_ms, warp_n, w, h):
@@ -97,6 +111,22 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
     else:
         out.update({"moved_image_bytes_per_launch": int(12 * P), "moved_GBps": round(rate(12.0 * P), 1),
                     "moved_note": "what the kernel itself reads and writes: c1 3 + c2 3 in, tr1 3 + tr2 3 out = 12 B/px (+ ~1.3 B/px of raster row masks and records); no id map, no blend mask"})
+    facts = profile_facts(ctx.warp_kernel_name(), w, h)
+    if facts:
+        if facts.get("trace_avg_us"):
+            ach_p = contract / (facts["trace_avg_us"] * 1e-6) / 1e9
+            out["from_profiles"] = {"avg_launch_us": facts["trace_avg_us"], "achieved": round(ach_p, 1), "frac": round(ach_p / HBM_PEAK_GBS, 4),
+                                    "moved_frac": round(12.0 * P / (facts["trace_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "source": facts.get("trace_source")}
+        if facts.get("issue_cycles_per_wave"):
+            waves = (w // 4) * h / 64.0
+            clk = facts.get("clock_GHz", 2.4)
+            bound_us = facts["issue_cycles_per_wave"] * waves / 1024.0 / (clk * 1e3)
+            out["valu"] = {"issue_cycles_per_wave": facts["issue_cycles_per_wave"], "instructions_per_wave": facts.get("instructions_per_wave"), "waves": int(waves),
+                           "bound_us": round(bound_us, 2), "frac_of_launch": round(bound_us / (per_launch_ms * 1e3), 3) if per_launch_ms > 0 else None,
+                           "note": "vector issue cycles of the kernel's main path by the measured per-instruction costs of gfx950 (profiles/r03_notes.md section 1: "
+                                   "2 cycles full rate, 4 half rate incl. every packed / perm / dot / cvt / min-max, 8 quarter) x waves / 1024 SIMDs / %.1f GHz: the time the "
+                                   "arithmetic alone needs; the binding resource beside the HBM fraction" % clk}
     out.update({"avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
                 "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
                 **dict(zip(("traffic", "traffic_source"), measured_traffic(ctx.warp_kernel_name(), w, h)))})
@@ -117,6 +147,30 @@ def roofline_isolated(ctx, shapes_or_ts, w, h, reps=60):
             "what": "the kernel relaunched back to back on the resident pair's 8th chained frame, nothing else running, outside the timed region; its inputs stay in the memory-side cache between relaunches, so this is the kernel's best case (in the chained frame loop the kernel trace under profiles/ shows it ~10 % slower, the per-dispatch stamps of the timed regions ~25 % slower)"}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_end_to_end(w=512, h=512, n=30):
+    """The WHOLE of poppy::morph on the CPU — the oracle's pair set-up from the raw images + n chained frames — at BASELINE.json configs[0]
+    (512x512, 30 frames; the 1080p set-up of the oracle takes minutes): the CPU figure that covers the same work as the GPU `value`."""
+    import oracle_lib as O
+    from poppy_amd import synth
+    a, b = synth.gen_pair(w, h, seed=1234)
+    t0 = time.perf_counter()
+    frames = O.morph(a, b, n)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(frames) / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"one {w}x{h} pair, oracle pair set-up from the raw images + {len(frames)} chained frames, {dt:.1f} s on 1 thread (BASELINE.json configs[0]); "
+                      "BASELINE.md: the real reference 7.0 frames/s on the build container for the same job"}
+
+
 def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):
     """oracle/ on `frames` chained frames of pair 0, fed with the pair state the GPU set-up produced (points, gabor2), one thread;
     its last frame is compared with the same frame of the GPU run."""
@@ -131,7 +185,25 @@ def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):
         cur, pts = O.morph_images(cur, b, g, pts, p2, s, s, 64)
     dt = time.perf_counter() - t0
     diff = int((cur != gpu_frames[frames - 1]).sum())
+    # every host thread at once: thread k renders its own short chained sequence of the same pair (the oracle library releases the GIL;
+    # independent pairs are what the reference's CLI would run as separate processes)
+    import threading
+    ncores = max(1, min(os.cpu_count() or 1, 64))
+    per_thread = 3
+    def worker():
+        c_, p_ = a, p1
+        for j in range(per_thread):
+            s_ = O.frame_ratio(j, FRAMES, -1.0)
+            c_, p_ = O.morph_images(c_, b, g, p_, p2, s_, s_, 64)
+    th = [threading.Thread(target=worker) for _ in range(ncores)]
+    t1 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    dt_all = time.perf_counter() - t1
     base = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "all_cores": {"value": round(ncores * per_thread / dt_all, 3), "unit": "frames/s", "cores": ncores,
+                          "sample": f"{ncores} threads x {per_thread} chained frames of the same pair at once, {dt_all:.1f} s",
+                          "cpu_model": cpu_model()},
             "sample": f"{frames} chained {a.shape[1]}x{a.shape[0]} frames (j = 0..{frames - 1} of the 60-frame sequence of pair 0, the per-frame operator "
                       f"only: the oracle's pair set-up at this size takes minutes) through oracle/liboracle.so, {dt:.1f} s on 1 of {os.cpu_count()} host threads; "
                       "BASELINE.md: the real reference ran 0.87 frames/s incl. set-up on the build container"}
@@ -140,7 +212,7 @@ def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):
     return base, par
 
 
-def run_cfg3_4k(capi, torch, dev, steps):
+def run_cfg3_4k(capi, torch, dev, steps, check=True):
     """BASELINE.json configs[2]: 3840x2160 pair, 120 phase-mode frames (t_j = j / 120), set-up and writer hand-off inside."""
     w, h, n = 3840, 2160, 120
     a, b = synth_pair(w, h, 0)
@@ -175,7 +247,22 @@ def run_cfg3_4k(capi, torch, dev, steps):
     roof = roofline_of(ctx, warp_ms, warp_n, w, h)
     chained = np.array([capi.lib().poppy_frame_ratio(j, 60, -1.0) for j in range(60)])
     roof["isolated"] = roofline_isolated(ctx, chained, w, h)
+    parity = None
+    if check:
+        try:            # the LAST frame of the 120-frame sequence as the GPU hands it to a writer, against the oracle's frame from the same pair state
+            import oracle_lib as O
+            p1, p2 = ctx.pair_points()
+            g = ctx.fetch("gabor2")
+            last = []
+            ctx.render_many(ts[-1:], chain=False, write=lambda f: last.append(f.copy()))
+            want, _ = O.morph_images(a, b, g, p1, p2, float(ts[-1]), float(ts[-1]), 64)
+            diff = int((want != last[0]).sum())
+            parity = {"frame": n - 1, "equal": diff == 0, "differing_bytes": diff,
+                      "what": f"frame {n - 1} (t = {n}/{n + 1}) of the {n}-frame {w}x{h} sequence as written by the GPU vs the oracle's frame from the same pair state"}
+        except Exception as e:
+            parity = {"error": str(e)}
     out = {"workload": f"{w}x{h} pair, {n} phase-mode frames per step, pair set-up from the raw images and the writer hand-off included",
+           "parity_check": parity,
            "value": round(got / dt, 2), "unit": "frames/s", "mpix_per_s": round(got / dt * w * h / 1e6, 1), "steps": steps,
            "ms_per_step": round(dt / steps * 1e3, 3), "resident_pair_fps": round(steps * n / dt_res, 1), "pair_setup_ms": round(setup_ms, 2),
            "roofline": roof}
@@ -197,6 +284,8 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
+    ap.add_argument("--total-frames", type=int, default=480, help="N > 1: frames of the ONE phase-mode morph that is sharded by frame range (fixed for every N: strong scaling); also the size of the N = 1 line's scaling_baseline_480")
+    ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the 512x512x30 whole-morph CPU figure (~40 s of oracle time)")
     ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 2 (4 measured +3 % at N = 1, at the price of a lower in-bench roofline fraction: more kernels compete)")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
@@ -353,8 +442,54 @@ def bench_single(args, torch, capi, dev, local):
     for _ in range(reps):
         ctx.render_many(ph[1:], chain=False)
     ctx.sync()
-    out["scaling_baseline"] = {"workload": f"one {FRAMES}-frame phase-mode morph per step (what every rank of --gpus N does), set-up and writer included",
+    out["scaling_baseline"] = {"workload": f"one {FRAMES}-frame phase-mode morph per step, set-up and writer included",
                                "fps": round(reps * FRAMES / dtp, 1), "frames_only_fps": round(reps * (FRAMES - 1) / (time.perf_counter() - t1), 1)}
+    # THE denominator of the --gpus N lines (north_star: ">= 7x at 8 GPUs vs 1 GPU on a 480-frame 1080p morph"): the same fixed job —
+    # one TOTAL-frame phase-mode morph, set-up from the raw pair + every frame handed to the writer — on this one GPU
+    TOTAL = args.total_frames
+    ph480 = np.arange(TOTAL) / float(TOTAL)
+
+    def job480():
+        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+        return ctx.render_phases(ph480, counted=True)
+    job480()
+    r480 = max(3, min(reps, 8))
+    t1 = time.perf_counter()
+    for _ in range(r480):
+        job480()
+    ctx.sync()
+    dt480 = time.perf_counter() - t1
+    out["scaling_baseline_480"] = {"workload": f"ONE {TOTAL}-frame phase-mode morph of a {W}x{H} pair on one GPU: pair set-up from the raw images + {TOTAL} frames handed to the writer "
+                                               "(the job every --gpus N line shards by frame range; its `value` / this `fps` = the speed-up)",
+                                   "fps": round(r480 * TOTAL / dt480, 1), "ms_per_job": round(dt480 / r480 * 1e3, 3), "jobs_timed": r480,
+                                   "serial_part_ms": out["pair_setup_ms"],
+                                   "amdahl_note": "with the set-up serial, N GPUs cannot beat (set-up + frames) / (set-up + frames / N)"}
+    # the headline step once more with the raw pairs copied from pinned host memory inside the step (the reference's morph() takes host images)
+    pinned = [(torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory()) for a, b in pairs_host]
+    pool2 = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
+
+    def step_h2d():
+        for (da, db), (ha, hb) in zip(pairs_dev, pinned):
+            da.copy_(ha, non_blocking=True); db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+        return pool2.morph_pairs_device_counted(ptrs, W, H, -1.0)
+    step_h2d()
+    rh = max(3, args.steps // 4)
+    t1 = time.perf_counter()
+    kh = 0
+    for _ in range(rh):
+        kh += step_h2d()
+    dth = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    for _ in range(rh):
+        for (da, db), (ha, hb) in zip(pairs_dev, pinned):
+            da.copy_(ha, non_blocking=True); db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+    out["h2d"] = {"value_incl_h2d": round(kh / dth, 1), "h2d_ms_per_pair": round((time.perf_counter() - t1) / rh / PAIRS * 1e3, 3),
+                  "what": "`value`'s step with the raw pairs (2 x %.1f MB each) copied host -> device inside the step, serially before the pool starts; the timed region of `value` starts with them resident in HBM" % (P * 3 / 1e6)}
+    pool2.close()
+    out["config"]["workload"] += (f"; the {PAIRS} pairs of a step are rendered by a pool of {args.contexts} contexts (pooled headline); the same step on ONE context, "
+                                  f"pair after pair, runs at sequential_fps = {out['sequential_fps']} frames/s")
     # per-kernel breakdown: one untimed sequence with events around every kernel group
     ctx.set_timing(1)
     ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
@@ -377,34 +512,43 @@ def bench_single(args, torch, capi, dev, local):
             ctx.reset()
             ctx.render_many(shapes[:20], chain=True, write=lambda f: got.append(f.copy()))
             out["cpu_baseline"], out["parity_check"] = cpu_baseline_and_parity(ctx, a_h, b_h, got, 20)
+            if not args.no_cpu_end_to_end:
+                out["cpu_baseline"]["end_to_end"] = cpu_end_to_end()
         except Exception as e:   # the checker is optional for the measurement, never for parity
             out["cpu_baseline"] = {"value": None, "error": str(e)}
     ctx.close()
     if not args.no_4k and (W, H) == (1920, 1080):
         try:
-            out["cfg3_4k"] = run_cfg3_4k(capi, torch, dev, max(3, min(args.steps, 10)))
+            out["cfg3_4k"] = run_cfg3_4k(capi, torch, dev, max(3, min(args.steps, 10)), check=not args.no_cpu_baseline)
         except Exception as e:
             out["cfg3_4k"] = {"error": str(e)}
     return out
 
 
 def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, rehearsal):
-    """configs[3]: one 60*world-frame phase-mode morph; set-up on rank 0, one broadcast of the pair state, frame ranges per rank."""
+    """configs[3]: ONE args.total_frames-frame phase-mode morph for every N; set-up on rank 0, one broadcast of the pair state, frame shares per rank."""
     P = W * H
-    total = FRAMES * world
+    total = args.total_frames
     cdev = torch.device("cpu") if rehearsal else dev
     ctx = capi.Context(local, number_of_frames=1)
     if rank == 0:
         a, b = synth_pair(W, H, 0)
         ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
-    ts = sharding.phase_schedule(rank, world, FRAMES)
+    ts = sharding.phase_share(rank, world, total)
     link = sharding.PairLink(torch, dist, capi, ctx, rank, world, W, H, cdev, use_library=not rehearsal)
+    t_setup = [0.0]; t_bcast = [0.0]; t_frames = [0.0]
 
     def step():
+        t0 = time.perf_counter()
         if rank == 0:
             ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+        t1 = time.perf_counter()
         link.broadcast(root=0)
-        return ctx.render_phases(ts, counted=True)        # global frame 0 (t = 0) is the reference's phase == 0 short-circuit: a copy of image 1
+        t2 = time.perf_counter()
+        n = ctx.render_phases(ts, counted=True)        # global frame 0 (t = 0) is the reference's phase == 0 short-circuit: a copy of image 1
+        t3 = time.perf_counter()
+        t_setup[0] += t1 - t0; t_bcast[0] += t2 - t1; t_frames[0] += t3 - t2
+        return n
 
     def fence():
         ctx.sync(); torch.cuda.synchronize()
@@ -414,6 +558,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     for _ in range(args.warmup):
         step()
     ctx.set_timing(2)          # HIP events on the roofline kernel's own dispatch (one launch in seven), as at N = 1; rank 0's launches are reported
+    t_setup[0] = t_bcast[0] = t_frames[0] = 0.0
     fence()
     t0 = time.perf_counter()
     n = 0
@@ -423,14 +568,14 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     dt = time.perf_counter() - t0
     warp_ms, warp_n = next(((ms, c) for nm, ms, c in ctx.timing_summary() if nm == "warp"), (0.0, 0))
     ctx.set_timing(0)
-    assert n == args.steps * FRAMES
+    assert n == args.steps * len(ts)
     dt_max = link.max_time(dt)
     # steady state: the broadcast pair resident, frames only (in HBM)
-    ctx.render_many(ts[1:] if ts[0] == 0.0 else ts, chain=False)
+    ctx.render_many(ts[1:] if len(ts) and ts[0] == 0.0 else ts, chain=False)
     fence()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.render_many(ts[1:] if ts[0] == 0.0 else ts, chain=False)
+        ctx.render_many(ts[1:] if len(ts) and ts[0] == 0.0 else ts, chain=False)
     fence()
     dt_f = link.max_time(time.perf_counter() - t1)
     # configs[4]: independent pairs spread over the GPUs (8 per GPU: 64 pairs on 8), each a whole chained poppy::morph from the raw
@@ -454,24 +599,29 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     out = None
     if rank == 0:
         fps = args.steps * total / dt_max
+        k = float(args.steps)
         out = {
             "metric": "morph frames/sec at 1080p; Mpix/s warped (one %d-frame phase-mode morph sharded by frame range)" % total,
             "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8+f32",
             "data": "synthetic (integer-defined shapes pair, poppy_amd/synth.py); pair state from the real pair set-up on rank 0",
-            "config": {"workload": f"{W}x{H} pair, ONE {total}-frame phase-mode morph (BASELINE.json configs[3] at N = 8): per step the pair set-up on rank 0, "
-                                   f"one broadcast of the pair state ({link.how}), then {FRAMES} frames per GPU handed to a writer",
-                       "frames_per_gpu": FRAMES, "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
+            "config": {"workload": f"{W}x{H} pair, ONE {total}-frame phase-mode morph (BASELINE.json configs[3]), the same job for every N: per step the pair set-up on rank 0, "
+                                   f"one broadcast of the pair state ({link.how}), then each GPU renders its contiguous share of the {total} frames and hands them to a writer",
+                       "total_frames": total, "frames_per_gpu": len(ts), "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
                        "broadcast_bytes": link.nbytes},
             "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
             "frames_only_fps": round(args.steps * total / dt_f, 1),
-            "cfg4_note": "value = configs[3] (one %d-frame morph sharded by frame range)" % total,
+            "amdahl": {"rank0_setup_ms": round(t_setup[0] / k * 1e3, 3), "rank0_broadcast_ms": round(t_bcast[0] / k * 1e3, 3),
+                       "rank0_frames_ms": round(t_frames[0] / k * 1e3, 3),
+                       "note": "host-side wall time on rank 0 per step; the set-up and the broadcast are the serial part of the job: N GPUs cannot beat "
+                               "(set-up + frames) / (set-up + broadcast + frames / N) over the --gpus 1 line's scaling_baseline_480"},
+            "cfg4_note": "value = configs[3] (one %d-frame morph sharded by frame range); speed-up = value / scaling_baseline_480.fps of the --gpus 1 line" % total,
             "cfg5_pairs": {"workload": f"BASELINE.json configs[4]: {ppg * world} independent {W}x{H} pairs x {FRAMES} chained frames, {ppg} pairs per GPU on "
                                        f"{args.contexts} contexts each, set-up from the raw images and the writer hand-off included, no communication",
                            "value": round(reps * ppg * world * FRAMES / dt_p, 2), "unit": "frames/s", "pairs": ppg * world, "steps": reps,
-                           "ms_per_step": round(dt_p / reps * 1e3, 3), "scaling_baseline": "the `value` of the --gpus 1 line (same per-GPU work)"},
-            "scaling_note": "read against `scaling_baseline.fps` (with set-up) or `scaling_baseline.frames_only_fps` of the --gpus 1 line, not against its chained `value`",
+                           "ms_per_step": round(dt_p / reps * 1e3, 3), "scaling": "weak", "scaling_baseline": "the `value` of the --gpus 1 line (same per-GPU work)"},
+            "scaling_note": "read `value` against `scaling_baseline_480.fps` of the --gpus 1 line (the same fixed job on one GPU), not against its chained `value`; `cfg5_pairs.value` against that chained `value` x N",
         }
     ctx.close()
     return out

@@ -85,9 +85,15 @@ int poppy_hip_pair_load_device(poppy_hip_ctx* ctx, const void* d_corrected1, con
 int poppy_hip_render(poppy_hip_ctx* ctx, double shape_ratio, double mask_ratio, int chain,
                      uint8_t* dst, size_t dst_stride);
 int poppy_hip_pair_reset(poppy_hip_ctx* ctx);                 /* back to the state right after pair_load */
-const void* poppy_hip_frame_device(poppy_hip_ctx* ctx);       /* device pointer of the last frame (u8x3, tight) */
-int poppy_hip_sync(poppy_hip_ctx* ctx);                       /* wait for all queued work of this ctx */
-void* poppy_hip_stream(poppy_hip_ctx* ctx);                   /* the hipStream_t all kernels of this ctx run on */
+const void* poppy_hip_frame_device(poppy_hip_ctx* ctx);       /* device pointer of the last frame (u8x3, tight); see poppy_hip_frame_wait */
+int poppy_hip_sync(poppy_hip_ctx* ctx);                       /* wait for all queued work of this ctx (every frame stream included) */
+void* poppy_hip_stream(poppy_hip_ctx* ctx);                   /* the hipStream_t the pair set-up and CHAINED frames run on */
+/* Independent frames (chain == 0, phase mode) run on per-slot streams of their own, several in flight: work queued on
+ * poppy_hip_stream() is NOT ordered behind them.  A caller that renders with dst == NULL and consumes poppy_hip_frame_device() on the
+ * device makes its own stream wait for the frame with poppy_hip_frame_wait (a hipStreamWaitEvent on the frame's completion event;
+ * stream == NULL: the host waits), or calls poppy_hip_sync().  poppy_hip_frame_stream: the stream the last frame was rendered on. */
+int poppy_hip_frame_wait(poppy_hip_ctx* ctx, void* hip_stream);
+void* poppy_hip_frame_stream(poppy_hip_ctx* ctx);
 
 /* Reference frame scheduler (src/poppy.hpp:181-210): shape (= color) ratio of frame j.
  * phase < 0 : default chained mode; 0 <= phase < 1 : phase mode (one frame).                          */
@@ -323,7 +329,8 @@ int poppy_hip_morph_pairs(const int* devices, int n_devices, int contexts_per_de
 
 /* File sinks for the frame hand-off, host only, no codec library: poppy_sink_write has the poppy_write_cb signature
  * (user = the sink), so  poppy_hip_morph(ctx, .., poppy_sink_write, sink, ..)  writes the sequence to disk.  RAW: one file, BGR rows back
- * to back; PPM: one P6 file per frame, `path` is a printf pattern with one %d; Y4M: one YUV4MPEG2 file, C444, full-range BT.601.
+ * to back; PPM: one P6 file per frame, `path` holds exactly one %d, %<width>d or %0<width>d for the frame index (the library substitutes
+ * it itself; any other conversion, or none, makes poppy_sink_open return NULL); Y4M: one YUV4MPEG2 file, C444, full-range BT.601.
  * poppy_sink_close returns the number of frames written, or a negative status if a write failed or a frame had another geometry.   */
 typedef struct poppy_sink poppy_sink;
 enum { POPPY_SINK_RAW = 0, POPPY_SINK_PPM = 1, POPPY_SINK_Y4M = 2 };

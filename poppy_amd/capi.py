@@ -25,7 +25,7 @@ WRITE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int,
 SYMBOLS = [
     "poppy_settings_default", "poppy_hip_create", "poppy_hip_destroy", "poppy_hip_last_error", "poppy_hip_create_error",
     "poppy_hip_morph_images", "poppy_hip_pair_load", "poppy_hip_pair_load_device", "poppy_hip_render", "poppy_hip_pair_reset",
-    "poppy_hip_frame_device", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
+    "poppy_hip_frame_device", "poppy_hip_frame_wait", "poppy_hip_frame_stream", "poppy_hip_sync", "poppy_hip_stream", "poppy_frame_ratio", "poppy_hip_morph_frames",
     "poppy_hip_dissolve", "poppy_hip_set_debug", "poppy_hip_last_warp_kind", "poppy_warp_records", "poppy_hip_hamming_knn2", "poppy_ratio_symmetry",
     "poppy_hip_pair_begin_descriptors", "poppy_hip_warp_affine", "poppy_hip_auto_align", "poppy_hip_align_step",
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
@@ -57,6 +57,9 @@ def lib():
         L.poppy_hip_frame_device.argtypes = [C.c_void_p]
         L.poppy_hip_stream.restype = C.c_void_p
         L.poppy_hip_stream.argtypes = [C.c_void_p]
+        L.poppy_hip_frame_stream.restype = C.c_void_p
+        L.poppy_hip_frame_stream.argtypes = [C.c_void_p]
+        L.poppy_hip_frame_wait.argtypes = [C.c_void_p, C.c_void_p]
         vp, sz, i, d = C.c_void_p, C.c_size_t, C.c_int, C.c_double
         L.poppy_hip_morph_images.argtypes = [vp, vp, sz, vp, sz, vp, i, i, vp, vp, i, d, d, vp, sz, vp]
         L.poppy_hip_pair_load.argtypes = [vp, vp, sz, vp, sz, vp, i, i, vp, vp, i]
@@ -780,3 +783,10 @@ class Context:
 
     def stream_ptr(self):
         return lib().poppy_hip_stream(self.h)
+
+    def frame_stream_ptr(self):
+        return lib().poppy_hip_frame_stream(self.h)
+
+    def frame_wait(self, stream_ptr=None):
+        """Orders `stream_ptr` (a hipStream_t; None: the host) behind the last frame rendered (phase-mode frames run on streams of their own)."""
+        self._chk(lib().poppy_hip_frame_wait(self.h, stream_ptr), "frame_wait")

@@ -109,19 +109,29 @@ int poppy_hip_pair_state_bytes(int width, int height, size_t* bytes) {
 }
 
 // The resident pair of rank `root` becomes the resident pair of every rank: one ncclBroadcast of the packed pair state.
+// Everything that can fail on ONE rank (the root's pair missing or holding more points than the state has room for, an allocation on
+// a receiver) happens first, and the ranks then agree on the outcome through a one-value reduction: a rank never returns with an
+// error while the others are already blocked inside the broadcast.
 int poppy_hip_pair_broadcast(poppy_hip_ctx* c, int root, int W, int H) {
     if (!c) return POPPY_E_ARG;
     if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
-    if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");
+    if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");   // the same on every rank
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if (c->comm_rank == root) {
-        if (!c->pair_ready || c->W != W || c->H != H) return fail(c, POPPY_E_STATE, "the root has no resident pair of this geometry");
-        rc = stage_pair_state(c); if (rc) return rc;
+        if (!c->pair_ready || c->W != W || c->H != H) rc = fail(c, POPPY_E_STATE, "the root has no resident pair of this geometry");
+        else rc = stage_pair_state(c);
     } else {
-        rc = alloc_pair(c, W, H); if (rc) return rc;
-        c->pair_ready = false;
+        rc = alloc_pair(c, W, H);
+        if (rc == POPPY_OK) c->pair_ready = false;
     }
+    if (c->comm_world > 1) {
+        double worst = rc == POPPY_OK ? 0.0 : 1.0;
+        const int ra = poppy_hip_comm_max(c, &worst);              // a collective: entered by every rank whatever its own outcome
+        if (ra != POPPY_OK) return ra;
+        if (rc != POPPY_OK) return rc;
+        if (worst != 0.0) return fail(c, POPPY_E_STATE, "another rank could not take part in the broadcast (its own error says why)");
+    } else if (rc != POPPY_OK) return rc;
     const int nr = rccl()->Broadcast(c->arena, c->arena, c->arena_bytes, kNcclUint8, root, c->comm, c->stream);
     if (nr != 0) return rccl_fail(c, "ncclBroadcast", nr);
     if (c->comm_rank != root) return adopt_pair_state(c);
@@ -262,6 +272,13 @@ void poppy_hip_pool_destroy(poppy_hip_pool* p) {
 int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, double phase, int inputs_on_device,
                                poppy_pair_source_cb source, poppy_write_pair_cb write, void* user, char* err, size_t err_len) {
     if (!p || n_pairs < 0 || !source || W <= 0 || H <= 0) { set_err(err, err_len, "bad arguments"); return POPPY_E_ARG; }
+    // With auto-align the reference's pairs are NOT independent: the aligned second image of one pair is the first image of the next
+    // (src/poppy.cpp:326: img1 = corrected2.clone()), which a caller's pair source cannot know in advance.  Such a sequence is a chain:
+    // poppy_hip_morph pair after pair on one context, feeding poppy_hip_pair_corrected2 forward (include/poppy_hip_shim.hpp does).
+    if (!p->ctx.empty() && p->ctx[0]->cfg.enable_auto_align && n_pairs > 1) {
+        set_err(err, err_len, "enable_auto_align chains the pairs (src/poppy.cpp:326): render them in sequence with poppy_hip_morph, not through the pool");
+        return POPPY_E_UNSUPPORTED;
+    }
     std::atomic<int> next{0}, failed{POPPY_OK};
     std::mutex mu;
     std::string first_err;

@@ -120,7 +120,12 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
         std::vector<float> rad;
         radial_mask(w, h, rad);
         chk(hipMalloc((void**)&radial12, P * 4), "hipMalloc");
-        if (radial12) chk(hipMemcpy(radial12, rad.data(), P * 4, hipMemcpyHostToDevice), "radial mask upload");
+        if (radial12 && hipMemcpy(radial12, rad.data(), P * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            // a table that did not arrive must not survive: the next pair would multiply its mask with uninitialised memory unnoticed
+            (void)hipFree(radial12); radial12 = nullptr;
+            chk(hipErrorUnknown, "radial mask upload");
+        }
+        if (!radial12) return nullptr;
     }
     launch_fg_tail(grey, acc[cur], logtab, radial_mask_on ? radial12 : nullptr, masked, hist, lut, out, dbg_floats, n, s);
     if (dbg) {

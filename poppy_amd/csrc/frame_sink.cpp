@@ -2,7 +2,7 @@
 // cv::VideoWriter (FFV1, src/poppy.cpp:249), which needs a codec library; these need none.  Host only, no GPU involved:
 // poppy_sink_write has the poppy_write_cb signature, so a sink plugs straight into poppy_hip_morph / poppy_hip_morph_frames.
 //   POPPY_SINK_RAW   one file, frames back to back, width*3 bytes per row, BGR (what the writer callback receives)
-//   POPPY_SINK_PPM   one binary PPM (P6, RGB) per frame; the path is a printf pattern with one %d (frame index from 0)
+//   POPPY_SINK_PPM   one binary PPM (P6, RGB) per frame; the path holds exactly one %d / %<width>d / %0<width>d (frame index from 0)
 //   POPPY_SINK_Y4M   one YUV4MPEG2 file, C444, full-range BT.601 in 8-bit integer arithmetic (lossless containers downstream can
 //                    re-encode it; the conversion is this file's, not the reference's)
 #include "../../include/poppy_hip.h"
@@ -13,7 +13,9 @@
 struct poppy_sink {
     int format = 0, w = 0, h = 0, frames = 0;
     bool failed = false;
-    std::string path;
+    std::string path;                  // PPM: the text before the pattern's conversion
+    std::string tail;                  // PPM: the text after it
+    int pad = 0; bool zero = false;    // PPM: width and zero flag of the conversion (%d, %5d, %05d)
     FILE* f = nullptr;
     std::vector<uint8_t> row;
 };
@@ -24,6 +26,27 @@ poppy_sink* poppy_sink_open(const char* path, int format, int width, int height,
     if (!path || width <= 0 || height <= 0 || format < POPPY_SINK_RAW || format > POPPY_SINK_Y4M) return nullptr;
     poppy_sink* s = new poppy_sink();
     s->format = format; s->w = width; s->h = height; s->path = path;
+    if (format == POPPY_SINK_PPM) {
+        // The pattern is parsed here, never handed to printf: exactly one conversion of the form %d / %<width>d / %0<width>d ("%%" is a
+        // literal percent sign); anything else — %s, %n, a second conversion, no conversion at all (every frame would overwrite the
+        // same file) — is refused.
+        std::string head, tail;
+        bool seen = false, bad = false;
+        const std::string pat = path;
+        for (size_t i = 0; i < pat.size() && !bad; ++i) {
+            if (pat[i] != '%') { (seen ? tail : head) += pat[i]; continue; }
+            if (i + 1 < pat.size() && pat[i + 1] == '%') { (seen ? tail : head) += '%'; ++i; continue; }
+            if (seen) { bad = true; break; }
+            size_t j = i + 1;
+            if (j < pat.size() && pat[j] == '0') { s->zero = true; ++j; }
+            int wdt = 0;
+            while (j < pat.size() && pat[j] >= '0' && pat[j] <= '9' && wdt < 100) wdt = wdt * 10 + (pat[j++] - '0');
+            if (j >= pat.size() || pat[j] != 'd' || wdt > 20) { bad = true; break; }
+            s->pad = wdt; seen = true; i = j;
+        }
+        if (bad || !seen) { delete s; return nullptr; }
+        s->path = head; s->tail = tail;
+    }
     if (format != POPPY_SINK_PPM) {
         s->f = fopen(path, "wb");
         if (!s->f) { delete s; return nullptr; }
@@ -40,9 +63,10 @@ void poppy_sink_write(void* user, const uint8_t* bgr, int width, int height, siz
     if (!bgr || width != s->w || height != s->h || stride < (size_t)width * 3) { s->failed = true; return; }
     FILE* f = s->f;
     if (s->format == POPPY_SINK_PPM) {
-        char name[4096];
-        snprintf(name, sizeof name, s->path.c_str(), s->frames);
-        f = fopen(name, "wb");
+        std::string num = std::to_string(s->frames);
+        if ((int)num.size() < s->pad) num.insert(0, (size_t)s->pad - num.size(), s->zero ? '0' : ' ');
+        const std::string name = s->path + num + s->tail;
+        f = fopen(name.c_str(), "wb");
         if (!f) { s->failed = true; return; }
         fprintf(f, "P6\n%d %d\n255\n", width, height);
     } else if (s->format == POPPY_SINK_Y4M) {

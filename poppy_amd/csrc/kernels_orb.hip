@@ -319,9 +319,12 @@ __global__ void __launch_bounds__(256) k_orb_describe(const uint8_t* __restrict_
 // best is (distance, index) with the lower index winning ties, reduced across the wave with shuffles.
 // ------------------------------------------------------------------------------------------------
 constexpr int kHamTile = 512;
+// LDS tile of train descriptors, word-major: tile[k * kHamStride + j] = word k of descriptor j.  The lanes of a wave read consecutive j
+// (one bank each); descriptor-major (tile[j * 8 + k]) put them 8 dwords apart, an 8-way bank conflict on every read.
+constexpr int kHamStride = kHamTile + 1;
 
 __global__ void __launch_bounds__(256) k_hamming(const uint32_t* __restrict__ query, int nq, const uint32_t* __restrict__ train, int nt, int* __restrict__ out2) {
-    __shared__ uint32_t tile[kHamTile * 8];
+    __shared__ uint32_t tile[kHamStride * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + wave;
     uint32_t q[8];
@@ -331,12 +334,12 @@ __global__ void __launch_bounds__(256) k_hamming(const uint32_t* __restrict__ qu
     for (int base = 0; base < nt; base += kHamTile) {
         const int cnt = min(kHamTile, nt - base);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[e] = train[(size_t)base * 8 + e];
+        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[(e & 7) * kHamStride + (e >> 3)] = train[(size_t)base * 8 + e];
         __syncthreads();
         for (int j = lane; j < cnt; j += 64) {
             int d = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[j * 8 + k]);
+            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[k * kHamStride + j]);
             if (d < bestD) { bestD = d; bestJ = base + j; }      // ascending j per lane: strict < keeps the lowest index
         }
     }
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(256) k_hamming(const uint32_t* __restrict__ qu
 __device__ __forceinline__ bool knn_less(int d, int j, int od, int oj) { return d < od || (d == od && j < oj); }
 
 __global__ void __launch_bounds__(256) k_hamming_knn2(const uint32_t* __restrict__ query, int nq, const uint32_t* __restrict__ train, int nt, int* __restrict__ out4) {
-    __shared__ uint32_t tile[kHamTile * 8];
+    __shared__ uint32_t tile[kHamStride * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + wave;
     uint32_t q[8];
@@ -364,12 +367,12 @@ __global__ void __launch_bounds__(256) k_hamming_knn2(const uint32_t* __restrict
     for (int base = 0; base < nt; base += kHamTile) {
         const int cnt = min(kHamTile, nt - base);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[e] = train[(size_t)base * 8 + e];
+        for (int e = threadIdx.x; e < cnt * 8; e += 256) tile[(e & 7) * kHamStride + (e >> 3)] = train[(size_t)base * 8 + e];
         __syncthreads();
         for (int j = lane; j < cnt; j += 64) {
             int d = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[j * 8 + k]);
+            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ tile[k * kHamStride + j]);
             const int jj = base + j;                              // ascending per lane
             if (d < d0) { d1 = d0; j1 = j0; d0 = d; j0 = jj; }
             else if (d < d1) { d1 = d; j1 = jj; }

@@ -37,30 +37,30 @@ constexpr int kMog2Modes = 5;
 // or a memory round trip of the model between steps did not help).  The call costs nothing that matters here.
 __device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Modes], float (&mu)[kMog2Modes], int& nmodes,
                                          float data, float alphaT, float prune) {
-    const float Tb = 16.f, TB = 0.9f, Tg = 9.f, varInit = 15.f, varMin = 4.f, varMax = 75.f, tau = 0.5f;
-    const float alpha1 = 1.f - alphaT;
-    bool background = false, fitsPDF = false;
-    float totalWeight = 0.f;
+    const float kBgSigma2 = 16.f, kBgShare = 0.9f, kMatchSigma2 = 9.f, kVar0 = 15.f, kVarLo = 4.f, kVarHi = 75.f, kShadowLo = 0.5f;
+    const float keep = 1.f - alphaT;
+    bool background = false, matched = false;
+    float wsum = 0.f;
 #pragma unroll
     for (int mode = 0; mode < kMog2Modes; ++mode) {
         if (mode < nmodes) {                               // nmodes shrinks inside the loop when a mode is pruned
-            float wgt = alpha1 * w[mode] + prune;
+            float wgt = keep * w[mode] + prune;
             int dst = mode;
-            if (!fitsPDF) {
+            if (!matched) {
                 const float var = v[mode];
-                const float dD = mu[mode] - data;
-                float dist2 = 0.f;
-                dist2 += dD * dD;
-                if (totalWeight < TB && dist2 < Tb * var) background = true;
-                if (dist2 < Tg * var) {
-                    fitsPDF = true;
+                const float delta = mu[mode] - data;
+                float d2 = 0.f;
+                d2 += delta * delta;
+                if (wsum < kBgShare && d2 < kBgSigma2 * var) background = true;
+                if (d2 < kMatchSigma2 * var) {
+                    matched = true;
                     wgt += alphaT;
                     const float k = __fdiv_rn(alphaT, wgt);
-                    mu[mode] -= k * dD;
-                    float varnew = var + k * (dist2 - var);
-                    varnew = fmaxf(varnew, varMin);
-                    varnew = fminf(varnew, varMax);
-                    v[mode] = varnew;
+                    mu[mode] -= k * delta;
+                    float var_upd = var + k * (d2 - var);
+                    var_upd = fmaxf(var_upd, kVarLo);
+                    var_upd = fminf(var_upd, kVarHi);
+                    v[mode] = var_upd;
 #pragma unroll
                     for (int i = kMog2Modes - 1; i > 0; --i) {   // bubble the matched mode up while its new weight is not smaller
                         if (i <= dst && i == dst && !(wgt < w[i - 1])) {
@@ -76,15 +76,15 @@ __device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Mo
             if (wgt < -prune) { wgt = 0.f; --nmodes; }
 #pragma unroll
             for (int k = 0; k < kMog2Modes; ++k) if (k == dst) w[k] = wgt;          // w[dst] = wgt without indexing the registers
-            totalWeight += wgt;
+            wsum += wgt;
         }
     }
-    float invWeight = 0.f;
-    if (fabsf(totalWeight) > 1.1920928955078125e-7f) invWeight = __fdiv_rn(1.f, totalWeight);
+    float wnorm = 0.f;
+    if (fabsf(wsum) > 1.1920928955078125e-7f) wnorm = __fdiv_rn(1.f, wsum);
 #pragma unroll
     for (int mode = 0; mode < kMog2Modes; ++mode)
-        if (mode < nmodes) w[mode] *= invWeight;
-    if (!fitsPDF && alphaT > 0.f) {
+        if (mode < nmodes) w[mode] *= wnorm;
+    if (!matched && alphaT > 0.f) {
         const int mode = nmodes == kMog2Modes ? kMog2Modes - 1 : nmodes++;
         if (nmodes == 1) {
 #pragma unroll
@@ -93,11 +93,11 @@ __device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Mo
 #pragma unroll
             for (int k = 0; k < kMog2Modes; ++k) {
                 if (k == mode) w[k] = alphaT;
-                else if (k < nmodes - 1) w[k] *= alpha1;
+                else if (k < nmodes - 1) w[k] *= keep;
             }
         }
 #pragma unroll
-        for (int k = 0; k < kMog2Modes; ++k) if (k == mode) { mu[k] = data; v[k] = varInit; }
+        for (int k = 0; k < kMog2Modes; ++k) if (k == mode) { mu[k] = data; v[k] = kVar0; }
         int pos = nmodes - 1;
 #pragma unroll
         for (int i = kMog2Modes - 1; i > 0; --i) {
@@ -113,26 +113,26 @@ __device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Mo
     int out = 0;
     if (!background) {
         out = 255;
-        float tWeight = 0.f;                               // detectShadowGMM
+        float wacc = 0.f;                               // detectShadowGMM
         bool done = false;
 #pragma unroll
         for (int mode = 0; mode < kMog2Modes; ++mode) {
             if (mode < nmodes && !done) {
-                float numerator = 0.f, denominator = 0.f;
-                numerator += data * mu[mode];
-                denominator += mu[mode] * mu[mode];
-                if (denominator == 0.f) done = true;
+                float dot_xm = 0.f, dot_mm = 0.f;
+                dot_xm += data * mu[mode];
+                dot_mm += mu[mode] * mu[mode];
+                if (dot_mm == 0.f) done = true;
                 else {
-                    if (numerator <= denominator && numerator >= tau * denominator) {
-                        const float a = __fdiv_rn(numerator, denominator);
-                        float dist2a = 0.f;
-                        const float dDs = a * mu[mode] - data;
-                        dist2a += dDs * dDs;
-                        if (dist2a < Tb * v[mode] * a * a) { out = 127; done = true; }
+                    if (dot_xm <= dot_mm && dot_xm >= kShadowLo * dot_mm) {
+                        const float a = __fdiv_rn(dot_xm, dot_mm);
+                        float resid2 = 0.f;
+                        const float resid = a * mu[mode] - data;
+                        resid2 += resid * resid;
+                        if (resid2 < kBgSigma2 * v[mode] * a * a) { out = 127; done = true; }
                     }
                     if (!done) {
-                        tWeight += w[mode];
-                        if (tWeight > TB) done = true;
+                        wacc += w[mode];
+                        if (wacc > kBgShare) done = true;
                     }
                 }
             }

@@ -216,11 +216,17 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
     for (int k = 0; k < 4; ++k) {
         const int li = (int)((ids >> (8 * k)) & 255u);
         float4 A, B, C, D; f2 E;
+#ifdef POPPY_WARP_COUNT_MAIN
+        {
+#else
         if (li < kSlots) {
+#endif
             A = s_rec[li * 5]; B = s_rec[li * 5 + 1]; C = s_rec[li * 5 + 2]; D = s_rec[li * 5 + 3];
             const float4 e4 = s_rec[li * 5 + 4];
             E = f2{e4.x, e4.y};
-        } else {                                                 // a tile with more triangles than the slots hold
+        }
+#ifndef POPPY_WARP_COUNT_MAIN
+        else {                                                   // a tile with more triangles than the slots hold
             const uint32_t ro = over_base + (uint32_t)(tile_off[tile] + li - 1) * kEntryBytes;
             A = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro, 0, 0));
             B = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 16, 0, 0));
@@ -228,6 +234,7 @@ __global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec
             D = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdata, ro + 48, 0, 0));
             E = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rdata, ro + 64, 0, 0));
         }
+#endif
         warp_taps(A, B, C, D, E, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
     }
     warp_fetch_blend_store(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {

@@ -764,6 +764,20 @@ int poppy_hip_render(poppy_hip_ctx* c, double shape, double mask, int chain, uin
 }
 
 const void* poppy_hip_frame_device(poppy_hip_ctx* c) { return (c && c->last_slot >= 0) ? c->slots[c->last_slot].out : nullptr; }
+void* poppy_hip_frame_stream(poppy_hip_ctx* c) {
+    if (!c || c->last_slot < 0) return nullptr;
+    const FrameSlot& f = c->slots[c->last_slot];
+    return (void*)(f.last_stream ? f.last_stream : c->stream);
+}
+int poppy_hip_frame_wait(poppy_hip_ctx* c, void* hip_stream) {
+    if (!c) return POPPY_E_ARG;
+    if (c->last_slot < 0) return fail(c, POPPY_E_STATE, "no frame rendered");
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameSlot& f = c->slots[c->last_slot];
+    if (hip_stream) HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, f.done, 0));
+    else HIPCHK(c, hipEventSynchronize(f.done));
+    return POPPY_OK;
+}
 
 int poppy_hip_morph_images(poppy_hip_ctx* c, const uint8_t* c1, size_t s1, const uint8_t* c2, size_t s2, const float* gabor2, int W, int H,
                            const float* p1, const float* p2, int n, double shape, double mask, uint8_t* dst, size_t dst_stride, float* morphed) {

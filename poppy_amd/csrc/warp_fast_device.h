@@ -122,6 +122,7 @@ __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amd
     const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
     __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, g * 12u, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, g * 12u, 0, 0);
+#ifndef POPPY_WARP_COUNT_MAIN          // tools/warp_facts.py counts the main path's instructions with the rare paths compiled out
     uint32_t edges = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
@@ -134,6 +135,7 @@ __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amd
             dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
     }
+#endif
 }
 
 // the eight taps of one pixel pair from its record (A..E as laid out by pack_warp_records)

@@ -25,6 +25,19 @@ def phase_schedule(rank, world, frames_per_rank):
     return np.array([j / total for j in frame_range(rank, world, frames_per_rank)], dtype=np.float64)
 
 
+def frame_share(rank, world, total_frames):
+    """Global frame indices of `rank` when ONE total_frames-frame morph is split over `world` ranks (strong scaling: the job is fixed):
+    the rank-th contiguous share, [total * rank / world, total * (rank + 1) / world) — what poppy_hip_morph_sharded gives device k."""
+    if not (0 <= rank < world) or total_frames < 0:
+        raise ValueError("bad rank / world / total_frames")
+    return range(total_frames * rank // world, total_frames * (rank + 1) // world)
+
+
+def phase_share(rank, world, total_frames):
+    """shape = mask ratio of every frame of `rank`'s share of the fixed job: t_j = j / total_frames (float64 as the reference's)."""
+    return np.array([j / float(total_frames) for j in frame_share(rank, world, total_frames)], dtype=np.float64)
+
+
 def pair_range(rank, world, n_pairs):
     """Pairs rendered by `rank` when n_pairs independent pairs are split over the ranks (BASELINE.json configs[4]: 64 pairs over 8
     GPUs): contiguous, disjoint, complete; the first n_pairs % world ranks take one more."""

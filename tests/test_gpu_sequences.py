@@ -236,3 +236,38 @@ def test_morph_pairs_one_device():
         assert len(out[p]) == n
         for j, f in enumerate(out[p]):
             G.check(cases[p], f"frame{j}", f)
+
+
+def test_pool_refuses_several_pairs_under_auto_align():
+    """With --autoalign the reference's pairs form a chain (src/poppy.cpp:326: img1 = corrected2.clone(), the ALIGNED image): the pool, which
+    hands pairs out concurrently, refuses more than one of them instead of silently rendering a different sequence."""
+    from poppy_amd import capi
+    inp = G.astage_inputs("a_256x256_chain")
+    n = int(inp["cfg"][0])
+    with pytest.raises(capi.PoppyError, match="auto_align"):
+        capi.morph_pairs([0], [(inp["img1"], inp["img2"])] * 2, contexts_per_device=2, number_of_frames=n, enable_auto_align=1)
+    out = capi.morph_pairs([0], [(inp["img1"], inp["img2"])], contexts_per_device=2, number_of_frames=n, enable_auto_align=1)    # one pair: fine
+    assert len(out[0]) == n
+
+
+def test_frame_wait_orders_a_caller_stream_behind_a_phase_mode_frame():
+    """Phase-mode frames run on per-slot streams: poppy_hip_frame_wait makes a caller's stream (here: the context's own) wait for the
+    last frame, so that device work queued there reads the finished image (the hand-off contract of include/poppy_hip.h)."""
+    import ctypes as C
+    from poppy_amd import capi
+    inp = G.astage_inputs("a_256x256_phase")
+    ctx = capi.Context(0, number_of_frames=1)
+    ctx.pair_begin(inp["img1"], inp["img2"])
+    want = ctx.render(0.5, 0.5, chain=False)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    got = np.zeros_like(want)
+    for _ in range(20):
+        ctx.render_many(np.array([0.25, 0.5]), chain=False)                 # two frames in flight, nothing downloaded, no sync
+        assert ctx.frame_stream_ptr() != ctx.stream_ptr()
+        ctx.frame_wait(ctx.stream_ptr())
+        assert hip.hipMemcpyAsync(got.ctypes.data, ctx.frame_device_ptr(), got.nbytes, 2, ctx.stream_ptr()) == 0    # 2 = device to host
+        assert hip.hipStreamSynchronize(ctx.stream_ptr()) == 0
+        assert (got == want).all()
+    ctx.close()

@@ -218,3 +218,18 @@ def test_file_sinks(tmp_path):
     s = L.poppy_sink_open(str(raw).encode(), 0, w, h, 30, 1)
     L.poppy_sink_write(s, padded[0].ctypes.data, w + 1, h, padded[0].strides[0])
     assert L.poppy_sink_close(s) < 0
+
+
+def test_ppm_sink_pattern_is_parsed_not_printed(tmp_path):
+    """The PPM path is never handed to printf: exactly one %d / %<w>d / %0<w>d is substituted by the library, "%%" is a literal percent
+    sign, everything else (no conversion, a second one, %s, %n, %x) is refused at open."""
+    L = capi.lib()
+    for bad in ("plain.ppm", "a%d_%d.ppm", "x%s.ppm", "x%n.ppm", "x%x.ppm", "x%", "x%5", "x%999999999d.ppm"):
+        assert not L.poppy_sink_open(str(tmp_path / bad).encode(), 1, 4, 4, 30, 1), bad
+    f = np.zeros((4, 4, 3), np.uint8)
+    for pat, name in (("p%d.ppm", "p0.ppm"), ("q%4d.ppm", "q   0.ppm"), ("r%03d_100%%.ppm", "r000_100%.ppm")):
+        s = L.poppy_sink_open(str(tmp_path / pat).encode(), 1, 4, 4, 30, 1)
+        assert s, pat
+        L.poppy_sink_write(s, f.ctypes.data, 4, 4, f.strides[0])
+        assert L.poppy_sink_close(s) == 1
+        assert (tmp_path / name).exists(), name

@@ -133,3 +133,24 @@ def test_partition_properties():
         assert np.array_equal(all_t, np.arange(60 * world) / float(60 * world))
     with pytest.raises(ValueError):
         sharding.frame_range(2, 2, 60)
+
+
+def test_fixed_job_shares():
+    """Strong scaling: ONE total-frame morph split over N ranks (bench.py --gpus N, poppy_hip_morph_sharded): contiguous, disjoint, complete
+    shares of [0, total), every frame's phase is j / total whatever N is, and the shares agree with the weak-scaling schedule when total = 60 N."""
+    for total in (480, 481, 7, 1):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                fr = list(sharding.frame_share(r, world, total))
+                assert fr == list(range(total * r // world, total * (r + 1) // world))
+                ts = sharding.phase_share(r, world, total)
+                assert np.array_equal(ts, np.array(fr, dtype=np.float64) / float(total))
+                seen += fr
+            assert seen == list(range(total))
+    for world in (1, 2, 4, 8):
+        for r in range(world):
+            assert np.array_equal(sharding.phase_share(r, world, 60 * world), sharding.phase_schedule(r, world, 60))
+    assert len(sharding.frame_share(7, 8, 480)) == 60
+    with pytest.raises(ValueError):
+        sharding.frame_share(8, 8, 480)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes profiles/r02_warp_pmc.json (the per-launch HBM bytes bench.py quotes as roofline.traffic) and prints the per-kernel
+"""Writes profiles/<round>_warp_pmc.json (round = the tag up to its first underscore) (the per-launch HBM bytes bench.py quotes as roofline.traffic) and prints the per-kernel
 tables of profiles/<tag>_pmc.md from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh:
     tools/pmc_json.py <tag>      reads gpurun_out/<tag>_{fetch,write}_{1920,3840}/*.db
 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: wide coalesced reads are tallied at half their bytes on this image);
@@ -28,7 +28,7 @@ for w, h in ((1920, 1080), (3840, 2160)):
     best = {}
     for (name, grid), (n, f) in fetch.items():          # the largest launch geometry of each kernel = its level-0 / full-frame form
         base = name.split("<")[0]
-        if base not in ("k_unsharp_tile", "k_collapse_level", "k_pyrdown_level", "k_tile_expand", "k_warp_bin", "k_gray_inv"):
+        if base not in ("k_unsharp_tile", "k_unsharp_stream", "k_collapse_level", "k_pyrdown_level", "k_tile_expand", "k_warp_bin", "k_gray_inv"):
             continue
         if base not in best or grid > best[base][0]:
             best[base] = (grid, name)
@@ -37,4 +37,4 @@ for w, h in ((1920, 1080), (3840, 2160)):
         sz[base] = {"fetch_bytes": int(round(2 * f)), "write_bytes": int(round(wv))}
         print(f"{w}x{h} {name} grid {grid}: read {2 * f / px:.2f} B/px, written {wv / px:.2f} B/px")
     out[f"{w}x{h}"] = sz
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", tag.split("_")[0] + "_warp_pmc.json"), "w"), indent=1)
