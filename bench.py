@@ -254,6 +254,7 @@ def run_cfg3_4k(capi, torch, dev, steps, check=True):
             p1, p2 = ctx.pair_points()
             g = ctx.fetch("gabor2")
             last = []
+            ctx.reset()                          # back to the pair's own first image (the isolated-kernel run above left a chained state)
             ctx.render_many(ts[-1:], chain=False, write=lambda f: last.append(f.copy()))
             want, _ = O.morph_images(a, b, g, p1, p2, float(ts[-1]), float(ts[-1]), 64)
             diff = int((want != last[0]).sum())

@@ -15,6 +15,7 @@ static void put_img(uint8_t* dst, const ImageU8& m) { if (dst) memcpy(dst, m.d.d
 extern "C" {
 
 int orc_round_f(float v) { return cv_round_f(v); }
+int orc_round_d(double v) { return cv_round(v); }
 
 void orc_clip_points(float* pts, int n, int cols, int rows) {
     auto v = wrap_pts(pts, n); clip_points(v, cols, rows); memcpy(pts, v.data(), (size_t)n * 8);

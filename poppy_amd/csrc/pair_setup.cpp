@@ -3,6 +3,7 @@
 // (poppy::morph up to its frame loop, src/poppy.hpp:46-160, incl. Matcher::find / prepare and the auto-align), blur_margin.
 // The per-frame path and the context itself live in poppy_hip.cpp; both share context.h.
 #include "context.h"
+#include <chrono>
 #include "dft_exact.h"
 
 extern "C" {
@@ -184,12 +185,19 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
         rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
     }
+    // POPPY_SETUP_TIMING: host wall time of the set-up's stages on stderr (chains = foreground + detail + ORB input (+ gabor2) of both
+    // images side by side; detect = the two ORB detections; match = the host matcher; finish = m2 + the pair state)
+    static const bool stage_times = getenv("POPPY_SETUP_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double ms_upload = 0, ms_chains = 0, ms_detect = 0, ms_match = 0;
     std::vector<uint8_t> g[2];
     if (ratio >= 0.f) { g[0].resize(P); g[1].resize(P); }
     const uint8_t* g_dev[2] = {nullptr, nullptr};
     double d[2] = {0, 0};
     if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamSynchronize(c->stream));                         // the uploads above
+    ms_upload = since(t_begin);
     // The two images go through the chain independently (Extractor::foreground -> dft_detail2 -> the ORB input of
     // Extractor::keypoints; image 2 also through gabor_filter(corrected2 / 255), src/poppy.hpp:119-122): one host thread and
     // one stream each, so that the medians of one image run beside the Gabor bank of the other.
@@ -222,6 +230,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         other.join();
     }
     for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
+    ms_chains = since(t_begin);
     const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
     c->last_detail[0] = d[0]; c->last_detail[1] = d[1];
     const int nfeatures = (int)(c->cfg.max_keypoints * detail);
@@ -234,6 +243,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         other.join();
         if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }
+    ms_detect = since(t_begin);
     if (ratio >= 0.f) {
         // Opt-in descriptor mode (the reference only sketched it, src/experiments.hpp:14-144): ORB::compute on both
         // keypoint sets, 2-NN Hamming both ways, ratio test, symmetry test; the surviving pairs, in query order, become the
@@ -295,8 +305,12 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (rc) return fail(c, rc, "poppy_match_points failed");
         rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
     }
+    ms_match = since(t_begin);
     rc = finish_pair_load(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stage_times)
+        fprintf(stderr, "pair set-up %dx%d: upload %.3f, chains %.3f, detect %.3f, match %.3f, finish %.3f ms (cumulative)\n", W, H, ms_upload, ms_chains,
+                ms_detect, ms_match, since(t_begin));
     return POPPY_OK;
 }
 
