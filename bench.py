@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
     ap.add_argument("--total-frames", type=int, default=480, help="N > 1: frames of the ONE phase-mode morph that is sharded by frame range (fixed for every N: strong scaling); also the size of the N = 1 line's scaling_baseline_480")
+    ap.add_argument("--no-shard-setup", action="store_true", help="N > 1: pair set-up on rank 0 alone + one broadcast of the pair state (round 2's form) instead of the set-up spread over ranks 0-2")
     ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the 512x512x30 whole-morph CPU figure (~40 s of oracle time)")
     ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 2 (4 measured +3 % at N = 1, at the price of a lower in-bench roofline fraction: more kernels compete)")
     args = ap.parse_args()
@@ -539,13 +540,19 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     link = sharding.PairLink(torch, dist, capi, ctx, rank, world, W, H, cdev, use_library=not rehearsal)
     t_setup = [0.0]; t_bcast = [0.0]; t_frames = [0.0]
 
+    shard_setup = link.library and not args.no_shard_setup
+
     def step():
         t0 = time.perf_counter()
-        if rank == 0:
-            ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
-        t1 = time.perf_counter()
-        link.broadcast(root=0)
-        t2 = time.perf_counter()
+        if shard_setup:          # the set-up itself spread over the ranks (image 1 on rank 0, image 2 on rank 1, the mask field on rank 2), one collective call
+            ctx.pair_begin_sharded(ta.data_ptr() if rank == 0 else None, tb.data_ptr() if rank == 0 else None, W, H, 0)
+            t1 = t2 = time.perf_counter()
+        else:
+            if rank == 0:
+                ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+            t1 = time.perf_counter()
+            link.broadcast(root=0)
+            t2 = time.perf_counter()
         n = ctx.render_phases(ts, counted=True)        # global frame 0 (t = 0) is the reference's phase == 0 short-circuit: a copy of image 1
         t3 = time.perf_counter()
         t_setup[0] += t1 - t0; t_bcast[0] += t2 - t1; t_frames[0] += t3 - t2
@@ -607,9 +614,11 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8+f32",
             "data": "synthetic (integer-defined shapes pair, poppy_amd/synth.py); pair state from the real pair set-up on rank 0",
-            "config": {"workload": f"{W}x{H} pair, ONE {total}-frame phase-mode morph (BASELINE.json configs[3]), the same job for every N: per step the pair set-up on rank 0, "
-                                   f"one broadcast of the pair state ({link.how}), then each GPU renders its contiguous share of the {total} frames and hands them to a writer",
-                       "total_frames": total, "frames_per_gpu": len(ts), "mode": "phase", "parallelism": f"frame-range x{world}", "broadcast": link.how,
+            "config": {"workload": f"{W}x{H} pair, ONE {total}-frame phase-mode morph (BASELINE.json configs[3]), the same job for every N: per step the pair set-up "
+                                   + ("spread over ranks 0-2 (image 1 / image 2 / mask field; raw pair, detail values, keypoints, point sets and mask field exchanged through the library's RCCL communicator), "
+                                      if shard_setup else f"on rank 0, one broadcast of the pair state ({link.how}), ") +
+                                   f"then each GPU renders its contiguous share of the {total} frames and hands them to a writer",
+                       "total_frames": total, "frames_per_gpu": len(ts), "mode": "phase", "parallelism": f"frame-range x{world}", "setup": "sharded over ranks 0-2" if shard_setup else "rank 0", "broadcast": link.how,
                        "broadcast_bytes": link.nbytes},
             "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
             "frames_only_fps": round(args.steps * total / dt_f, 1),

@@ -286,6 +286,14 @@ int poppy_hip_comm_id(uint8_t* id128);
 int poppy_hip_comm_init(poppy_hip_ctx* ctx, int rank, int world, const uint8_t* id128);
 int poppy_hip_comm_free(poppy_hip_ctx* ctx);
 int poppy_hip_pair_broadcast(poppy_hip_ctx* ctx, int root, int width, int height);
+/* The pair set-up ITSELF spread over the communicator's ranks — a collective that replaces poppy_hip_pair_begin_device + poppy_hip_pair_broadcast
+ * (the serial part of a sharded morph): rank `root` holds the raw pair (device pointers; the other ranks pass NULL) and filters / detects image 1,
+ * rank root + 1 does image 2, rank root + 2 the mask field (src/poppy.hpp:52,114-122: independent until the matcher); the raw pair, the
+ * two dft_detail2 values, image 2's keypoint positions, the matched point sets and the mask field's grey complement are exchanged through the
+ * communicator.  Afterwards every rank holds the resident pair exactly as poppy_hip_pair_begin_device would have produced it on one GPU.
+ * POPPY_E_UNSUPPORTED with enable_auto_align.  _local: the same protocol between n contexts of THIS process (host threads; context k = rank k). */
+int poppy_hip_pair_begin_sharded(poppy_hip_ctx* ctx, const void* d_bgr1, const void* d_bgr2, int width, int height, int root);
+int poppy_hip_pair_begin_sharded_local(poppy_hip_ctx** ctxs, int n, const void* d_bgr1, const void* d_bgr2, int width, int height, int root);
 int poppy_hip_comm_max(poppy_hip_ctx* ctx, double* value);
 int poppy_hip_pair_state_bytes(int width, int height, size_t* bytes);
 int poppy_hip_pair_export_device(poppy_hip_ctx* ctx, void* d_dst, size_t bytes);

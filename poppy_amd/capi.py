@@ -32,7 +32,7 @@ SYMBOLS = [
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
     "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
-    "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
+    "poppy_hip_pair_begin_sharded", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
@@ -133,6 +133,8 @@ def lib():
         L.poppy_hip_morph_sharded.argtypes = [vp, i, vp, vp, sz, vp, sz, i, i, i, vp, vp, vp, sz]
         L.poppy_hip_morph_pairs.argtypes = [vp, i, i, vp, i, i, i, d, vp, vp, vp, vp, sz]
         L.poppy_hip_pair_begin_device.argtypes = [vp, vp, vp, i, i]
+        L.poppy_hip_pair_begin_sharded.argtypes = [vp, vp, vp, i, i, i]
+        L.poppy_hip_pair_begin_sharded_local.argtypes = [C.POINTER(vp), i, vp, vp, i, i, i]
         L.poppy_hip_morph.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, vp, vp, vp]
         L.poppy_hip_pair_distance.argtypes = [vp, vp]
         L.poppy_printed_morph_distance.argtypes = [vp, vp, i, i, i, vp]
@@ -330,6 +332,16 @@ def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True,
     return {p: [v[j] for j in sorted(v)] for p, v in out.items()} if collect else count[0]
 
 
+def pair_begin_sharded_local(ctxs, d1, d2, w, h, root=0):
+    """The sharded pair set-up between contexts of this process (context k plays rank k; d1 / d2 valid for ctxs[root]'s device)."""
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    rc = lib().poppy_hip_pair_begin_sharded_local(arr, len(ctxs), d1, d2, w, h, root)
+    if rc:
+        raise PoppyError(f"pair_begin_sharded_local: {rc}: " + "; ".join(lib().poppy_hip_last_error(c.h).decode() for c in ctxs))
+    for c in ctxs:
+        c.w, c.h_ = w, h
+
+
 class Pool:
     """Persistent contexts for batches of independent pairs (poppy_hip_pool_*)."""
 
@@ -515,6 +527,12 @@ class Context:
         lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), d)
         return nf.value, (d[0], d[1])
 
+    def pair_begin_info(self):
+        """(nfeatures, (detail of image 1, of image 2)) of the resident pair's set-up."""
+        nf = C.c_int(0); d = (C.c_double * 2)()
+        lib().poppy_hip_pair_begin_info(self.h, C.byref(nf), d)
+        return nf.value, (d[0], d[1])
+
     def comm_init(self, rank, world, id128):
         buf = (C.c_uint8 * 128).from_buffer_copy(id128)
         self._chk(lib().poppy_hip_comm_init(self.h, rank, world, buf), "comm_init")
@@ -536,6 +554,12 @@ class Context:
 
     def pair_import_device(self, d_src, nbytes, w, h):
         self._chk(lib().poppy_hip_pair_import_device(self.h, d_src, nbytes, w, h), "pair_import_device")
+        self.w, self.h_ = w, h
+
+    def pair_begin_sharded(self, d1, d2, w, h, root=0):
+        """Collective over this context's communicator: the pair set-up itself spread over the ranks (d1 / d2: device pointers of the raw
+        pair on rank `root`, None elsewhere); every rank ends up with the resident pair."""
+        self._chk(lib().poppy_hip_pair_begin_sharded(self.h, d1, d2, w, h, root), "pair_begin_sharded")
         self.w, self.h_ = w, h
 
     def pair_begin_device(self, d1, d2, w, h):

@@ -17,7 +17,10 @@
 #include "context.h"
 #include <dlfcn.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -139,22 +142,26 @@ int poppy_hip_pair_broadcast(poppy_hip_ctx* c, int root, int W, int H) {
     return POPPY_OK;
 }
 
-// max over the ranks of a host double (step timing), through the same communicator
-int poppy_hip_comm_max(poppy_hip_ctx* c, double* value) {
-    if (!c || !value) return POPPY_E_ARG;
-    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+// max over the ranks of n <= 8 host doubles (step timing, the set-up's detail values and status flags), through the same communicator;
+// the device scratch is allocated once per context (hipMalloc / hipFree per call cost more than the reduction)
+static int comm_max_n(poppy_hip_ctx* c, double* values, int n) {
+    if (n < 1 || n > 8) return fail(c, POPPY_E_ARG, "comm_max_n: 1..8 values");
     HIPCHK(c, hipSetDevice(c->device));
-    double* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, 8));
-    hipError_t e = hipMemcpyAsync(d, value, 8, hipMemcpyHostToDevice, c->stream);
+    if (!c->d_comm_scratch) HIPCHK(c, hipMalloc((void**)&c->d_comm_scratch, 8 * sizeof(double)));
+    double* d = c->d_comm_scratch;
+    hipError_t e = hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
     int nr = 0;
-    if (e == hipSuccess) nr = rccl()->AllReduce(d, d, 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
-    if (e == hipSuccess && nr == 0) e = hipMemcpyAsync(value, d, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) nr = rccl()->AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclMax, c->comm, c->stream);
+    if (e == hipSuccess && nr == 0) e = hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
     if (nr != 0) return rccl_fail(c, "ncclAllReduce", nr);
     if (e != hipSuccess) { c->err = std::string("comm_max: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
     return POPPY_OK;
+}
+int poppy_hip_comm_max(poppy_hip_ctx* c, double* value) {
+    if (!c || !value) return POPPY_E_ARG;
+    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+    return comm_max_n(c, value, 1);
 }
 
 // The packed pair state to / from a caller's device buffer (one device copy): for callers that move it with their own
@@ -178,6 +185,248 @@ int poppy_hip_pair_import_device(poppy_hip_ctx* c, const void* d_src, size_t byt
     HIPCHK(c, hipMemcpyAsync(c->arena, d_src, c->arena_bytes, hipMemcpyDeviceToDevice, c->stream));
     return adopt_pair_state(c);
 }
+
+}  // extern "C"
+
+// ---- the pair set-up itself, spread over the ranks --------------------------------------------------------------------------
+// The set-up is the serial part of a sharded morph (Amdahl: ~5.5 ms on one GPU against 60 frames x 90 us per rank at N = 8).  Its three
+// heavy pieces are independent until the matcher (src/poppy.hpp:52,114-122, src/extractor.cpp:33-83):
+//   A  image 1: Extractor::foreground -> dft_detail2 -> the ORB input -> ORB::detect        on rank `root`
+//   B  image 2: the same                                                                     on rank root + 1
+//   C  gabor_filter(corrected2 / 255) -> m2                                                  on rank root + 2 (with B when there are two ranks)
+// The exchanges, all through the same communicator: the raw pair from `root` (one broadcast of the c1 | c2 region), the two detail
+// values (one 3-double max-reduction, which also carries an error flag: nfeatures needs both, src/extractor.cpp:40-45), image 2's
+// keypoint positions B -> A (one broadcast through the state's point area), then the matcher on A and two broadcasts that complete the
+// pair state everywhere: header + points from A, m2 from C.  No step can leave a rank alone inside a collective: whatever can fail on
+// one rank is reported through the reduction or through an invalid header that every rank refuses.
+// The transport is abstract so that the role logic can run — and be tested bit for bit — with several contexts of ONE process on one
+// GPU (LocalHub: device-to-device copies between the contexts' buffers behind a thread barrier).
+namespace {
+
+struct Transport {
+    int rank = 0, world = 1;
+    std::function<int(poppy_hip_ctx*, void*, size_t, int)> bcast;     // in place, device memory, complete on return
+    std::function<int(poppy_hip_ctx*, double*, int)> allmax;          // host doubles
+};
+
+int chain_image(poppy_hip_ctx* c, int i, bool with_gabor, double* detail, const uint8_t** g_dev, std::string* err) {
+    const int W = c->W, H = c->H;
+    const size_t P = (size_t)W * H;
+    if (hipSetDevice(c->device) != hipSuccess) { *err = "hipSetDevice failed"; return POPPY_E_DEVICE; }
+    ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
+    hipStream_t st = i ? c->aux_stream : c->stream;
+    const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
+    if (!gf) { *err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
+    if (fg.detail(gf, W, H, st, detail)) { *err = "dft_detail2: " + fg.err; return POPPY_E_DEVICE; }
+    const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
+    if (!gi) { *err = "orb_input: " + fg.err; return POPPY_E_DEVICE; }
+    *g_dev = gi;
+    hipError_t e = hipSuccess;
+    if (with_gabor) {
+        const float* gab = fg.gabor_field(c->c2, W, H, st);
+        if (!gab) { *err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
+        e = hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { *err = std::string("pair set-up: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
+int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2, int W, int H, int root) {
+    if (c->cfg.enable_auto_align) return fail(c, POPPY_E_UNSUPPORTED, "the sharded set-up does not take auto-align (image 2 changes after the match)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t P = (size_t)W * H;
+    const int rA = root, rB = T.world >= 2 ? (root + 1) % T.world : root, rC = T.world >= 3 ? (root + 2) % T.world : rB;
+    const bool isA = T.rank == rA, isB = T.rank == rB, isC = T.rank == rC;
+    int rc = alloc_pair(c, W, H);
+    if (rc == POPPY_OK) { c->pair_ready = false; c->c2_raw_valid = false; }
+    if (rc == POPPY_OK && !c->aux_stream && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "hipStreamCreate");
+    if (rc == POPPY_OK && isA) {
+        if (!d1 || !d2) rc = fail(c, POPPY_E_ARG, "the root has no images");
+        else if (hipMemcpyAsync(c->c1, d1, P * 3, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                 hipMemcpyAsync(c->c2, d2, P * 3, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                 hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, POPPY_E_DEVICE, "copy of the raw pair");
+    }
+    double v[3] = {0, 0, rc == POPPY_OK ? 0.0 : 1.0};
+    { const int ra = T.allmax(c, v, 3); if (ra) return ra; }
+    if (v[2] != 0.0) return rc != POPPY_OK ? rc : fail(c, POPPY_E_STATE, "another rank could not start the set-up");
+    // 1. the raw pair to every rank
+    rc = T.bcast(c, c->c1, (size_t)((uint8_t*)c->m2 - c->c1), rA); if (rc) return rc;
+    // 2. the independent pieces
+    double d[2] = {0, 0};
+    const uint8_t* g_dev[2] = {nullptr, nullptr};
+    std::string errs[2];
+    int rcs[2] = {POPPY_OK, POPPY_OK};
+    {
+        std::thread other;
+        if (isB) {
+            if (isA) other = std::thread([&]() { rcs[1] = chain_image(c, 1, isC, &d[1], &g_dev[1], &errs[1]); });
+            else rcs[1] = chain_image(c, 1, isC, &d[1], &g_dev[1], &errs[1]);
+        }
+        if (isA) rcs[0] = chain_image(c, 0, false, &d[0], &g_dev[0], &errs[0]);
+        if (other.joinable()) other.join();
+        if (isC && !isB) {                                              // gabor2 alone
+            const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->stream);
+            if (!gab) { rcs[1] = POPPY_E_DEVICE; errs[1] = "gabor_field: " + c->foreground_b.err; }
+            else if (hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { rcs[1] = POPPY_E_DEVICE; errs[1] = "gabor2 copy"; }
+        }
+        if (isC && rcs[1] == POPPY_OK) {                                // m2 = 1 - gray(gabor2), where the frames read the mask field from
+            launch_gray_inv(c->gabor2, c->m2, W * H, c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { rcs[1] = POPPY_E_DEVICE; errs[1] = "m2"; }
+        }
+    }
+    rc = rcs[0] ? rcs[0] : rcs[1];
+    if (rc) c->err = rcs[0] ? errs[0] : errs[1];
+    v[0] = d[0]; v[1] = d[1]; v[2] = rc == POPPY_OK ? 0.0 : 1.0;
+    { const int ra = T.allmax(c, v, 3); if (ra) return ra; }
+    if (v[2] != 0.0) return rc != POPPY_OK ? rc : fail(c, POPPY_E_STATE, "another rank failed in its part of the set-up");
+    const double detail = 255.0 / std::max(v[0], v[1]);                 // src/extractor.cpp:40-45
+    c->last_detail[0] = v[0]; c->last_detail[1] = v[1];
+    const int nfeatures = (int)(c->cfg.max_keypoints * detail);
+    c->last_nfeatures = nfeatures;
+    // 3. ORB::detect where the ORB inputs lie
+    std::vector<OrbKeyPoint> k1, k2;
+    int r1 = 0, r2 = 0;
+    {
+        std::thread other;
+        if (isB) {
+            if (isA) other = std::thread([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g_dev[1], W, W, H, nfeatures, c->aux_stream, k2, true) : -2; });
+            else r2 = c->orb_b.detect(g_dev[1], W, W, H, nfeatures, c->aux_stream, k2, true);
+        }
+        if (isA) r1 = c->orb.detect(g_dev[0], W, W, H, nfeatures, c->stream, k1, true);
+        if (other.joinable()) other.join();
+    }
+    // 4. image 2's keypoint positions to A, through the state's point area: [count or -1][x, y pairs]
+    uint8_t* const xarea = c->arena + kPairHeadBytes;
+    const size_t xbytes = 2 * (size_t)kPairMaxPoints * 8;
+    if (isB) {
+        std::vector<float> buf(2 + 2 * (size_t)kPairMaxPoints, 0.f);
+        int n2 = r2 < 0 || (int)k2.size() > kPairMaxPoints - 1 ? -1 : (int)k2.size();
+        memcpy(&buf[0], &n2, 4);
+        for (int i = 0; i < n2; ++i) { buf[2 + 2 * i] = k2[i].x; buf[3 + 2 * i] = k2[i].y; }
+        if (hipMemcpyAsync(xarea, buf.data(), (2 + 2 * (size_t)std::max(n2, 0)) * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "keypoint hand-off");     // (a HIP failure here is fatal for the job anyway)
+    }
+    if (rA != rB) { rc = T.bcast(c, xarea, xbytes, rB); if (rc) return rc; }
+    // 5. the matcher on A (host), then header + points for everybody
+    bool valid = true;
+    if (isA) {
+        std::vector<float> p2v;
+        int n2 = (int)k2.size();
+        if (rA != rB) {
+            std::vector<float> buf(2 + 2 * (size_t)kPairMaxPoints);
+            if (hipMemcpyAsync(buf.data(), xarea, buf.size() * 4 > xbytes ? xbytes : buf.size() * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) valid = false;
+            memcpy(&n2, &buf[0], 4);
+            if (valid && n2 >= 0) p2v.assign(buf.begin() + 2, buf.begin() + 2 + 2 * (size_t)n2);
+        } else {
+            if (r2 < 0) n2 = -1;
+            for (int i = 0; i < n2; ++i) { p2v.push_back(k2[i].x); p2v.push_back(k2[i].y); }
+        }
+        if (r1 < 0 || n2 < 0) { valid = false; c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : std::string("the other image's detection failed")); }
+        if (valid) {
+            const size_t n = std::min(k1.size(), (size_t)n2);                   // Extractor::points (extractor.cpp:96-99)
+            std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
+            for (size_t i = 0; i < n; ++i) { p1[2 * i] = k1[i].x; p1[2 * i + 1] = k1[i].y; p2[2 * i] = p2v[2 * i]; p2[2 * i + 1] = p2v[2 * i + 1]; }
+            int m = 0;
+            int mr = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
+            if (mr == POPPY_OK) mr = set_points(c, o1.data(), o2.data(), m);
+            if (mr == POPPY_OK) mr = stage_pair_state(c);
+            if (mr != POPPY_OK) valid = false;
+        }
+        if (!valid) {                                                           // a header every rank refuses (adopt_pair_state checks the magic)
+            (void)hipMemsetAsync(c->arena, 0, kPairHeadBytes, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    }
+    rc = T.bcast(c, c->arena, kPairHeadBytes + xbytes, rA); if (rc) return rc;
+    rc = T.bcast(c, c->m2, P * 4, rC); if (rc) return rc;
+    rc = adopt_pair_state(c);
+    if (rc != POPPY_OK && isA && !valid) return fail(c, POPPY_E_DEVICE, ("sharded set-up: " + c->err).c_str());
+    return rc;
+}
+
+// several contexts of one process (any devices): broadcasts are device copies from the root context's buffer behind a barrier
+struct LocalHub {
+    int n;
+    std::mutex mu; std::condition_variable cv; int arrived = 0; unsigned phase = 0;
+    const void* src = nullptr; int src_device = 0;
+    std::vector<double> vals;
+    explicit LocalHub(int n_) : n(n_) {}
+    void barrier() {
+        std::unique_lock<std::mutex> g(mu);
+        const unsigned ph = phase;
+        if (++arrived == n) { arrived = 0; ++phase; cv.notify_all(); }
+        else cv.wait(g, [&] { return phase != ph; });
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int poppy_hip_pair_begin_sharded(poppy_hip_ctx* c, const void* d1, const void* d2, int W, int H, int root) {
+    if (!c) return POPPY_E_ARG;
+    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+    if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");
+    if (c->comm_world == 1) return poppy_hip_pair_begin_device(c, d1, d2, W, H);
+    Transport T;
+    T.rank = c->comm_rank; T.world = c->comm_world;
+    T.bcast = [](poppy_hip_ctx* cc, void* buf, size_t bytes, int r) -> int {
+        const int nr = rccl()->Broadcast(buf, buf, bytes, kNcclUint8, r, cc->comm, cc->stream);
+        if (nr != 0) return rccl_fail(cc, "ncclBroadcast", nr);
+        if (hipStreamSynchronize(cc->stream) != hipSuccess) return fail(cc, POPPY_E_DEVICE, "broadcast");
+        return POPPY_OK;
+    };
+    T.allmax = [](poppy_hip_ctx* cc, double* v, int n) -> int { return comm_max_n(cc, v, n); };
+    return setup_sharded(c, T, d1, d2, W, H, root);
+}
+
+// The same set-up by n contexts of THIS process (one host thread each; the contexts may share a GPU): context k plays rank k, the raw
+// pair (device pointers valid for context `root`'s device) ends up resident in every context.  What the multi-rank path does, minus RCCL.
+int poppy_hip_pair_begin_sharded_local(poppy_hip_ctx** ctxs, int n, const void* d1, const void* d2, int W, int H, int root) {
+    if (!ctxs || n < 1 || n > 64 || root < 0 || root >= n || W <= 0 || H <= 0) return POPPY_E_ARG;
+    for (int k = 0; k < n; ++k) if (!ctxs[k]) return POPPY_E_ARG;
+    if (n == 1) return poppy_hip_pair_begin_device(ctxs[0], d1, d2, W, H);
+    LocalHub hub(n);
+    hub.vals.assign(64, 0.0);
+    std::vector<int> rcs(n, POPPY_OK);
+    auto work = [&](int k) {
+        Transport T;
+        T.rank = k; T.world = n;
+        T.bcast = [&hub, k](poppy_hip_ctx* cc, void* buf, size_t bytes, int r) -> int {
+            if (k == r) { hub.src = buf; hub.src_device = cc->device; }
+            hub.barrier();
+            hipError_t e = hipSuccess;
+            if (k != r) {
+                e = hipMemcpyAsync(buf, hub.src, bytes, hipMemcpyDeviceToDevice, cc->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(cc->stream);
+            }
+            hub.barrier();                                             // the root's buffer may change again only now
+            return e == hipSuccess ? POPPY_OK : fail(cc, POPPY_E_DEVICE, "local broadcast");
+        };
+        T.allmax = [&hub, k](poppy_hip_ctx*, double* v, int m) -> int {
+            hub.barrier();
+            if (k == 0) std::fill(hub.vals.begin(), hub.vals.end(), -1e300);
+            hub.barrier();
+            { std::lock_guard<std::mutex> g(hub.mu); for (int i = 0; i < m; ++i) hub.vals[i] = std::max(hub.vals[i], v[i]); }
+            hub.barrier();
+            for (int i = 0; i < m; ++i) v[i] = hub.vals[i];
+            return POPPY_OK;
+        };
+        rcs[k] = setup_sharded(ctxs[k], T, k == root ? d1 : nullptr, k == root ? d2 : nullptr, W, H, root);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int k = 0; k < n; ++k) if (rcs[k] != POPPY_OK) return rcs[k];
+    return POPPY_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- one process, several GPUs ---------------------------------------------------------------------------------------------
 static void set_err(char* err, size_t n, const std::string& s) { if (err && n) { snprintf(err, n, "%s", s.c_str()); } }
@@ -205,8 +454,20 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
         if (rc != 0) { set_err(err, err_len, std::string("ncclCommInitAll: ") + (r->GetErrorString ? r->GetErrorString(rc) : "")); cleanup(); return POPPY_E_DEVICE; }
         for (int k = 0; k < n_devices; ++k) { ctx[k]->comm = comms[k]; ctx[k]->comm_rank = k; ctx[k]->comm_world = n_devices; }
     }
-    // the pair set-up runs before any other device's thread exists: nobody can be left waiting inside RCCL when it fails
-    {
+    // Several devices: the set-up itself is spread over them (poppy_hip_pair_begin_sharded: image 1 on device 0, image 2 on device 1, the mask
+    // field on device 2), unless auto-align is on or POPPY_HIP_SHARD_SETUP=0; otherwise it runs on device 0 before any other device's thread
+    // exists (nobody can be left waiting inside RCCL when it fails) and the pair state is broadcast.
+    static const bool shard_off = getenv("POPPY_HIP_SHARD_SETUP") && atoi(getenv("POPPY_HIP_SHARD_SETUP")) == 0;
+    const bool shard_setup = n_devices > 1 && !cfg.enable_auto_align && !shard_off;
+    uint8_t* d_raw = nullptr;
+    const size_t P3 = (size_t)W * H * 3;
+    if (shard_setup) {
+        hipError_t e = hipSetDevice(devices[0]);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_raw, 2 * P3);
+        if (e == hipSuccess) e = hipMemcpy2D(d_raw, (size_t)W * 3, bgr1, s1, (size_t)W * 3, H, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy2D(d_raw + P3, (size_t)W * 3, bgr2, s2, (size_t)W * 3, H, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_err(err, err_len, std::string("upload of the raw pair: ") + hipGetErrorString(e)); if (d_raw) (void)hipFree(d_raw); cleanup(); return POPPY_E_DEVICE; }
+    } else {
         int rc = poppy_hip_pair_begin(ctx[0], bgr1, s1, bgr2, s2, W, H);
         if (rc == POPPY_OK && ctx[0]->pts1_0.empty()) rc = fail(ctx[0], POPPY_E_NOMATCH, "no point pairs");
         if (rc != POPPY_OK) { set_err(err, err_len, std::string("pair set-up: ") + poppy_hip_last_error(ctx[0])); cleanup(); return rc; }
@@ -216,7 +477,10 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
     auto work = [&](int k) {
         poppy_hip_ctx* c = ctx[k];
         int rc = POPPY_OK;
-        if (n_devices > 1) rc = poppy_hip_pair_broadcast(c, 0, W, H);
+        if (shard_setup) {
+            rc = poppy_hip_pair_begin_sharded(c, k == 0 ? d_raw : nullptr, k == 0 ? d_raw + P3 : nullptr, W, H, 0);
+            if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_NOMATCH, "no point pairs");      // every rank sees the same (empty) point sets
+        } else if (n_devices > 1) rc = poppy_hip_pair_broadcast(c, 0, W, H);
         const int lo = (int)((long long)total_frames * k / n_devices), hi = (int)((long long)total_frames * (k + 1) / n_devices);
         if (rc == POPPY_OK && hi > lo) {
             Relay relay{write, user, lo};
@@ -234,6 +498,7 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
     for (int k = 1; k < n_devices; ++k) th.emplace_back(work, k);
     work(0);
     for (auto& t : th) t.join();
+    if (d_raw) { (void)hipSetDevice(devices[0]); (void)hipFree(d_raw); }
     int rc = POPPY_OK;
     for (int k = 0; k < n_devices; ++k)
         if (rcs[k] != POPPY_OK) { rc = rcs[k]; set_err(err, err_len, "device " + std::to_string(devices[k]) + ": " + poppy_hip_last_error(ctx[k])); break; }

@@ -121,6 +121,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     (void)hipStreamSynchronize(c->copy_stream);
     if (c->d_align) (void)hipFree(c->d_align);
+    if (c->d_comm_scratch) (void)hipFree(c->d_comm_scratch);
     c->aligner.release();
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);

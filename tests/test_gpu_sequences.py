@@ -271,3 +271,38 @@ def test_frame_wait_orders_a_caller_stream_behind_a_phase_mode_frame():
         assert hip.hipStreamSynchronize(ctx.stream_ptr()) == 0
         assert (got == want).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("n_ctx,root", [(2, 0), (3, 0), (3, 1), (4, 2)])
+def test_sharded_pair_setup_between_contexts_equals_the_one_gpu_setup(n_ctx, root):
+    """The pair set-up spread over ranks (comm.cpp: setup_sharded — image 1 on rank root, image 2 on root + 1, the mask field on root + 2,
+    five small exchanges) run between contexts of this process on one GPU: every context ends up with the pair state of the one-GPU set-up —
+    same point sets, same nfeatures, and the reference's frames."""
+    import ctypes as C
+    from poppy_amd import capi
+    case = "a_256x256_phase"
+    inp = G.astage_inputs(case)
+    h, w = inp["img1"].shape[:2]
+    ref = _ctx(number_of_frames=1)
+    nf, _ = ref.pair_begin(inp["img1"], inp["img2"])
+    want_pts = ref.pair_points()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    d = [C.c_void_p(), C.c_void_p()]
+    for k, img in enumerate((inp["img1"], inp["img2"])):
+        img = np.ascontiguousarray(img)
+        assert hip.hipMalloc(C.byref(d[k]), C.c_size_t(img.nbytes)) == 0
+        assert hip.hipMemcpy(d[k], img.ctypes.data, img.nbytes, 1) == 0          # 1 = host to device
+    ctxs = [_ctx(number_of_frames=1) for _ in range(n_ctx)]
+    for rep in range(2):                                                           # twice: the second run reuses every buffer
+        capi.pair_begin_sharded_local(ctxs, d[0], d[1], w, h, root)
+        for c in ctxs:
+            p = c.pair_points()
+            assert np.array_equal(p[0], want_pts[0]) and np.array_equal(p[1], want_pts[1])
+            G.check(case, "frame0", c.morph_frames(0.5)[0])
+    assert ctxs[root].pair_begin_info()[0] == nf
+    for k in range(2):
+        hip.hipFree(d[k])
+    for c in ctxs:
+        c.close()
+    ref.close()
