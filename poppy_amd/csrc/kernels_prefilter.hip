@@ -262,6 +262,24 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
             }
         }
     };
+    // A step down adds row y + r + 1 and removes row y - r.  Where the value entering a column of the window equals the one leaving it the
+    // two updates cancel: nothing is sent to LDS (the kernel is bound by its LDS atomics, four per such pair).  The chain feeds every median
+    // with the previous median's output — plateaus — so most pairs cancel from the second stage on; a wave whose 64 lanes all cancel
+    // skips the instructions altogether.
+    auto apply_step = [&](const uint32_t* add_regs, const uint32_t* sub_regs) {
+#pragma unroll
+        for (int i = WV; i < NDW; i += NW) {
+            const int nb = (i == ndw - 1) ? tail : 4;
+            if (add_regs[i] != sub_regs[i] || nb < 4) {                  // (a dword of four equal pairs is the common case)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nb) {
+                        const uint32_t va = (add_regs[i] >> (8 * k)) & 255u, vs = (sub_regs[i] >> (8 * k)) & 255u;
+                        if (va != vs) { med_update(lane_base, unit, va, true); med_update(lane_base, unit, vs, false); }
+                    }
+            }
+        }
+    };
     uint32_t ra[NDW], rs[NDW];
     // warm-up: rows y_begin - r .. y_begin + r, loaded one ahead of the row being applied
     load_row(row_ptr(y_begin - r), ra);
@@ -299,8 +317,7 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
 #pragma unroll
             for (int i = WV; i < NDW; i += NW) { ca[i] = ra[i]; cs[i] = rs[i]; }
             if (y + 2 < y_end) { load_row(row_ptr(y + r + 2), ra); load_row(row_ptr(y + 1 - r), rs); }   // rows of the NEXT step
-            apply_row(ca, true);
-            apply_row(cs, false);
+            apply_step(ca, cs);
         }
     }
 }
