@@ -18,7 +18,10 @@ struct OrbLevel {
 struct OrbLevelSet { int n; OrbLevel lv[kOrbLevels]; };
 
 void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8_t* atlas, const OrbLevelSet& S, hipStream_t s);
-void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, hipStream_t s);
+// FAST score + non-maximum suppression; the survivors of every level land in `cand` as (x | y << 16, score) pairs IN RASTER ORDER (FAST's own
+// emission order), their number in counters[level].  scratch: fast_nms_scratch_bytes(S) bytes of device memory.
+size_t fast_nms_scratch_bytes(const OrbLevelSet& S);
+void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, void* scratch, hipStream_t s);
 void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s);
 void launch_ic_angle(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* angle, hipStream_t s);
 

@@ -135,23 +135,21 @@ __global__ void __launch_bounds__(256) k_fast_score(const uint8_t* __restrict__ 
 }
 
 // strict 3x3 maximum + border filter; survivors appended unordered: (level, y*w + x, score).
-// A block takes 256 columns x kNmsRows rows of a level and claims its survivors' slots with ONE atomic: ~10^5 survivors per 1080p image
-// on the eight per-level counters were the kernel (one atomic per wave: 343 us; per block: the kernel is its ~3 MB of score reads).
+// Non-maximum suppression + compaction IN RASTER ORDER (fast.cpp:271-290 emits row by row, left to right, and the order of the list is part of
+// the contract: ORB's retainBest permutes it with std::nth_element).  A block takes 256 columns x kNmsRows rows of a level.  Three launches:
+//   k_fast_nms_count   survivors per (row, block of columns) -> rowblk[], each thread's survivor bits -> keep[] (one byte);
+//   k_fast_nms_scan    one block per level: exclusive prefix of rowblk[] in (row, column block) order -> the slot of every row piece, and the
+//                      level's total -> counters[];
+//   k_fast_nms_emit    every survivor writes (position, score) at its row piece's slot + its rank among the piece's survivors.
+// The host gets the candidates in FAST's own emission order and no longer re-sorts ~10^5 of them per image (0.4 ms of the pair set-up); the
+// round-2 form claimed slots with one atomic per block, in whatever order the blocks ran.
 constexpr int kNmsRows = 8;
+struct NmsLayout { int base[kOrbLevels + 1]; int nbx[kOrbLevels]; };            // rowblk[] offsets per level (entries = rows x column blocks)
 
-__global__ void __launch_bounds__(256) k_fast_nms(const uint8_t* __restrict__ scores, OrbLevelSet S, int edge, int* __restrict__ counters,
-                                                  int* __restrict__ cand, int cap) {
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    const int lvl = blockIdx.z;
-    const OrbLevel L = S.lv[lvl];
+__device__ __forceinline__ unsigned nms_keep_bits(const uint8_t* __restrict__ scores, const OrbLevel& L, int edge, int x, int y0, int* sc) {
     const int W = L.w;
-    if (W <= 2 * edge || L.h <= 2 * edge) return;                         // uniform
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * kNmsRows;
-    if (y0 >= L.h - edge || y0 + kNmsRows <= edge || (int)(blockIdx.x * blockDim.x) >= W - edge) return;       // uniform: nothing of this block can survive
     const bool col_ok = x >= edge && x < W - edge;
-    unsigned keep = 0;                                                   // bit r: row y0 + r survives
-    int sc[kNmsRows];
+    unsigned keep = 0;
 #pragma unroll
     for (int r = 0; r < kNmsRows; ++r) {
         const int y = y0 + r;
@@ -163,26 +161,84 @@ __global__ void __launch_bounds__(256) k_fast_nms(const uint8_t* __restrict__ sc
             if (v != 0 && v > p[-1] && v > p[1] && v > p[-W - 1] && v > p[-W] && v > p[-W + 1] && v > p[W - 1] && v > p[W] && v > p[W + 1]) keep |= 1u << r;
         }
     }
-    // slots: exclusive prefix of the threads' survivor counts inside the block
-    const int mine = __builtin_popcount(keep);
-    int incl = mine;
+    return keep;
+}
+
+__global__ void __launch_bounds__(256) k_fast_nms_count(const uint8_t* __restrict__ scores, OrbLevelSet S, NmsLayout lay, int edge,
+                                                        int* __restrict__ rowblk, uint8_t* __restrict__ keepbuf, size_t keep_stride) {
+    __shared__ int s_cnt[kNmsRows][4];
+    const int lvl = blockIdx.z;
+    const OrbLevel L = S.lv[lvl];
+    const int W = L.w, nbx = lay.nbx[lvl];
+    const int bx = blockIdx.x, y0 = blockIdx.y * kNmsRows;
+    if (bx >= nbx || y0 >= L.h) return;                                   // uniform: outside this level's grid
+    const int x = bx * 256 + threadIdx.x;
+    const bool dead = W <= 2 * edge || L.h <= 2 * edge || y0 >= L.h - edge || y0 + kNmsRows <= edge || bx * 256 >= W - edge;   // uniform: nothing can survive
+    unsigned keep = 0;
+    if (!dead) { int sc[kNmsRows]; keep = nms_keep_bits(scores, L, edge, x, y0, sc); }
+    if (x < W) keepbuf[(size_t)lvl * keep_stride + (size_t)blockIdx.y * W + x] = (uint8_t)keep;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        s_base = total ? atomicAdd(&counters[lvl], total) : 0;
+    for (int r = 0; r < kNmsRows; ++r) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((keep >> r) & 1u);
+        if (lane == 0) s_cnt[r][wv] = __builtin_popcountll(m);
     }
     __syncthreads();
-    int slot = s_base + incl - mine;
-    for (int w = 0; w < wv; ++w) slot += s_wave[w];
+    if (threadIdx.x < kNmsRows && y0 + (int)threadIdx.x < L.h)
+        rowblk[lay.base[lvl] + (y0 + threadIdx.x) * nbx + bx] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+}
+
+__global__ void __launch_bounds__(1024) k_fast_nms_scan(NmsLayout lay, int* __restrict__ rowblk, int* __restrict__ counters) {
+    __shared__ int s_part[1024];
+    const int lvl = blockIdx.x, tid = threadIdx.x;
+    const int n = lay.base[lvl + 1] - lay.base[lvl];
+    int* const a = rowblk + lay.base[lvl];
+    const int per = (n + 1023) / 1024, lo = min(tid * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                                  // inclusive scan of the threads' sums
+        const int v = tid >= d ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i) { const int c = a[i]; a[i] = run; run += c; }
+    if (tid == 1023) counters[lvl] = s_part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_fast_nms_emit(const uint8_t* __restrict__ scores, OrbLevelSet S, NmsLayout lay, const int* __restrict__ rowblk,
+                                                       const uint8_t* __restrict__ keepbuf, size_t keep_stride, int* __restrict__ cand, int cap) {
+    __shared__ int s_cnt[kNmsRows][4];
+    const int lvl = blockIdx.z;
+    const OrbLevel L = S.lv[lvl];
+    const int W = L.w, nbx = lay.nbx[lvl];
+    const int bx = blockIdx.x, y0 = blockIdx.y * kNmsRows;
+    if (bx >= nbx || y0 >= L.h) return;
+    const int x = bx * 256 + threadIdx.x;
+    const unsigned keep = x < W ? keepbuf[(size_t)lvl * keep_stride + (size_t)blockIdx.y * W + x] : 0u;
+    if (__syncthreads_or(keep != 0) == 0) return;                         // uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int rank[kNmsRows];
+#pragma unroll
+    for (int r = 0; r < kNmsRows; ++r) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((keep >> r) & 1u);
+        rank[r] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[r][wv] = __builtin_popcountll(m);
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < kNmsRows; ++r)
         if (keep & (1u << r)) {
-            if (slot < cap) { cand[((size_t)lvl * cap + slot) * 2] = (y0 + r) * W + x; cand[((size_t)lvl * cap + slot) * 2 + 1] = sc[r]; }
-            ++slot;
+            int slot = rowblk[lay.base[lvl] + (y0 + r) * nbx + bx] + rank[r];
+            for (int w = 0; w < wv; ++w) slot += s_cnt[r][w];
+            if (slot < cap) {
+                const int pos = (y0 + r) * W + x;
+                cand[((size_t)lvl * cap + slot) * 2] = x | ((y0 + r) << 16);           // both fit 16 bits (levels up to 65535 x 65535)
+                cand[((size_t)lvl * cap + slot) * 2 + 1] = scores[L.score_offset + pos];
+            }
         }
 }
 
@@ -425,11 +481,33 @@ void launch_orb_pyramid(const uint8_t* d_img, int w, int h, size_t stride, uint8
     }
 }
 
-void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, hipStream_t s) {
+size_t fast_nms_scratch_bytes(const OrbLevelSet& S) {
+    size_t rows = 0, keep = 0;
+    for (int l = 0; l < S.n; ++l) {
+        rows += (size_t)S.lv[l].h * ((S.lv[l].w + 255) / 256);
+        keep = std::max(keep, (size_t)((S.lv[l].h + kNmsRows - 1) / kNmsRows) * S.lv[l].w);
+    }
+    return rows * sizeof(int) + 256 + (size_t)S.n * ((keep + 255) & ~(size_t)255);
+}
+void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, int threshold, int edge, int* counters, int* cand, int cap, void* scratch, hipStream_t s) {
     const dim3 grid_score((S.lv[0].w + 255) / 256, (S.lv[0].h + kFastRows - 1) / kFastRows, S.n);
     const dim3 grid_nms((S.lv[0].w + 255) / 256, (S.lv[0].h + kNmsRows - 1) / kNmsRows, S.n);
+    NmsLayout lay;
+    size_t rows = 0, keep = 0;
+    for (int l = 0; l < kOrbLevels; ++l) {
+        lay.base[l] = (int)rows;
+        lay.nbx[l] = l < S.n ? (S.lv[l].w + 255) / 256 : 0;
+        if (l < S.n) { rows += (size_t)S.lv[l].h * lay.nbx[l]; keep = std::max(keep, (size_t)((S.lv[l].h + kNmsRows - 1) / kNmsRows) * S.lv[l].w); }
+    }
+    lay.base[kOrbLevels] = (int)rows;
+    for (int l = S.n; l < kOrbLevels; ++l) lay.base[l] = (int)rows;
+    const size_t keep_stride = (keep + 255) & ~(size_t)255;
+    int* rowblk = (int*)scratch;
+    uint8_t* keepbuf = (uint8_t*)scratch + ((rows * sizeof(int) + 255) & ~(size_t)255);
     hipLaunchKernelGGL(k_fast_score, grid_score, dim3(256), 0, s, atlas, S, scores, threshold);
-    hipLaunchKernelGGL(k_fast_nms, grid_nms, dim3(256), 0, s, scores, S, edge, counters, cand, cap);
+    hipLaunchKernelGGL(k_fast_nms_count, grid_nms, dim3(256), 0, s, scores, S, lay, edge, rowblk, keepbuf, keep_stride);
+    hipLaunchKernelGGL(k_fast_nms_scan, dim3(S.n), dim3(1024), 0, s, lay, rowblk, counters);
+    hipLaunchKernelGGL(k_fast_nms_emit, grid_nms, dim3(256), 0, s, scores, S, lay, rowblk, keepbuf, keep_stride, cand, cap);
 }
 
 void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s) {

@@ -11,6 +11,9 @@
 #include "orb_detect.h"
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -20,23 +23,25 @@ namespace {
 inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
 
 struct Cand { int x, y, level; float response; };
-struct ByResponse { bool operator()(const Cand& a, const Cand& b) const { return a.response > b.response; } };
+struct Key { float response; int i; };            // what retainBest compares, plus where the candidate sits in the raster-ordered list
+struct ByResponse { template <typename T> bool operator()(const T& a, const T& b) const { return a.response > b.response; } };
 
-void retain_best(std::vector<Cand>& k, int n) {
+template <typename T>
+void retain_best(std::vector<T>& k, int n) {
     if (n >= 0 && k.size() > (size_t)n) {
         if (n == 0) { k.clear(); return; }
         std::nth_element(k.begin(), k.begin() + n - 1, k.end(), ByResponse());
         const float ambiguous = k[n - 1].response;
-        auto new_end = std::partition(k.begin() + n, k.end(), [ambiguous](const Cand& c) { return c.response >= ambiguous; });
+        auto new_end = std::partition(k.begin() + n, k.end(), [ambiguous](const T& c) { return c.response >= ambiguous; });
         k.resize(new_end - k.begin());
     }
 }
 }  // namespace
 
 void OrbDetector::release() {
-    void* bufs[] = {d_img, d_atlas, d_blur, d_scores, d_counters, d_cand, d_kp, d_val, d_desc};
+    void* bufs[] = {d_img, d_atlas, d_blur, d_scores, d_counters, d_cand, d_kp, d_val, d_desc, d_nms};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    d_img = d_atlas = d_blur = d_scores = nullptr; d_counters = d_cand = d_kp = nullptr; d_val = nullptr; d_desc = nullptr;
+    d_img = d_atlas = d_blur = d_scores = nullptr; d_counters = d_cand = d_kp = nullptr; d_val = nullptr; d_desc = nullptr; d_nms = nullptr;
     if (h_cand) (void)hipHostFree(h_cand);
     if (h_kp) (void)hipHostFree(h_kp);
     if (h_val) (void)hipHostFree(h_val);
@@ -70,6 +75,7 @@ hipError_t OrbDetector::prepare(int w, int h) {
     if ((e = hipMalloc((void**)&d_blur, off)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_scores, soff)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_counters, kOrbLevels * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&d_nms, fast_nms_scratch_bytes(S))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_cand, (size_t)kOrbLevels * cap * 2 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
@@ -88,19 +94,24 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
     out.clear();
     ORB_CHK(prepare(w, h));
     const int edge = 31, patch = 31, fastThreshold = 20;
+    static const bool stage_times = getenv("POPPY_SETUP_TIMING") != nullptr;          // host wall time of the detection's stages on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double ms_fast = 0, ms_cand = 0, ms_sort = 0, ms_harris = 0;
     ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, gray_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
-    ORB_CHK(hipMemsetAsync(d_counters, 0, kOrbLevels * sizeof(int), s));
-    launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, s);
+    launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, d_nms, s);
     int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
     ORB_CHK(hipMemcpyAsync(h_counts, d_counters, kOrbLevels * sizeof(int), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
+    ms_fast = since();
     for (int l = 0; l < kOrbLevels; ++l) {
         if (h_counts[l] > cap) { err = "FAST candidate buffer overflow"; return -1; }
         if (h_counts[l])
             ORB_CHK(hipMemcpyAsync(h_cand + (size_t)l * cap * 2, d_cand + (size_t)l * cap * 2, (size_t)h_counts[l] * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     }
     ORB_CHK(hipStreamSynchronize(s));
+    ms_cand = since();
 
     // per-level quota (orb.cpp:803-813)
     int quota[kOrbLevels];
@@ -120,35 +131,30 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
     auto level_job = [&](int l) {
         const int n = h_counts[l], lw = S.lv[l].w;
         const int* c = h_cand + (size_t)l * cap * 2;
-        // raster order = FAST's emission order (fast.cpp:271-290).  The kernel emits candidates in whatever order its
-        // atomics land; positions are unique, so a counting pass over the rows and a sort inside each row restore the
-        // order in O(n) (a comparison sort of the 10^5 candidates of a 1080p level costs milliseconds).
-        std::vector<std::pair<int, int>> keyed(n);
-        {
-            const int lh = S.lv[l].h;
-            std::vector<int> row_at(lh + 1, 0);
-            for (int i = 0; i < n; ++i) ++row_at[c[2 * i] / lw + 1];
-            for (int y = 0; y < lh; ++y) row_at[y + 1] += row_at[y];
-            std::vector<int> fill(row_at.begin(), row_at.end() - 1);
-            for (int i = 0; i < n; ++i) keyed[fill[c[2 * i] / lw]++] = {c[2 * i], c[2 * i + 1]};
-            for (int y = 0; y < lh; ++y)
-                if (row_at[y + 1] - row_at[y] > 1) std::sort(keyed.begin() + row_at[y], keyed.begin() + row_at[y + 1]);
-        }
+        // the candidates arrive in raster order = FAST's emission order (fast.cpp:271-290): the kernels compact them that way
+        // retainBest on 8-byte keys (response, index): std::nth_element / std::partition make the same comparisons in the same order
+        // whatever else an element carries, so the keys end up permuted exactly as the reference's KeyPoints would
+        std::vector<Key> keys(n);
+        for (int i = 0; i < n; ++i) keys[i] = Key{(float)c[2 * i + 1], i};
+        retain_best(keys, 2 * quota[l]);
         std::vector<Cand>& kl = per_level[l];
-        kl.resize(n);
-        for (int i = 0; i < n; ++i) kl[i] = Cand{keyed[i].first % lw, keyed[i].first / lw, l, (float)keyed[i].second};
-        retain_best(kl, 2 * quota[l]);
+        kl.resize(keys.size());
+        for (size_t j = 0; j < keys.size(); ++j) { const int p = c[2 * keys[j].i]; kl[j] = Cand{p & 0xffff, p >> 16, l, keys[j].response}; }
+        (void)lw;
     };
-    {
-        std::vector<std::thread> workers;
-        for (int l = 1; l < kOrbLevels; ++l) if (h_counts[l] > 2000) workers.emplace_back(level_job, l);
-        for (int l = 0; l < kOrbLevels; ++l) if (l == 0 || h_counts[l] <= 2000) level_job(l);
-        for (auto& t : workers) t.join();
+    {   // level 0 holds ~45 % of the candidates: one helper thread takes the other seven levels (a thread per level cost more in thread
+        // creation, ~50 us each, than the levels' work)
+        std::thread helper;
+        if (h_counts[0] > 2000) helper = std::thread([&]() { for (int l = 1; l < kOrbLevels; ++l) level_job(l); });
+        level_job(0);
+        if (helper.joinable()) helper.join();
+        else for (int l = 1; l < kOrbLevels; ++l) level_job(l);
     }
     for (int l = 0; l < kOrbLevels; ++l) {
         counts[l] = (int)per_level[l].size();
         all.insert(all.end(), per_level[l].begin(), per_level[l].end());
     }
+    ms_sort = since();
     if (all.empty()) return 0;
     if ((int)all.size() > kp_cap) { err = "keypoint buffer overflow"; return -1; }
 
@@ -161,6 +167,7 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
     ORB_CHK(hipMemcpyAsync(h_val, d_val, all.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
     for (size_t i = 0; i < all.size(); ++i) all[i].response = h_val[i];
+    ms_harris = since();
 
     std::vector<Cand> fin;
     size_t off = 0;
@@ -181,6 +188,12 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
         const float sc = S.lv[fin[i].level].scale;
         out[i] = OrbKeyPoint{(float)fin[i].x * sc, (float)fin[i].y * sc, patch * sc, h_val[i], fin[i].response, fin[i].level, -1};
         last_levels[3 * i] = fin[i].level; last_levels[3 * i + 1] = fin[i].x; last_levels[3 * i + 2] = fin[i].y;
+    }
+    if (stage_times) {
+        long long ncand = 0;
+        for (int l = 0; l < kOrbLevels; ++l) ncand += h_counts[l];
+        fprintf(stderr, "  orb detect %dx%d: pyramid + FAST %.3f, %lld candidates on the host %.3f, order + retainBest %.3f, Harris %.3f, angle %.3f ms (cumulative)\n",
+                w, h, ms_fast, ncand, ms_cand, ms_sort, ms_harris, since());
     }
     return (int)fin.size();
 }

@@ -26,6 +26,7 @@ public:
     OrbLevelSet S{};
     uint8_t *d_img = nullptr, *d_atlas = nullptr, *d_blur = nullptr, *d_scores = nullptr, *d_desc = nullptr;
     int *d_counters = nullptr, *d_cand = nullptr, *d_kp = nullptr;
+    void* d_nms = nullptr;                   // scratch of the ordered compaction (kernels_orb.h: fast_nms_scratch_bytes)
     float* d_val = nullptr;
     int *h_cand = nullptr, *h_kp = nullptr;
     float* h_val = nullptr;
