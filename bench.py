@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — morph frames/sec at 1080p for 60-frame sequences (BASELINE.json metric) on N MI355X GPUs of one node.
 
-N = 1 (BASELINE.json configs[1]).  A step = PAIRS (4) independent synthetic 1080p pairs (seeds 1234 + k), each
+N = 1 (BASELINE.json configs[1]).  A step = PAIRS (6) independent synthetic 1080p pairs (seeds 1234 + k), each
 taken through the WHOLE of poppy::morph (src/poppy.hpp:46-248) by the library:
     poppy_hip_pair_begin_device   raw BGR pair (resident in HBM before the timed region) -> foreground x2, dft_detail2 x2, ORB
                                   input x2, ORB x2, matcher, gabor2: the real point sets and mask field, nothing synthetic
@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H, FRAMES = 1920, 1080, 60
-PAIRS = 4                      # pairs per step at N = 1
+PAIRS = 6                      # pairs per step at N = 1 (two per context of the default pool)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 WARP_CONTRACT_B_PER_PX = 16.0  # the faithful fused map+remap kernel
 WARP_RIDER_B_PER_PX = 8.0      # m2 in, lbmask out (the kernel computes the blend mask on the way)
@@ -283,12 +283,12 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 60)")
-    ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 4)")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 6)")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
     ap.add_argument("--total-frames", type=int, default=480, help="N > 1: frames of the ONE phase-mode morph that is sharded by frame range (fixed for every N: strong scaling); also the size of the N = 1 line's scaling_baseline_480")
     ap.add_argument("--no-shard-setup", action="store_true", help="N > 1: pair set-up on rank 0 alone + one broadcast of the pair state (round 2's form) instead of the set-up spread over ranks 0-2")
     ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the 512x512x30 whole-morph CPU figure (~40 s of oracle time)")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 2 (4 measured +3 % at N = 1, at the price of a lower in-bench roofline fraction: more kernels compete)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 3 (measured on one box, pairs per step 4 / 8: 2 contexts 5.11k / 5.03k frames/s, 3: 5.35k / 5.51k, 4: 5.26k / 5.36k; the roofline kernel's in-bench launches stretch from 21.6 to 23.5-24.8 and 27 us as more kernels compete)")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
     if args.width and args.height:
@@ -305,7 +305,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.contexts <= 0:
-        args.contexts = 2
+        args.contexts = 3
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:

@@ -24,6 +24,9 @@
 // masks themselves to the warp kernel — 208 bytes per entry behind a tile_off lookup — and resolved painter's order there: timing
 // builds showed that kernel's front end, not its arithmetic, to be what its duration followed: profiles/r03_notes.md.)
 #include "warp_fast_device.h"
+#ifndef POPPY_WARP_WAVES
+#define POPPY_WARP_WAVES 8      // waves per SIMD the register allocation must leave room for (64 VGPRs: the 2025 workgroups of a 1080p frame are then ONE round)
+#endif
 #include <climits>
 #include <cstdlib>
 
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
 }
 
 template <int kTileW>
-__global__ void __launch_bounds__(256) k_warp_bin(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
+__global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
                                                   const int* __restrict__ tile_off,
                                                   const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                   uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
