@@ -8,7 +8,7 @@ issue slots, so kernels with packed arithmetic (warp, unsharp) are busier than t
 wave spends waiting."""
 import re, sys
 FRAME = ["k_upload", "k_tile_expand", "k_warp_bin", "k_pyrdown_level<true>", "k_pyrdown_level<false>", "k_pyrdown2", "k_pyr_tail", "k_collapse2",
-         "k_collapse_level<false>", "k_collapse_level<true>", "k_unsharp_tile"]
+         "k_collapse_level<false>", "k_collapse_level<true>", "k_unsharp_tile", "k_unsharp_stream"]
 for tag in sys.argv[1:]:
     vals = {}
     head = ""
