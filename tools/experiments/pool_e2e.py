@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 from poppy_amd import capi, synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 contexts = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-W, H, FRAMES, PAIRS = 1920, 1080, 60, 4
+W, H, FRAMES = 1920, 1080, 60
+PAIRS = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 capi.lib()
 hip = ctypes.CDLL("libamdhip64.so")
 ptrs = []
