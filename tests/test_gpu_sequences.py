@@ -106,6 +106,25 @@ def test_cfg3_4k_phase_mode_frame():
     c.close()
 
 
+def test_cfg3_4k_sequence_in_flight_equals_single_frames():
+    """configs[2] as bench.py runs it: 3840x2160 phase-mode frames of one pair, several in flight, handed to a writer through the pinned ring.
+    Every delivered frame must equal the frame rendered on its own (the streaming unsharp kernel, the 128 x 8 warp tiles and the id bytes are
+    what a 4K frame takes); the frame at t = 0.5 is the reference's own (fixture a_3840x2160_phase)."""
+    case = "a_3840x2160_phase"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=1)
+    c.pair_begin(inp["img1"], inp["img2"])
+    ts = np.array([k / 121.0 for k in (1, 30, 60, 61, 90, 120)] + [0.5])
+    got = []
+    c.render_many(ts, chain=False, write=lambda f: got.append(f.copy()))
+    assert len(got) == len(ts)
+    G.check(case, "frame0", got[-1])
+    for t, f in zip(ts[:-1], got[:-1]):
+        c.reset()
+        assert np.array_equal(c.render(float(t), float(t), chain=False), f), t
+    c.close()
+
+
 def test_distance_flag_writes_nothing():
     case = "a_512x512_chain30"
     inp = G.astage_inputs(case)
