@@ -57,7 +57,7 @@ int ForegroundFilter::ensure(int w, int h) {
     FG_CHK(hipMalloc((void**)&flows, P * kMog2Steps));             // one mask plane per MOG2 step
     FG_CHK(hipMalloc((void**)&masked, P)); FG_CHK(hipMalloc((void**)&out, P)); FG_CHK(hipMalloc((void**)&lut, 256));
     FG_CHK(hipMalloc((void**)&tmp16, P * 2));
-    FG_CHK(hipMalloc((void**)&padded, median_padded_bytes(w, h)));
+    FG_CHK(hipMalloc((void**)&padded, 2 * median_padded_bytes(w, h)));        // two: a median reads one and writes the next one's
     FG_CHK(hipMalloc((void**)&hist, 256 * sizeof(unsigned)));
     W = w; H = h;
     return 0;
@@ -77,14 +77,18 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     //    It does not depend on the masks, so it runs first and every plane is kept.
     const uint8_t* inputs[kMog2Steps];
     inputs[0] = grey;
-    const uint8_t* last = grey;
+    uint8_t* pad[2] = {padded, padded + median_padded_bytes(w, h)};
+    int pc = 0;
+    launch_pad_cols(grey, pad[pc], w, h, s);                  // medianBlur(ksize 1) is a copy: the first real median reads the grey image
     for (int i = 0; i < 12; ++i) {
         uint8_t* med = meds + (size_t)i * P;
         const int ksize = i * 8 + 1;
-        if (ksize <= 1) chk(hipMemcpyAsync(med, last, P, hipMemcpyDeviceToDevice, s), "copy");
-        else launch_median_u8(last, padded, med, w, h, ksize, s);
+        if (ksize <= 1) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy");
+        else {                                                // every median writes its result twice: tight (MOG2's input) and padded (the next median's)
+            launch_median_padded(pad[pc], med, i < 11 ? pad[pc ^ 1] : nullptr, w, h, ksize, s);
+            pc ^= 1;
+        }
         inputs[i + 1] = med;
-        last = med;
     }
     // 2. all thirteen MOG2 applies in one launch (mixture in registers), one mask plane per step
     float alphaT[kMog2Steps], prune[kMog2Steps];

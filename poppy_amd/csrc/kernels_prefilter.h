@@ -24,6 +24,10 @@ bool prepare_median_u8();               // raises the kernel's LDS limit once; c
 // padded_tmp: median_padded_bytes(w, h) bytes of scratch (the source with replicated side columns)
 size_t median_padded_bytes(int w, int h);
 void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s);
+// The same in two parts, for chains of medians: launch_pad_cols makes the padded copy of a source; launch_median_padded filters a padded source into
+// dst (tight rows) and, when padded_next is not null, ALSO writes the result as the padded source of the next median (one launch per link of the chain).
+void launch_pad_cols(const uint8_t* src, uint8_t* padded, int w, int h, hipStream_t s);
+void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, hipStream_t s);
 
 // GaussianBlur(src, dst, 23x23, sigma 1) on 8 bit (the fixed-point path); tmp = w*h uint16
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);

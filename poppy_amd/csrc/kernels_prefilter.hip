@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(256) k_pad_cols(const uint8_t* __restrict__ sr
 // workgroup barriers per row step (updates | search | updates) and the search done twice.  Counts cannot go negative whatever the
 // order of the two waves' atomics: a value removed in a step is in the window at its start.
 template <int NDW, int NW, int WV>
-__device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
-                                            int ksize, int rows_per_block) {
+__device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst,
+                                            uint8_t* __restrict__ padded_out, int W, int H, int ksize, int rows_per_block) {
     const int lane = threadIdx.x & (kMedLanes - 1);
     const int x = blockIdx.x * kMedLanes + lane;
     const int y_begin = blockIdx.y * rows_per_block, y_end = min(y_begin + rows_per_block, H);
@@ -309,7 +309,16 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
                 s += count_of(cb * 16 + k);
                 fb += (s > half) ? 0 : 1;
             }
-            if (live) dst[(size_t)y * W + x] = (uint8_t)(cb * 16 + fb);
+            if (live) {
+                const uint8_t m = (uint8_t)(cb * 16 + fb);
+                dst[(size_t)y * W + x] = m;
+                if (padded_out) {                             // the next median of the chain reads its source with replicated side columns: written here
+                    uint8_t* prow = padded_out + (size_t)y * Wp;
+                    prow[kMedPad + x] = m;
+                    if (x == 0) for (int j = 0; j < kMedPad; ++j) prow[j] = m;
+                    if (x == W - 1) for (int j = 0; j < kMedPad; ++j) prow[kMedPad + W + j] = m;
+                }
+            }
         }
         if (NW > 1) __syncthreads();                          // every wave has read the window's counts
         if (y + 1 < y_end) {
@@ -323,20 +332,27 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
 }
 
 template <int NDW, int NW>
-__global__ void __launch_bounds__(kMedLanes * NW) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, int W, int H,
-                                                              int ksize, int rows_per_block) {
+__global__ void __launch_bounds__(kMedLanes * NW) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, uint8_t* __restrict__ padded_out,
+                                                              int W, int H, int ksize, int rows_per_block) {
     __shared__ uint32_t hist[kMedWords * kMedLanes];
     static_assert(NW == 1 || NW == 2 || NW == 4, "waves per histogram set");
     static_assert(NW <= NDW, "every wave needs a dword of the row");
     const int wv = threadIdx.x >> 6;
-    if (NW == 1 || wv == 0) median_body<NDW, NW, 0>(hist, srcp, dst, W, H, ksize, rows_per_block);
-    else if (NW == 2 || wv == 1) median_body<NDW, NW, 1 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
-    else if (wv == 2) median_body<NDW, NW, 2 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
-    else median_body<NDW, NW, 3 % NW>(hist, srcp, dst, W, H, ksize, rows_per_block);
+    if (NW == 1 || wv == 0) median_body<NDW, NW, 0>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (NW == 2 || wv == 1) median_body<NDW, NW, 1 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (wv == 2) median_body<NDW, NW, 2 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else median_body<NDW, NW, 3 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+}
+void launch_pad_cols(const uint8_t* src, uint8_t* padded, int w, int h, hipStream_t s) {
+    const int wp = w + 2 * kMedPad;
+    hipLaunchKernelGGL(k_pad_cols, dim3((wp + 255) / 256, h), dim3(256), 0, s, src, padded, w, h);
 }
 void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int w, int h, int ksize, hipStream_t s) {
-    const int wp = w + 2 * kMedPad;
-    hipLaunchKernelGGL(k_pad_cols, dim3((wp + 255) / 256, h), dim3(256), 0, s, src, padded_tmp, w, h);
+    launch_pad_cols(src, padded_tmp, w, h, s);
+    launch_median_padded(padded_tmp, dst, nullptr, w, h, ksize, s);
+}
+void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, hipStream_t s) {
+    const uint8_t* padded_tmp = padded_src;
     // Segments of rows.  A segment pays a ksize-row warm-up, so longer is cheaper in total work; but a wave is a long
     // serial instruction stream and 35 KB of LDS limits a CU to 4 of them, so the time is that of ONE segment as long as
     // there are no more than ~1000: aim for that many, never shorter than ksize / 2 rows.
@@ -354,7 +370,7 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
     // waves per histogram set: POPPY_MED_WAVES forces 1 / 2 / 4 (experiments); default by row length
     static const int forced = getenv("POPPY_MED_WAVES") ? atoi(getenv("POPPY_MED_WAVES")) : 0;
     const int nw = forced == 1 || ndw < 2 ? 1 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 4 ? kMedWavesLong : 1);
-#define MEDW(N, NWV) hipLaunchKernelGGL((k_median_u8<N, NWV>), dim3(col_blocks, segs), dim3(kMedLanes * NWV), 0, s, padded_tmp, dst, w, h, ksize, rows)
+#define MEDW(N, NWV) hipLaunchKernelGGL((k_median_u8<N, NWV>), dim3(col_blocks, segs), dim3(kMedLanes * NWV), 0, s, padded_tmp, dst, padded_next, w, h, ksize, rows)
 #define MED(N) case N: if (nw == 4) MEDW(N, (N >= 4 ? 4 : 1)); else if (nw == 2) MEDW(N, (N >= 2 ? 2 : 1)); else MEDW(N, 1); break;
     switch (ndw) {
         MED(1) MED(2) MED(3) MED(4) MED(5) MED(6) MED(7) MED(8) MED(9) MED(10) MED(11) MED(12) MED(13) MED(14) MED(15) MED(16)
