@@ -224,7 +224,14 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; }
     };
-    {
+    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
+    if (serial_chains) {
+        const double t0 = since(t_begin);
+        chain_of(0);
+        const double t1 = since(t_begin);
+        chain_of(1);
+        if (stage_times) fprintf(stderr, "  chains one after the other: image 1 %.3f ms, image 2 (+ gabor2) %.3f ms\n", t1 - t0, since(t_begin) - t1);
+    } else {
         std::thread other(chain_of, 1);
         chain_of(0);
         other.join();
