@@ -24,8 +24,8 @@ One JSON line on rank 0 (driver contract) with
                 the dominant kernel (fused create_map + remap of both sources): algorithmic bytes per launch = 16 B/px (SURVEY.md
                 8d, faithful path: id 4 + src 3 + 3 in, warped 3 + 3 out) x pixels, / the kernel's average launch duration
                 measured live with HIP events attached to the dispatch on the library's stream (one launch in seven of the timed
-                region).  The kernel moves LESS than the contract counts: no id map (the raster reaches it as per-tile row masks,
-                ~1.3 B/px) and no blend mask (the level-0 blend kernels derive it from m2) — 12 B/px of images; `moved_*` states
+                region).  The kernel moves about what the contract counts: no id map (the raster reaches it as one id byte per pixel
+                + 2.5 KB of record slots per tile, ~3.6 B/px) and no blend mask (the level-0 blend kernels derive it from m2) — 12 B/px of images; `moved_*` states
                 that.  Only when the mask rider is on (POPPY_HIP_LBMASK_RIDER) `frac_with_rider` adds its 8 B/px;
   cpu_baseline  oracle/ (CPU restatement, "port"): 20 chained 1080p frames of pair 0 from the GPU's own pair state on 1 thread (`value`),
                 the same operator on every host thread at once (`all_cores`), and one whole morph incl. the oracle's pair set-up at
@@ -110,7 +110,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
         out.update({"achieved_with_rider": round(ach_r, 1), "frac_with_rider": round(ach_r / HBM_PEAK_GBS, 4)})
     else:
         out.update({"moved_image_bytes_per_launch": int(12 * P), "moved_GBps": round(rate(12.0 * P), 1),
-                    "moved_note": "what the kernel itself reads and writes: c1 3 + c2 3 in, tr1 3 + tr2 3 out = 12 B/px (+ ~1.3 B/px of raster row masks and records); no id map, no blend mask"})
+                    "moved_note": "what the kernel itself reads and writes: c1 3 + c2 3 in, tr1 3 + tr2 3 out = 12 B/px (+ 1 B/px of id bytes and ~2.5 B/px of record slots: 15.6 B/px by the counters); no id map, no blend mask"})
     facts = profile_facts(ctx.warp_kernel_name(), w, h)
     if facts:
         if facts.get("trace_avg_us"):

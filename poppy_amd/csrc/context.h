@@ -38,7 +38,7 @@ struct FrameSlot {
     int32_t* triMap = nullptr;
     int map_tag = 0;                            // frame tag of the values last written to triMap (kernels.h: launch_raster); 0 = must be zeroed first
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // this slot's frame plan (pinned host copy, device copy)
-    uint8_t* tile_data = nullptr;                   // per-tile entries (row masks + records) expanded from the plan on the device (kernels_warp_bin.hip)
+    uint8_t* tile_data = nullptr;                   // the plan's raster expanded on the device: id bytes, record slots, overflow records (kernels_warp_bin.hip)
     void* h_blob_dev = nullptr;                     // device-side address of the pinned copy
     hipEvent_t uploaded = nullptr;                  // the device copy is complete
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry

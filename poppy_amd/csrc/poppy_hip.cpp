@@ -633,7 +633,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     hipStream_t up = chained ? c->copy_stream : s;
     if (chained) HIPCHK(c, hipEventSynchronize(f.done));          // the frame that last read this slot's device copy of the plan (2+ frames back)
     launch_upload(f.h_blob_dev, f.d_blob, used, up);
-    // the raster of the frame, as per-tile row masks: needs the plan only
+    // the raster of the frame, as one id byte per pixel + the tiles' record slots: needs the plan only
     if (bin_warp) launch_tile_expand(d_rec, d_edges, d_outl, d_toff, d_ttri, f.tile_data, c->plan.tile_w, W, H, up);
     // (The blend mask also depends on the plan only.  Taking it out of the warp kernel — a kernel of its own on this stream —
     // made that kernel faster (20.5 -> 18.1 us at 1080p, 53.6 -> 46.5 us at 4K) and the chained FRAME slower (183.8 -> 188.3 us,

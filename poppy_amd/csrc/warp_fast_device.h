@@ -1,5 +1,5 @@
 // warp_fast_device.h — the packed-arithmetic pieces shared by the two tiled warp kernels (kernels_warp_fast.hip: ids from the
-// id map; kernels_warp_bin.hip: ids rasterised in LDS).  The header comment of kernels_warp_fast.hip explains why each of them
+// id map; kernels_warp_bin.hip: one id byte per pixel from k_tile_expand).  The header comment of kernels_warp_fast.hip explains why each of them
 // returns the reference's bits.
 #pragma once
 #include "kernels.h"
