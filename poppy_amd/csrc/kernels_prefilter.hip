@@ -35,8 +35,24 @@ constexpr int kMog2Modes = 5;
 // Kept out of line on purpose: inlined into k_mog2_all's step loop, hipcc 7.2 drops the `mu[k] = data; v[k] = varInit` stores of a
 // newly opened mode (found by comparing the fused kernel with a step-by-step one on the same inputs; an optimisation barrier
 // or a memory round trip of the model between steps did not help).  The call costs nothing that matters here.
-__device__ __noinline__ int mog2_step(float (&w)[kMog2Modes], float (&v)[kMog2Modes], float (&mu)[kMog2Modes], int& nmodes,
-                                         float data, float alphaT, float prune) {
+// The mixture travels BY VALUE (in and out in registers: 17 dwords); passed by reference the arrays of an out-of-line call live in scratch
+// memory, 30 scratch accesses per step and pixel.
+typedef float mog2_vec __attribute__((ext_vector_type(16)));      // w[5], v[5], mu[5], and nmodes | out << 8 as the bits of the last lane
+__device__ __forceinline__ int mog2_step_body(float (&w)[kMog2Modes], float (&v)[kMog2Modes], float (&mu)[kMog2Modes], int& nmodes,
+                                              float data, float alphaT, float prune);
+__device__ __noinline__ mog2_vec mog2_step(mog2_vec m, float data, float alphaT, float prune) {
+    float w[kMog2Modes], v[kMog2Modes], mu[kMog2Modes];
+#pragma unroll
+    for (int k = 0; k < kMog2Modes; ++k) { w[k] = m[k]; v[k] = m[kMog2Modes + k]; mu[k] = m[2 * kMog2Modes + k]; }
+    int nmodes = __float_as_int(m[15]) & 255;
+    const int out = mog2_step_body(w, v, mu, nmodes, data, alphaT, prune);
+#pragma unroll
+    for (int k = 0; k < kMog2Modes; ++k) { m[k] = w[k]; m[kMog2Modes + k] = v[k]; m[2 * kMog2Modes + k] = mu[k]; }
+    m[15] = __int_as_float(nmodes | (out << 8));
+    return m;
+}
+__device__ __forceinline__ int mog2_step_body(float (&w)[kMog2Modes], float (&v)[kMog2Modes], float (&mu)[kMog2Modes], int& nmodes,
+                                              float data, float alphaT, float prune) {
     const float kBgSigma2 = 16.f, kBgShare = 0.9f, kMatchSigma2 = 9.f, kVar0 = 15.f, kVarLo = 4.f, kVarHi = 75.f, kShadowLo = 0.5f;
     const float keep = 1.f - alphaT;
     bool background = false, matched = false;
@@ -149,13 +165,11 @@ struct Mog2Inputs { const uint8_t* img[kMog2Steps]; float alphaT[kMog2Steps], pr
 __global__ void __launch_bounds__(256) k_mog2_all(Mog2Inputs in, uint8_t* __restrict__ flows, int n, int steps) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    float w[kMog2Modes], v[kMog2Modes], mu[kMog2Modes];
-#pragma unroll
-    for (int k = 0; k < kMog2Modes; ++k) w[k] = v[k] = mu[k] = 0.f;
-    int nmodes = 0;
+    mog2_vec m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // no modes yet
     for (int i = 0; i < steps; ++i) {
         const float data = (float)in.img[i][p];
-        flows[(size_t)i * n + p] = (uint8_t)mog2_step(w, v, mu, nmodes, data, in.alphaT[i], in.prune[i]);
+        m = mog2_step(m, data, in.alphaT[i], in.prune[i]);
+        flows[(size_t)i * n + p] = (uint8_t)(__float_as_int(m[15]) >> 8);
     }
 }
 
