@@ -371,7 +371,9 @@ def bench_single(args, torch, capi, dev, local):
         "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "timed_region_s": round(dt, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "scaling_note": "the --gpus N lines shard ONE fixed 480-frame 1080p morph by frame range (total work fixed: strong); the N = 1 point of that series is "
+                        "`scaling_baseline_480.fps` of this line (the same job on one GPU), not this line's `value`, which is BASELINE.json configs[1]",
         "dtype": "u8+f32",
         "dtype_note": "u8 pixels and fixed-point remap, f32 pyramid and unsharp, f64 Gabor sums; bit-compatible with the reference (no FMA contraction)",
         "data": "synthetic (integer-defined shapes pairs, seeds 1234+k: poppy_amd/synth.py); point sets and mask field come from the real pair set-up",
