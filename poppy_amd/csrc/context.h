@@ -90,6 +90,7 @@ struct poppy_hip_ctx {
     hipStream_t copy_stream = nullptr;
     FramePlan plan;
     OrbDetector orb, orb_b;
+    Worker setup_worker;                            // the second image's half of a pair set-up (chain, detector)
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;
     double initial_morph_dist = 0;

@@ -265,6 +265,7 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
         for (int i = WV; i < NDW; i += NW)
             __builtin_memcpy(&regs[i], p + 4 * i, 4);
     };
+    constexpr bool kSumCoarse = NDW >= 7;                     // ksize 25 and up (625+ coarse atomics per lane against 256 reads shared by the waves; at 17 the reads lose: 65 -> 75 us)
     auto apply_row = [&](const uint32_t* regs, bool add) {
 #pragma unroll
         for (int i = WV; i < NDW; i += NW) {
@@ -272,7 +273,13 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
                 const int nb = (i == ndw - 1) ? tail : 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < nb) med_update(lane_base, unit, (regs[i] >> (8 * k)) & 255u, add);
+                    if (k < nb) {
+                        const uint32_t v = (regs[i] >> (8 * k)) & 255u;
+                        if (kSumCoarse) {                       // fine bins only: the warm-up's coarse counts are summed up once, below
+                            uint32_t* f = reinterpret_cast<uint32_t*>(lane_base + v * kMedBinBytes);
+                            if (add) atomicAdd(f, unit); else atomicSub(f, unit);
+                        } else med_update(lane_base, unit, v, add);
+                    }
             }
         }
     };
@@ -305,6 +312,19 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
         apply_row(cur, true);
     }
     if (y_begin + 1 < y_end) { load_row(row_ptr(y_begin + r + 1), ra); load_row(row_ptr(y_begin - r), rs); }
+    // The warm-up is ksize * ksize additions per lane — 40 % of a segment's atomics at ksize 89 — and none of them cancels; its coarse level is
+    // therefore not kept by atomics but summed from the fine bins once, every wave a share of the 16 groups (256 reads per lane instead of
+    // ksize * ksize atomics).
+    if (kSumCoarse && NW > 1) __syncthreads();                // every wave's fine additions are in
+#pragma unroll 1
+    for (int g = WV; kSumCoarse && g < 16; g += NW) {
+        int c[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] = count_of(g * 16 + j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += c[j];
+        *reinterpret_cast<uint16_t*>(hist_b + kMedCoarseOff + g * kMedBinBytes + (lane & 31) * 4 + (lane >> 5) * 2) = (uint16_t)sum;
+    }
     for (int y = y_begin; y < y_end; ++y) {
         if (NW > 1) __syncthreads();                          // every wave's updates of this window are in
         if (WV == 0) {                                        // one wave searches; the others wait at the barrier below

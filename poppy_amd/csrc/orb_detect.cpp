@@ -92,26 +92,44 @@ hipError_t OrbDetector::prepare(int w, int h) {
 int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out,
                         bool gray_on_device) {
     out.clear();
+    const int rc = detect_begin(gray, stride, w, h, s, gray_on_device);
+    return rc < 0 ? rc : detect_finish(nfeatures, s, out);
+}
+
+static const bool g_stage_times = getenv("POPPY_SETUP_TIMING") != nullptr;              // host wall time of the detection's stages on stderr
+
+int OrbDetector::detect_begin(const uint8_t* gray, size_t stride, int w, int h, hipStream_t s, bool gray_on_device) {
     ORB_CHK(prepare(w, h));
-    const int edge = 31, patch = 31, fastThreshold = 20;
-    static const bool stage_times = getenv("POPPY_SETUP_TIMING") != nullptr;          // host wall time of the detection's stages on stderr
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    double ms_fast = 0, ms_cand = 0, ms_sort = 0, ms_harris = 0;
+    const int edge = 31, fastThreshold = 20;
+    t_begin_ = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin_).count(); };
     ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, gray_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
     launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, d_nms, s);
     int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
     ORB_CHK(hipMemcpyAsync(h_counts, d_counters, kOrbLevels * sizeof(int), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
-    ms_fast = since();
+    ms_fast_ = since();
     for (int l = 0; l < kOrbLevels; ++l) {
         if (h_counts[l] > cap) { err = "FAST candidate buffer overflow"; return -1; }
         if (h_counts[l])
             ORB_CHK(hipMemcpyAsync(h_cand + (size_t)l * cap * 2, d_cand + (size_t)l * cap * 2, (size_t)h_counts[l] * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     }
     ORB_CHK(hipStreamSynchronize(s));
-    ms_cand = since();
+    ms_cand_ = since();
+    return 0;
+}
+
+int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out) {
+    out.clear();
+    if (!W) { err = "detect_finish without detect_begin"; return -1; }
+    const int w = W, h = H, patch = 31;
+    const bool stage_times = g_stage_times;
+    const auto t_finish = std::chrono::steady_clock::now();
+    auto since = [&]() { return ms_cand_ + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_finish).count(); };
+    const double ms_fast = ms_fast_, ms_cand = ms_cand_;
+    double ms_sort = 0, ms_harris = 0;
+    int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
 
     // per-level quota (orb.cpp:803-813)
     int quota[kOrbLevels];
@@ -142,12 +160,12 @@ int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nf
         for (size_t j = 0; j < keys.size(); ++j) { const int p = c[2 * keys[j].i]; kl[j] = Cand{p & 0xffff, p >> 16, l, keys[j].response}; }
         (void)lw;
     };
-    {   // level 0 holds ~45 % of the candidates: one helper thread takes the other seven levels (a thread per level cost more in thread
+    {   // level 0 holds ~45 % of the candidates: the helper thread takes the other seven levels (a thread per level cost more in thread
         // creation, ~50 us each, than the levels' work)
-        std::thread helper;
-        if (h_counts[0] > 2000) helper = std::thread([&]() { for (int l = 1; l < kOrbLevels; ++l) level_job(l); });
+        const bool split = h_counts[0] > 2000;
+        if (split) helper_.run([&]() { for (int l = 1; l < kOrbLevels; ++l) level_job(l); });
         level_job(0);
-        if (helper.joinable()) helper.join();
+        if (split) helper_.wait();
         else for (int l = 1; l < kOrbLevels; ++l) level_job(l);
     }
     for (int l = 0; l < kOrbLevels; ++l) {

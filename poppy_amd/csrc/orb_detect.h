@@ -1,6 +1,8 @@
 // orb_detect.h — ORB::detect driver (host) over the kernels of kernels_orb.hip.
 #pragma once
 #include "kernels_orb.h"
+#include "worker.h"
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -14,6 +16,11 @@ public:
     // ORB::create(nfeatures)->detect(gray): host image in, keypoints (order significant) out.  <0 on error (see err).
     int detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out,
                bool gray_on_device = false);   // gray_on_device: `gray` is a device pointer of this GPU (no host round trip)
+    // The same in two halves.  detect_begin: everything that does not depend on nfeatures — pyramid, FAST scores, non-maximum suppression, the
+    // raster-ordered candidates on the host (returns after they have arrived; 0 or <0 on error).  detect_finish: quotas, retainBest, Harris,
+    // retainBest, angles (orb.cpp:803-959).  The pair set-up knows nfeatures only when BOTH images' chains are through (src/extractor.cpp:40-45).
+    int detect_begin(const uint8_t* gray, size_t stride, int w, int h, hipStream_t s, bool gray_on_device = false);
+    int detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out);
     // ORB::compute: 32 bytes per keypoint (kps7 rows in cv::KeyPoint field order); returns n or <0
     int describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out);
     // BFMatcher(NORM_HAMMING).match on 32-byte descriptors: out3 rows (queryIdx, trainIdx, distance)
@@ -36,6 +43,9 @@ public:
 
 private:
     hipError_t prepare(int w, int h);
+    Worker helper_;                          // takes levels 1..7 of the first retainBest while the caller does level 0
+    std::chrono::steady_clock::time_point t_begin_{};
+    double ms_fast_ = 0, ms_cand_ = 0;
 };
 
 }  // namespace poppy_hip

@@ -216,14 +216,19 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
         hipError_t e = ratio >= 0.f ? hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st) : hipSuccess;
-        if (e == hipSuccess && i == 1 && !align_first) {
-            const float* gab = fg.gabor_field(c->c2, W, H, st);
-            if (!gab) { errs[i] = "gabor_field: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-            e = hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, st);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; }
+        if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; return; }
+        // the detector's first half needs no nfeatures (which takes BOTH images' detail, src/extractor.cpp:40-45): it follows the chain at once,
+        // so the image that is through first does not wait for the other with the GPU half idle
+        OrbDetector& orb = i ? c->orb_b : c->orb;
+        if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
     };
+    // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes first, on the plan-upload stream — idle
+    // during a set-up —, and runs beside the medians instead of after them, where the chains are a string of small dependent launches
+    if (!align_first) {
+        const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream);
+        if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return POPPY_E_DEVICE; }
+        HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->copy_stream));
+    }
     static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
     if (serial_chains) {
         const double t0 = since(t_begin);
@@ -232,10 +237,11 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         chain_of(1);
         if (stage_times) fprintf(stderr, "  chains one after the other: image 1 %.3f ms, image 2 (+ gabor2) %.3f ms\n", t1 - t0, since(t_begin) - t1);
     } else {
-        std::thread other(chain_of, 1);
+        c->setup_worker.run([&]() { chain_of(1); });
         chain_of(0);
-        other.join();
+        c->setup_worker.wait();
     }
+    if (!align_first) HIPCHK(c, hipStreamSynchronize(c->copy_stream));                // gabor2 is in place
     for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
     ms_chains = since(t_begin);
     const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
@@ -245,9 +251,9 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     std::vector<OrbKeyPoint> k1, k2;
     {   // the two detections are independent too
         int r1 = 0, r2 = 0;
-        std::thread other([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect(g_dev[1], W, W, H, nfeatures, c->aux_stream, k2, true) : -2; });
-        r1 = c->orb.detect(g_dev[0], W, W, H, nfeatures, c->stream, k1, true);
-        other.join();
+        c->setup_worker.run([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect_finish(nfeatures, c->aux_stream, k2) : -2; });
+        r1 = c->orb.detect_finish(nfeatures, c->stream, k1);
+        c->setup_worker.wait();
         if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }
     ms_detect = since(t_begin);
