@@ -93,6 +93,7 @@ struct poppy_hip_ctx {
     Worker setup_worker;                            // the second image's half of a pair set-up (chain, detector)
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;
+    hipEvent_t setup_ev = nullptr;                  // "the second image's medians are through" (pair set-up: gabor2 starts there)
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
     AutoAligner aligner;

@@ -90,6 +90,7 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
         }
         inputs[i + 1] = med;
     }
+    if (medians_done) chk(hipEventRecord(medians_done, s), "event record");
     // 2. all thirteen MOG2 applies in one launch (mixture in registers), one mask plane per step
     float alphaT[kMog2Steps], prune[kMog2Steps];
     for (int i = 0; i < kMog2Steps; ++i) {

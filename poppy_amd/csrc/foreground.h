@@ -38,6 +38,7 @@ public:
     int prepare(int w, int h) { return ensure(w, h); }
     std::string err;
 
+    hipEvent_t medians_done = nullptr;   // when set, run_device records it on its stream behind the last median (the pair set-up starts gabor2 there)
     bool radial_mask_on = false;         // Settings::enable_radial_mask (src/extractor.cpp:178-197): set before the first run of a geometry or any time after
     bool gabor_direct = false;           // run the Gabor banks as direct double sums even when the FFT spectra exist (tests compare the two)
 private:

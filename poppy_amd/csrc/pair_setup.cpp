@@ -205,12 +205,30 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     int rcs[2] = {POPPY_OK, POPPY_OK};
     // with auto-align, gabor2 belongs to the ALIGNED second image (src/poppy.hpp:116-122 runs after Matcher::find): computed further down
     const bool align_first = c->cfg.enable_auto_align != 0 && ratio < 0.f;
+    // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes to the plan-upload stream — idle during a
+    // set-up — and starts when the second image's medians are through, beside the strings of small dependent launches that follow them (at
+    // the very start it ran beside the first medians, one wave per histogram set, and tripled their time; POPPY_GABOR2_FIRST: that order)
+    static const bool gabor2_first = getenv("POPPY_GABOR2_FIRST") != nullptr;
+    auto gabor2_on_side_stream = [&]() -> bool {
+        const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream);
+        if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return false; }
+        if (hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->copy_stream) != hipSuccess) { c->err = "gabor2 copy failed"; return false; }
+        return true;
+    };
+    if (!align_first && gabor2_first && !gabor2_on_side_stream()) return POPPY_E_DEVICE;
+    if (!c->setup_ev) HIPCHK(c, hipEventCreateWithFlags(&c->setup_ev, hipEventDisableTiming));
+    c->foreground_b.medians_done = (!align_first && !gabor2_first) ? c->setup_ev : nullptr;
     auto chain_of = [&](int i) {
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
         ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
         hipStream_t st = i ? c->aux_stream : c->stream;
         const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
         if (!gf) { errs[i] = "foreground: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        if (i == 1 && fg.medians_done) {                          // gabor2 starts when the second image's medians are through (queued now, long before)
+            if (hipStreamWaitEvent(c->copy_stream, fg.medians_done, 0) != hipSuccess || !gabor2_on_side_stream()) {
+                errs[i] = c->err.empty() ? "gabor2: stream wait failed" : c->err; rcs[i] = POPPY_E_DEVICE; return;
+            }
+        }
         if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
@@ -222,13 +240,6 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         OrbDetector& orb = i ? c->orb_b : c->orb;
         if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
     };
-    // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes first, on the plan-upload stream — idle
-    // during a set-up —, and runs beside the medians instead of after them, where the chains are a string of small dependent launches
-    if (!align_first) {
-        const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream);
-        if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return POPPY_E_DEVICE; }
-        HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->copy_stream));
-    }
     static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
     if (serial_chains) {
         const double t0 = since(t_begin);
@@ -241,6 +252,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         chain_of(0);
         c->setup_worker.wait();
     }
+    c->foreground_b.medians_done = nullptr;
     if (!align_first) HIPCHK(c, hipStreamSynchronize(c->copy_stream));                // gabor2 is in place
     for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
     ms_chains = since(t_begin);
