@@ -5,6 +5,7 @@
 #include "kernels_prefilter.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -104,7 +105,14 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     int cur = 0;                                              // acc[cur] is fgMask
     launch_acc_flow(acc[cur], flows, n, acc_scale, s);
     stage_out(0, flows); stage_out(1, acc[cur]);
-    for (int i = 0; i < 12; ++i) {
+    // accumulate + blur: POPPY_ACC_STEPS of the twelve dependent steps per launch (1, 2, 3, 4, 6; 0: the byte-per-thread kernel, one step each)
+    static const int acc_steps = getenv("POPPY_ACC_STEPS") ? atoi(getenv("POPPY_ACC_STEPS")) : 3;
+    const bool fused = !(dbg && dbg->stages) && acc_steps > 0 && 12 % acc_steps == 0 && acc_steps != 5 && acc_steps <= 6 && acc_gauss23_fused_takes(w, h) && P % 4 == 0;
+    for (int i = 0; fused && i < 12; i += acc_steps) {
+        launch_acc_gauss23_fused(acc[cur], flows + (size_t)(i + 1) * P, P, acc_steps, acc[cur ^ 1], w, h, acc_scale, s);
+        cur ^= 1;
+    }
+    for (int i = 0; !fused && i < 12; ++i) {
         if (!(dbg && dbg->stages)) {                          // accumulate + blur in one launch; the staged form below also shows the sum before the blur
             launch_acc_gauss23(acc[cur], flows + (size_t)(i + 1) * P, acc[cur ^ 1], w, h, acc_scale, s);
             cur ^= 1;

@@ -33,6 +33,10 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);
 // dst = GaussianBlur23(acc + sat(round(flow * scale))) in one launch (acc is not modified)
 void launch_acc_gauss23(const uint8_t* acc, const uint8_t* flow, uint8_t* dst, int w, int h, float acc_scale, hipStream_t s);
+// S = 1, 2, 3, 4 or 6 of those steps in one launch (flows: the first step's mask plane, the following ones `plane` bytes apart), for the
+// geometries acc_gauss23_fused_takes() accepts (width divisible by 4, at least 256 x 64; 4-byte aligned planes)
+bool acc_gauss23_fused_takes(int w, int h);
+void launch_acc_gauss23_fused(const uint8_t* acc, const uint8_t* flows, size_t plane, int steps, uint8_t* dst, int w, int h, float acc_scale, hipStream_t s);
 
 // mask = log(fg/255*19 + 1)/log(20); masked = u8(grey/255 * mask * 255); out = equalizeHist(masked).
 // d_logtab: 512 floats (see foreground.cpp); hist: 256 unsigned; lut: 256 bytes; dbg (optional): 3*n_px floats lin, logged, mask;

@@ -123,20 +123,23 @@ int poppy_perspective_from4(const float* s4, const float* d4, double* m) {
     return POPPY_OK;
 }
 
-int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
+static int match_points_with(Worker* helper, const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
     if (n < 0 || W <= 0 || H <= 0 || !n_out || (n && (!p1 || !p2))) return POPPY_E_ARG;
     std::vector<P2f> a(n), b(n);
     if (n) { memcpy(a.data(), p1, (size_t)n * 8); memcpy(b.data(), p2, (size_t)n * 8); }
     drop_out_of_image(a, b, W, H);
     if (a.empty()) { *n_out = 0; if (imd) *imd = 0; return POPPY_OK; }     // caller falls back to the dissolve (poppy.hpp:125)
     std::vector<PointPair> pairs;
-    const double d = morph_distance_pairs(a, b, W, H, pairs);
+    const double d = morph_distance_pairs(a, b, W, H, pairs, helper);
     if (imd) *imd = d;
     match_and_prepare_from(pairs, a, b, W, H, tol, d);
     *n_out = (int)a.size();
     if (o1) memcpy(o1, a.data(), a.size() * 8);
     if (o2) memcpy(o2, b.data(), b.size() * 8);
     return POPPY_OK;
+}
+int poppy_match_points(const float* p1, const float* p2, int n, int W, int H, double tol, float* o1, float* o2, int* n_out, double* imd) {
+    return match_points_with(nullptr, p1, p2, n, W, H, tol, o1, o2, n_out, imd);
 }
 
 int poppy_hip_pair_begin_prefiltered(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2,
@@ -202,7 +205,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     // Extractor::keypoints; image 2 also through gabor_filter(corrected2 / 255), src/poppy.hpp:119-122): one host thread and
     // one stream each, so that the medians of one image run beside the Gabor bank of the other.
     std::string errs[2];
-    int rcs[2] = {POPPY_OK, POPPY_OK};
+    std::atomic<int> rcs[2] = {{POPPY_OK}, {POPPY_OK}};          // (each written by its own thread, read by the other once)
     // with auto-align, gabor2 belongs to the ALIGNED second image (src/poppy.hpp:116-122 runs after Matcher::find): computed further down
     const bool align_first = c->cfg.enable_auto_align != 0 && ratio < 0.f;
     // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes to the plan-upload stream — idle during a
@@ -218,7 +221,20 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     if (!align_first && gabor2_first && !gabor2_on_side_stream()) return POPPY_E_DEVICE;
     if (!c->setup_ev) HIPCHK(c, hipEventCreateWithFlags(&c->setup_ev, hipEventDisableTiming));
     c->foreground_b.medians_done = (!align_first && !gabor2_first) ? c->setup_ev : nullptr;
+    // Each image's thread goes on to the detector's second half by itself as soon as BOTH details are known (nfeatures, src/extractor.cpp:40-45):
+    // the other image's detail is ready long before its own candidates are, so nobody waits for a whole chain.  `details` counts the images
+    // whose detail is published (or whose chain failed before it).
+    std::atomic<int> details{0};
+    std::vector<OrbKeyPoint> k1, k2;
+    int nfeatures = 0;
+    struct Publish {                                                      // counts once, at the detail or at whichever exit comes before it
+        std::atomic<int>& n; bool done = false;
+        void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } }
+        ~Publish() { now(); }
+    };
+    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
     auto chain_of = [&](int i) {
+        Publish publish{details};
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
         ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
         hipStream_t st = i ? c->aux_stream : c->stream;
@@ -230,6 +246,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
             }
         }
         if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        publish.now();
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
@@ -238,9 +255,13 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         // the detector's first half needs no nfeatures (which takes BOTH images' detail, src/extractor.cpp:40-45): it follows the chain at once,
         // so the image that is through first does not wait for the other with the GPU half idle
         OrbDetector& orb = i ? c->orb_b : c->orb;
-        if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
+        if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; return; }
+        if (serial_chains) return;                                // (one chain after the other: the second half follows below)
+        while (details.load(std::memory_order_acquire) < 2) std::this_thread::yield();
+        if (rcs[i ^ 1]) return;                                   // the other chain failed (its error is reported)
+        const int nf = (int)(c->cfg.max_keypoints * (255.0 / std::max(d[0], d[1])));
+        if (orb.detect_finish(nf, st, i ? k2 : k1) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
     };
-    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
     if (serial_chains) {
         const double t0 = since(t_begin);
         chain_of(0);
@@ -254,14 +275,13 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     }
     c->foreground_b.medians_done = nullptr;
     if (!align_first) HIPCHK(c, hipStreamSynchronize(c->copy_stream));                // gabor2 is in place
-    for (int i = 0; i < 2; ++i) if (rcs[i]) { c->err = errs[i]; return rcs[i]; }
+    for (int i = 0; i < 2; ++i) if (rcs[i].load()) { c->err = errs[i]; return rcs[i].load(); }
     ms_chains = since(t_begin);
     const double detail = 255.0 / std::max(d[0], d[1]);                 // src/extractor.cpp:40-45
     c->last_detail[0] = d[0]; c->last_detail[1] = d[1];
-    const int nfeatures = (int)(c->cfg.max_keypoints * detail);
+    nfeatures = (int)(c->cfg.max_keypoints * detail);
     c->last_nfeatures = nfeatures;
-    std::vector<OrbKeyPoint> k1, k2;
-    {   // the two detections are independent too
+    if (serial_chains) {
         int r1 = 0, r2 = 0;
         c->setup_worker.run([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect_finish(nfeatures, c->aux_stream, k2) : -2; });
         r1 = c->orb.detect_finish(nfeatures, c->stream, k1);
@@ -326,7 +346,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
             HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
         }
         int m = 0;
-        rc = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
+        rc = match_points_with(&c->setup_worker, p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
         if (rc) return fail(c, rc, "poppy_match_points failed");
         rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
     }

@@ -23,7 +23,9 @@ double morph_distance_combine(float total, size_t n_pairs, float inner1_sum, flo
                               double area1, double area2, int w, int h);
 void match_and_prepare(std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h, double tolerance, double initial_morph_dist);
 // the two steps sharing one greedy pairing (the reference pairs the same sets twice: morph_distance, then match)
-double morph_distance_pairs(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h, std::vector<PointPair>& pairs);
+class Worker;
+// `helper`: a persistent thread for the O(n^2) offset sums that run beside the pairing (null: a std::thread is made for them)
+double morph_distance_pairs(const std::vector<P2f>& p1, const std::vector<P2f>& p2, int w, int h, std::vector<PointPair>& pairs, Worker* helper = nullptr);
 void match_and_prepare_from(const std::vector<PointPair>& pairs, std::vector<P2f>& s1, std::vector<P2f>& s2, int w, int h,
                             double tolerance, double initial_morph_dist);
 

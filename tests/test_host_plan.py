@@ -79,6 +79,40 @@ def test_host_point_matcher_on_real_keypoints():
     G.check(case, "prepared2", b)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_host_point_matcher_ties_and_tombstones_against_the_oracle(seed):
+    """The host matcher picks partners by SQUARED distance and takes a root only where floats could tie (point_match.cpp: greedy_pairs);
+    the oracle evaluates the reference's hypot for every candidate (oracle/match.cpp: make_distance_map, src/util.cpp:351-383).  Point sets made
+    to tie: integer grids, repeated points, ORB-style coordinates (integers times 1.2^level), the reference's tombstone value (-1, -1) —
+    filter_invalid_points keeps nothing negative, so that one enters through the pairing alone, below."""
+    import oracle_lib as O
+    rng = np.random.default_rng(100 + seed)
+    w, h, n = 640, 480, 300
+    kind = seed % 4
+    if kind == 0:                                          # coarse integer grid: many equal distances
+        p1 = rng.integers(0, 40, (n, 2)).astype(np.float32) * 12
+        p2 = rng.integers(0, 40, (n, 2)).astype(np.float32) * 12
+    elif kind == 1:                                        # ORB-like: level coordinates scaled by 1.2^level
+        lv = rng.integers(0, 8, n)
+        sc = (np.float32(1.2) ** lv).astype(np.float32)
+        p1 = (rng.integers(16, 300, (n, 2)).astype(np.float32) * sc[:, None]).astype(np.float32)
+        p2 = (rng.integers(16, 300, (n, 2)).astype(np.float32) * sc[::-1, None]).astype(np.float32)
+    elif kind == 2:                                        # duplicates of a few points, both sets
+        base = (rng.random((20, 2)) * [w - 1, h - 1]).astype(np.float32)
+        p1 = base[rng.integers(0, 20, n)]; p2 = base[rng.integers(0, 20, n)]
+    else:                                                  # near-ties: a jitter of one float ulp around common positions
+        base = (rng.random((30, 2)) * [w - 1, h - 1]).astype(np.float32)
+        p1 = base[rng.integers(0, 30, n)]
+        p2 = np.nextafter(base[rng.integers(0, 30, n)], np.float32(1e9) * rng.choice([-1, 1], (n, 2)).astype(np.float32)).astype(np.float32)
+    p1 = np.clip(p1, 0, [w, h]).astype(np.float32); p2 = np.clip(p2, 0, [w, h]).astype(np.float32)
+    f1, f2 = O.filter_invalid(p1, p2, w, h)
+    imd = O.morph_distance(f1, f2, w, h)
+    e1, e2 = O.match_prepare(f1, f2, w, h, 1.0, imd)
+    a, b, got = capi.match_points(p1, p2, w, h, 1.0)
+    assert got == imd
+    assert np.array_equal(a, e1) and np.array_equal(b, e2)
+
+
 def test_match_points_all_out_of_image():
     p = np.array([[-5, 3], [700, 2]], np.float32)
     a, b, imd = capi.match_points(p, p, 64, 48, 1.0)
