@@ -210,9 +210,15 @@ __global__ void __launch_bounds__(1024) k_fast_nms_scan(NmsLayout lay, int* __re
 }
 
 __global__ void __launch_bounds__(256) k_fast_nms_emit(const uint8_t* __restrict__ scores, OrbLevelSet S, NmsLayout lay, const int* __restrict__ rowblk,
-                                                       const uint8_t* __restrict__ keepbuf, size_t keep_stride, int* __restrict__ cand, int cap) {
+                                                       const uint8_t* __restrict__ keepbuf, size_t keep_stride, const int* __restrict__ counters,
+                                                       int* __restrict__ cand, int cap) {
     __shared__ int s_cnt[kNmsRows][4];
     const int lvl = blockIdx.z;
+    // the levels' lists lie one behind the other (the host fetches counts and candidates in ONE copy of a guessed length): this level starts
+    // where the survivors of the finer levels end (the scan kernel's totals)
+    int level_base = 0;
+    for (int l = 0; l < lvl; ++l) level_base += min(counters[l], cap);
+    const int total_cap = kOrbLevels * cap;
     const OrbLevel L = S.lv[lvl];
     const int W = L.w, nbx = lay.nbx[lvl];
     const int bx = blockIdx.x, y0 = blockIdx.y * kNmsRows;
@@ -234,10 +240,10 @@ __global__ void __launch_bounds__(256) k_fast_nms_emit(const uint8_t* __restrict
         if (keep & (1u << r)) {
             int slot = rowblk[lay.base[lvl] + (y0 + r) * nbx + bx] + rank[r];
             for (int w = 0; w < wv; ++w) slot += s_cnt[r][w];
-            if (slot < cap) {
+            if (slot < cap && level_base + slot < total_cap) {
                 const int pos = (y0 + r) * W + x;
-                cand[((size_t)lvl * cap + slot) * 2] = x | ((y0 + r) << 16);           // both fit 16 bits (levels up to 65535 x 65535)
-                cand[((size_t)lvl * cap + slot) * 2 + 1] = scores[L.score_offset + pos];
+                cand[((size_t)level_base + slot) * 2] = x | ((y0 + r) << 16);          // both fit 16 bits (levels up to 65535 x 65535)
+                cand[((size_t)level_base + slot) * 2 + 1] = scores[L.score_offset + pos];
             }
         }
 }
@@ -507,7 +513,7 @@ void launch_fast(const uint8_t* atlas, const OrbLevelSet& S, uint8_t* scores, in
     hipLaunchKernelGGL(k_fast_score, grid_score, dim3(256), 0, s, atlas, S, scores, threshold);
     hipLaunchKernelGGL(k_fast_nms_count, grid_nms, dim3(256), 0, s, scores, S, lay, edge, rowblk, keepbuf, keep_stride);
     hipLaunchKernelGGL(k_fast_nms_scan, dim3(S.n), dim3(1024), 0, s, lay, rowblk, counters);
-    hipLaunchKernelGGL(k_fast_nms_emit, grid_nms, dim3(256), 0, s, scores, S, lay, rowblk, keepbuf, keep_stride, cand, cap);
+    hipLaunchKernelGGL(k_fast_nms_emit, grid_nms, dim3(256), 0, s, scores, S, lay, rowblk, keepbuf, keep_stride, counters, cand, cap);
 }
 
 void launch_harris(const uint8_t* atlas, const OrbLevelSet& S, const int* kp, int n, float* resp, hipStream_t s) {

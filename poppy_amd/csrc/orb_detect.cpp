@@ -39,7 +39,7 @@ void retain_best(std::vector<T>& k, int n) {
 }  // namespace
 
 void OrbDetector::release() {
-    void* bufs[] = {d_img, d_atlas, d_blur, d_scores, d_counters, d_cand, d_kp, d_val, d_desc, d_nms};
+    void* bufs[] = {d_img, d_atlas, d_blur, d_scores, d_counters, d_kp, d_val, d_desc, d_nms};        // (d_cand lies inside d_counters' allocation)
     for (void* b : bufs) if (b) (void)hipFree(b);
     d_img = d_atlas = d_blur = d_scores = nullptr; d_counters = d_cand = d_kp = nullptr; d_val = nullptr; d_desc = nullptr; d_nms = nullptr;
     if (h_cand) (void)hipHostFree(h_cand);
@@ -74,13 +74,15 @@ hipError_t OrbDetector::prepare(int w, int h) {
     if ((e = hipMalloc((void**)&d_atlas, off)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_blur, off)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_scores, soff)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&d_counters, kOrbLevels * sizeof(int))) != hipSuccess) return e;
+    // counts (16 ints, 8 used) and, right behind them, the candidate lists of all levels one after the other: ONE copy of a guessed length fetches both
+    if ((e = hipMalloc((void**)&d_counters, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
+    d_cand = d_counters + kCandHeader;
+    last_total = 0;
     if ((e = hipMalloc(&d_nms, fast_nms_scratch_bytes(S))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&d_cand, (size_t)kOrbLevels * cap * 2 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_desc, (size_t)kp_cap * 32)) != hipSuccess) return e;
-    if ((e = hipHostMalloc((void**)&h_cand, ((size_t)kOrbLevels * cap * 2 + kOrbLevels) * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_cand, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
     if ((e = hipHostMalloc((void**)&h_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipHostMalloc((void**)&h_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
     W = w; H = h;
@@ -106,16 +108,25 @@ int OrbDetector::detect_begin(const uint8_t* gray, size_t stride, int w, int h, 
     ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, gray_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
     launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, d_nms, s);
-    int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
-    ORB_CHK(hipMemcpyAsync(h_counts, d_counters, kOrbLevels * sizeof(int), hipMemcpyDeviceToHost, s));
+    // The counts and the candidates come back in one copy: its length is a guess — a quarter more than the last image's candidates (pairs
+    // follow each other with similar images), 1/32 of the pixels the first time — and a second copy fetches the rest when the guess was short.
+    const size_t room = (size_t)kOrbLevels * cap;
+    const size_t guess = std::min(room, last_total ? last_total + last_total / 4 + 1024 : (size_t)w * h / 32 + 1024);
+    ORB_CHK(hipMemcpyAsync(h_cand, d_counters, (kCandHeader + guess * 2) * sizeof(int), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
     ms_fast_ = since();
+    const int* h_counts = h_cand;
+    size_t total = 0;
     for (int l = 0; l < kOrbLevels; ++l) {
         if (h_counts[l] > cap) { err = "FAST candidate buffer overflow"; return -1; }
-        if (h_counts[l])
-            ORB_CHK(hipMemcpyAsync(h_cand + (size_t)l * cap * 2, d_cand + (size_t)l * cap * 2, (size_t)h_counts[l] * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        level_base_[l] = total;
+        total += (size_t)h_counts[l];
     }
-    ORB_CHK(hipStreamSynchronize(s));
+    if (total > guess) {
+        ORB_CHK(hipMemcpyAsync(h_cand + kCandHeader + guess * 2, d_cand + guess * 2, (total - guess) * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        ORB_CHK(hipStreamSynchronize(s));
+    }
+    last_total = total;
     ms_cand_ = since();
     return 0;
 }
@@ -129,7 +140,7 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
     auto since = [&]() { return ms_cand_ + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_finish).count(); };
     const double ms_fast = ms_fast_, ms_cand = ms_cand_;
     double ms_sort = 0, ms_harris = 0;
-    int* h_counts = h_cand + (size_t)kOrbLevels * cap * 2;
+    const int* h_counts = h_cand;
 
     // per-level quota (orb.cpp:803-813)
     int quota[kOrbLevels];
@@ -148,7 +159,7 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
     std::vector<Cand> per_level[kOrbLevels];
     auto level_job = [&](int l) {
         const int n = h_counts[l], lw = S.lv[l].w;
-        const int* c = h_cand + (size_t)l * cap * 2;
+        const int* c = h_cand + kCandHeader + level_base_[l] * 2;
         // the candidates arrive in raster order = FAST's emission order (fast.cpp:271-290): the kernels compact them that way
         // retainBest on 8-byte keys (response, index): std::nth_element / std::partition make the same comparisons in the same order
         // whatever else an element carries, so the keys end up permuted exactly as the reference's KeyPoints would

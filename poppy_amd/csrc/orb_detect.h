@@ -40,12 +40,15 @@ public:
     std::vector<int> last_levels;
     size_t atlas_bytes = 0;
     int W = 0, H = 0, cap = 0, kp_cap = 0;
+    static constexpr int kCandHeader = 16;   // ints in front of the candidate lists (device and host): the levels' counts
+    size_t last_total = 0;                   // candidates of the last image (the next fetch's guess)
 
 private:
     hipError_t prepare(int w, int h);
     Worker helper_;                          // takes levels 1..7 of the first retainBest while the caller does level 0
     std::chrono::steady_clock::time_point t_begin_{};
     double ms_fast_ = 0, ms_cand_ = 0;
+    size_t level_base_[kOrbLevels] = {};     // where each level's list starts among the fetched candidates
 };
 
 }  // namespace poppy_hip
