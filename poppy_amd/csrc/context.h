@@ -91,6 +91,7 @@ struct poppy_hip_ctx {
     FramePlan plan;
     OrbDetector orb, orb_b;
     Worker setup_worker;                            // the second image's half of a pair set-up (chain, detector)
+    Team planners;                                  // the frame planners of multi-frame calls
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;
     hipEvent_t setup_ev = nullptr;                  // "the second image's medians are through" (pair set-up: gabor2 starts there)

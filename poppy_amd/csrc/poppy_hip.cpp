@@ -397,8 +397,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
             ready[j].store(1, std::memory_order_release);
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    c->planners.run(nthreads, worker);                            // persistent threads (worker.h): parked between calls
     int rc = POPPY_OK;
     const size_t row = (size_t)W * 3, frame_bytes = row * H;
     static const int ring_pref = getenv("POPPY_HIP_RING") ? std::max(1, atoi(getenv("POPPY_HIP_RING"))) : 3;
@@ -472,7 +471,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         while (written < n && rc == POPPY_OK) deliver(written);
     }
     next.store(n);                         // on an error: let the workers drain
-    for (auto& t : pool) t.join();
+    c->planners.wait();
     return rc;
 }
 
