@@ -111,7 +111,8 @@ int OrbDetector::detect_begin(const uint8_t* gray, size_t stride, int w, int h, 
     // The counts and the candidates come back in one copy: its length is a guess — a quarter more than the last image's candidates (pairs
     // follow each other with similar images), 1/32 of the pixels the first time — and a second copy fetches the rest when the guess was short.
     const size_t room = (size_t)kOrbLevels * cap;
-    const size_t guess = std::min(room, last_total ? last_total + last_total / 4 + 1024 : (size_t)w * h / 32 + 1024);
+    static const long forced_guess = getenv("POPPY_ORB_GUESS") ? atol(getenv("POPPY_ORB_GUESS")) : -1;       // tests: make the first copy short
+    const size_t guess = std::min(room, forced_guess >= 0 ? (size_t)forced_guess : last_total ? last_total + last_total / 4 + 1024 : (size_t)w * h / 32 + 1024);
     ORB_CHK(hipMemcpyAsync(h_cand, d_counters, (kCandHeader + guess * 2) * sizeof(int), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
     ms_fast_ = since();

@@ -10,7 +10,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0; t0 = time.time()
 for i in range(cases):
-    w = int(rng.integers(96, 260)); h = int(rng.integers(80, 200))
+    w = int(rng.integers(96, 420)); h = int(rng.integers(80, 200))       # (from 256 x 64 up, widths divisible by 4 take the fused accumulate kernel)
     if rng.random() < 0.5: w &= ~3
     s = int(rng.integers(1, 10000))
     if rng.random() < 0.5:
