@@ -80,7 +80,7 @@ def measured_traffic(kernel, w, h):
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
             return None, "no counter pass for this kernel / size in profiles/r03_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r03_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r03_x_pmc.md)"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r03_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r03_z_pmc.md)"
     except (OSError, ValueError, KeyError):
         return None, "profiles/r03_warp_pmc.json missing"
 
