@@ -30,7 +30,8 @@ def test_foreground_every_stage_vs_reference(ctx, case):
     assert np.array_equal(ctx.foreground(img), got["foreground"])      # the non-debug path is the same computation
 
 
-@pytest.mark.parametrize("w,h,seed", [(64, 48, 1), (97, 61, 2), (130, 23, 3), (33, 150, 4)])
+# (256 x 64 and wider in steps of 4: k_acc_gauss23_v4, three accumulate-and-blur steps per launch with reflected halos; the rest: k_acc_gauss23)
+@pytest.mark.parametrize("w,h,seed", [(64, 48, 1), (97, 61, 2), (130, 23, 3), (33, 150, 4), (256, 64, 5), (300, 70, 6), (388, 101, 7), (260, 65, 8), (258, 80, 9)])
 def test_foreground_ragged_vs_oracle(ctx, w, h, seed):
     import oracle_lib as O
     from poppy_amd import synth
@@ -41,7 +42,7 @@ def test_foreground_ragged_vs_oracle(ctx, w, h, seed):
         a, b = got[name], want[name]
         same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
         assert same.all(), f"{w}x{h} {name}: {np.count_nonzero(~same)} elements differ"
-    # the non-debug path accumulates and blurs the mask in one launch per step (k_acc_gauss23): same image at ragged sizes too
+    # the non-debug path accumulates and blurs the mask in fused launches (k_acc_gauss23 / k_acc_gauss23_v4): same image at ragged sizes too
     assert np.array_equal(ctx.foreground(img), want["foreground"])
 
 
