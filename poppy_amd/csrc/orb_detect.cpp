@@ -172,12 +172,15 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
         for (size_t j = 0; j < keys.size(); ++j) { const int p = c[2 * keys[j].i]; kl[j] = Cand{p & 0xffff, p >> 16, l, keys[j].response}; }
         (void)lw;
     };
-    {   // level 0 holds ~45 % of the candidates: the helper thread takes the other seven levels (a thread per level cost more in thread
-        // creation, ~50 us each, than the levels' work)
+    {   // level 0 holds ~45 % of the candidates, level 1 ~25 %: the caller takes level 0, one helper level 1, another levels 2-7 (a thread per
+        // level cost more in thread creation, ~50 us each, than the levels' work — these two are persistent)
         const bool split = h_counts[0] > 2000;
-        if (split) helper_.run([&]() { for (int l = 1; l < kOrbLevels; ++l) level_job(l); });
+        if (split) {
+            helper_.run([&]() { level_job(1); });
+            helper2_.run([&]() { for (int l = 2; l < kOrbLevels; ++l) level_job(l); });
+        }
         level_job(0);
-        if (split) helper_.wait();
+        if (split) { helper_.wait(); helper2_.wait(); }
         else for (int l = 1; l < kOrbLevels; ++l) level_job(l);
     }
     for (int l = 0; l < kOrbLevels; ++l) {

@@ -45,7 +45,7 @@ public:
 
 private:
     hipError_t prepare(int w, int h);
-    Worker helper_;                          // takes levels 1..7 of the first retainBest while the caller does level 0
+    Worker helper_, helper2_;                // take level 1 and levels 2..7 of the first retainBest while the caller does level 0
     std::chrono::steady_clock::time_point t_begin_{};
     double ms_fast_ = 0, ms_cand_ = 0;
     size_t level_base_[kOrbLevels] = {};     // where each level's list starts among the fetched candidates
