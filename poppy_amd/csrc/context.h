@@ -92,6 +92,7 @@ struct poppy_hip_ctx {
     OrbDetector orb, orb_b;
     Worker setup_worker;                            // the second image's half of a pair set-up (chain, detector)
     Team planners;                                  // the frame planners of multi-frame calls
+    double wait_ms[4] = {0, 0, 0, 0};               // host waits inside submit_frame since the context was made (POPPY_SEQ_TIMING prints the per-sequence share)
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;
     hipEvent_t setup_ev = nullptr;                  // "the second image's medians are through" (pair set-up: gabor2 starts there)

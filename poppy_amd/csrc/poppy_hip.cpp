@@ -414,12 +414,20 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     // the runtime's: a kernel of ours storing the frame into the mapped ring costs the frame kernels beside it far more (3.7k frames/s
     // against 5.8k, whatever its geometry: shader stores over PCIe hold up the other kernels' stores, profiles/r02_notes.md section 7).
     static const bool dev_wait = getenv("POPPY_HIP_DL_DEVWAIT") != nullptr;
+    static const bool seq_times = getenv("POPPY_SEQ_TIMING") != nullptr;      // where the calling thread's time goes, on stderr
+    using clk = std::chrono::steady_clock;
+    double ms_plan = 0, ms_done = 0, ms_deliver = 0, ms_submit = 0;
+    const auto t_seq = clk::now();
+    const double w0[4] = {c->wait_ms[0], c->wait_ms[1], c->wait_ms[2], c->wait_ms[3]};
+    auto lap = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     std::vector<int> slot_of(n, -1);
     int issued = 0;                                               // downloads queued so far (frames 0 .. issued-1)
     auto issue_download = [&](int k) -> bool {
         FrameSlot& f = c->slots[slot_of[k]];
         const int r = k % R;
+        const auto t0 = clk::now();
         hipError_t e = dev_wait ? hipStreamWaitEvent(c->dl_stream, f.done, 0) : hipEventSynchronize(f.done);
+        ms_done += lap(t0);
         if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * slot_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(f.downloaded, c->dl_stream);          // the slot's own: ring events are re-recorded every R frames
@@ -429,13 +437,17 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     };
     auto deliver = [&](int k) -> bool {
         const int rr = k % R;
+        const auto t0 = clk::now();
         if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; return false; }
+        ms_deliver += lap(t0);
         write(user, c->h_stage + (size_t)rr * slot_bytes, W, H, row);
         ++written;
         return true;
     };
     for (int j = 0; j < n && rc == POPPY_OK; ++j) {
+        const auto t_plan = clk::now();
         while (!ready[j].load(std::memory_order_acquire)) std::this_thread::yield();
+        ms_plan += lap(t_plan);
         if (rcs[j]) { rc = fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)"); break; }
         c->plan = std::move(plans[j]);
         if (chain) c->pts1 = src1[j];
@@ -452,7 +464,9 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
             }
             if (rc != POPPY_OK) break;
         }
+        const auto t_sub = clk::now();
         rc = submit_frame(c, mask[j], chain);
+        ms_submit += lap(t_sub);
         if (rc != POPPY_OK) break;
         slot_of[j] = c->last_slot;
         if (write) {
@@ -472,6 +486,10 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     }
     next.store(n);                         // on an error: let the workers drain
     c->planners.wait();
+    if (seq_times)
+        fprintf(stderr, "sequence of %d frames: %.2f ms; waiting for plans %.2f, submit_frame %.2f (of which waiting for: the slot's download %.2f, its pinned plan %.2f, "
+                "its last frame %.2f, upload + expansion %.2f), waiting for frames to finish %.2f, waiting for downloads %.2f ms\n",
+                n, lap(t_seq), ms_plan, ms_submit, c->wait_ms[0] - w0[0], c->wait_ms[1] - w0[1], c->wait_ms[2] - w0[2], c->wait_ms[3] - w0[3], ms_done, ms_deliver);
     return rc;
 }
 
@@ -553,9 +571,15 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     FrameSlot& f = c->slots[fi];
     // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
     // `out` before that copy has read it
-    if (f.dl_pending) { HIPCHK(c, hipEventSynchronize(f.downloaded)); f.dl_pending = false; }
+    auto waited = [&](double& acc, hipEvent_t ev) -> hipError_t {     // host wait for an event, accounted (POPPY_SEQ_TIMING)
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipEventSynchronize(ev);
+        acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return e;
+    };
+    if (f.dl_pending) { HIPCHK(c, waited(c->wait_ms[0], f.downloaded)); f.dl_pending = false; }
 
-    HIPCHK(c, hipEventSynchronize(f.uploaded));                    // the pinned copy is free again
+    HIPCHK(c, waited(c->wait_ms[1], f.uploaded));                  // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
     *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
     ((double*)(f.h_blob + kBlobMaskAB))[0] = 1.0 - mask;           // lbmask = clamp(alpha + m2 * beta), read by the level-0 blend kernels
@@ -631,7 +655,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     Timer tm(c, s);
     if (all_marks) tm.mark(nullptr);
     hipStream_t up = chained ? c->copy_stream : s;
-    if (chained) HIPCHK(c, hipEventSynchronize(f.done));          // the frame that last read this slot's device copy of the plan (2+ frames back)
+    if (chained) HIPCHK(c, waited(c->wait_ms[2], f.done));        // the frame that last read this slot's device copy of the plan (2+ frames back)
     launch_upload(f.h_blob_dev, f.d_blob, used, up);
     // the raster of the frame, as one id byte per pixel + the tiles' record slots: needs the plan only
     if (bin_warp) launch_tile_expand(d_rec, d_edges, d_outl, d_toff, d_ttri, f.tile_data, c->plan.tile_w, W, H, up);
@@ -640,7 +664,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     // 403 -> 411 us): the extra traffic beside the chain costs the chain's bandwidth-bound kernels more than the rider did.
     // profiles/r02_notes.md.)
     HIPCHK(c, hipEventRecord(f.uploaded, up));
-    if (chained) HIPCHK(c, hipEventSynchronize(f.uploaded));
+    if (chained) HIPCHK(c, waited(c->wait_ms[3], f.uploaded));
     // -- independent of the previous frame ---------------------------------------------------------------------
     // Id-map path only (debug mode, POPPY_HIP_IDMAP, oversized tile lists).  The id map is not cleared between frames: every
     // frame writes its ids above a tag that grows from frame to frame, and its warp kernel reads everything else as "no
