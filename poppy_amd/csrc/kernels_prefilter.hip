@@ -396,7 +396,10 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
     // less work.  Measured per launch, both images interleaved (us at 1024 / 768 / 512 / 384 sets): ksize 17: 75 / 78 / 81 / 104; 41: 142 / 148 /
     // 140 / 174; 65: 259 / 245 / 224 / 273; 89: 373 / 345 / 251 / 356.  POPPY_MED_SETS forces a number.
     static const int forced_sets = getenv("POPPY_MED_SETS") ? std::max(64, atoi(getenv("POPPY_MED_SETS"))) : 0;
-    const int seg_target = forced_sets ? forced_sets : (ksize >= 41 ? 512 : 1024);
+    // (Round 3: with the warm-up's coarse level summed instead of kept by atomics and cancelling updates skipped, 1024 sets are the fastest for
+    // every ksize — us per launch at 1024 / 512 sets, both images: ksize 41: 116 / 124, 65: 178 / 192, 89: 238 / 259, the set-up 3.69 / 3.91 ms; up to round
+    // 2 the long windows did better with 512.  tools/experiments/med_sets_sweep.sh.)
+    const int seg_target = forced_sets ? forced_sets : 1024;
     int segs = std::max(1, seg_target / col_blocks);
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
