@@ -369,13 +369,17 @@ template <int NDW, int NW>
 __global__ void __launch_bounds__(kMedLanes * NW) k_median_u8(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, uint8_t* __restrict__ padded_out,
                                                               int W, int H, int ksize, int rows_per_block) {
     __shared__ uint32_t hist[kMedWords * kMedLanes];
-    static_assert(NW == 1 || NW == 2 || NW == 4, "waves per histogram set");
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "waves per histogram set");
     static_assert(NW <= NDW, "every wave needs a dword of the row");
     const int wv = threadIdx.x >> 6;
     if (NW == 1 || wv == 0) median_body<NDW, NW, 0>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
     else if (NW == 2 || wv == 1) median_body<NDW, NW, 1 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
     else if (wv == 2) median_body<NDW, NW, 2 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
-    else median_body<NDW, NW, 3 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (NW == 4 || wv == 3) median_body<NDW, NW, 3 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (wv == 4) median_body<NDW, NW, 4 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (wv == 5) median_body<NDW, NW, 5 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else if (wv == 6) median_body<NDW, NW, 6 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
+    else median_body<NDW, NW, 7 % NW>(hist, srcp, dst, padded_out, W, H, ksize, rows_per_block);
 }
 void launch_pad_cols(const uint8_t* src, uint8_t* padded, int w, int h, hipStream_t s) {
     const int wp = w + 2 * kMedPad;
@@ -404,11 +408,11 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
     int rows = std::max((h + segs - 1) / segs, std::min(h, (ksize + 1) / 2));
     segs = (h + rows - 1) / rows;
     const int ndw = (ksize + 3) >> 2;
-    // waves per histogram set: POPPY_MED_WAVES forces 1 / 2 / 4 (experiments); default by row length
+    // waves per histogram set: POPPY_MED_WAVES forces 1 / 2 / 4 / 8 (experiments); default by row length
     static const int forced = getenv("POPPY_MED_WAVES") ? atoi(getenv("POPPY_MED_WAVES")) : 0;
-    const int nw = forced == 1 || ndw < 2 ? 1 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 4 ? kMedWavesLong : 1);
+    const int nw = forced == 1 || ndw < 2 ? 1 : forced == 8 && ndw >= 12 ? 8 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 13 ? 8 : ndw >= 4 ? kMedWavesLong : 1);      // eight waves from ksize 49 up: 8-10 % off the long windows' launches (round 3)
 #define MEDW(N, NWV) hipLaunchKernelGGL((k_median_u8<N, NWV>), dim3(col_blocks, segs), dim3(kMedLanes * NWV), 0, s, padded_tmp, dst, padded_next, w, h, ksize, rows)
-#define MED(N) case N: if (nw == 4) MEDW(N, (N >= 4 ? 4 : 1)); else if (nw == 2) MEDW(N, (N >= 2 ? 2 : 1)); else MEDW(N, 1); break;
+#define MED(N) case N: if (nw == 8) MEDW(N, (N >= 12 ? 8 : N >= 4 ? 4 : 1)); else if (nw == 4) MEDW(N, (N >= 4 ? 4 : 1)); else if (nw == 2) MEDW(N, (N >= 2 ? 2 : 1)); else MEDW(N, 1); break;
     switch (ndw) {
         MED(1) MED(2) MED(3) MED(4) MED(5) MED(6) MED(7) MED(8) MED(9) MED(10) MED(11) MED(12) MED(13) MED(14) MED(15) MED(16)
         MED(17) MED(18) MED(19) MED(20) MED(21) MED(22) MED(23)
