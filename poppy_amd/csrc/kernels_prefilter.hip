@@ -410,7 +410,7 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
     const int ndw = (ksize + 3) >> 2;
     // waves per histogram set: POPPY_MED_WAVES forces 1 / 2 / 4 / 8 (experiments); default by row length
     static const int forced = getenv("POPPY_MED_WAVES") ? atoi(getenv("POPPY_MED_WAVES")) : 0;
-    const int nw = forced == 1 || ndw < 2 ? 1 : forced == 8 && ndw >= 12 ? 8 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 13 ? 8 : ndw >= 4 ? kMedWavesLong : 1);      // eight waves from ksize 49 up: 8-10 % off the long windows' launches (round 3)
+    const int nw = forced == 1 || ndw < 2 ? 1 : forced == 8 && ndw >= 12 ? 8 : forced == 4 && ndw >= 4 ? 4 : forced == 2 ? 2 : (ndw >= 13 && ndw != 17 ? 8 : ndw >= 4 ? kMedWavesLong : 1);      // eight waves from ksize 49 up: 8-10 % off the long windows' launches (round 3); 17 dwords share out badly among eight (3 rounds): 191 against 184 us with four
 #define MEDW(N, NWV) hipLaunchKernelGGL((k_median_u8<N, NWV>), dim3(col_blocks, segs), dim3(kMedLanes * NWV), 0, s, padded_tmp, dst, padded_next, w, h, ksize, rows)
 #define MED(N) case N: if (nw == 8) MEDW(N, (N >= 12 ? 8 : N >= 4 ? 4 : 1)); else if (nw == 4) MEDW(N, (N >= 4 ? 4 : 1)); else if (nw == 2) MEDW(N, (N >= 2 ? 2 : 1)); else MEDW(N, 1); break;
     switch (ndw) {
