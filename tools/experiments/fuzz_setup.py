@@ -36,7 +36,9 @@ for i in range(cases):
         ok = (nf == st["nfeatures"] and p1.shape == st["points1"].shape and np.array_equal(p1.view(np.uint32), st["points1"].view(np.uint32))
               and np.array_equal(p2.view(np.uint32), st["points2"].view(np.uint32)) and np.array_equal(g.view(np.uint32), st["gabor2"].view(np.uint32)))
         if not ok:
-            print(f"case {i} {w}x{h} seed {s}: MISMATCH nfeatures {nf} vs {st['nfeatures']}, points {p1.shape} vs {st['p1'].shape}, "
-                  f"gabor2 differing {(g.view(np.uint32) != st['gabor2'].view(np.uint32)).sum() if g.shape == st['gabor2'].shape else 'shape'}")
+            print(f"case {i} {w}x{h} seed {s}: MISMATCH nfeatures {nf} vs {st['nfeatures']}, points {p1.shape} vs {st['points1'].shape}, "
+                  f"gabor2 differing {(g.view(np.uint32) != st['gabor2'].view(np.uint32)).sum() if g.shape == st['gabor2'].shape else 'shape'}"
+                  + (f" (largest difference {np.abs(g.view(np.int32).astype(np.int64) - st['gabor2'].view(np.int32).astype(np.int64)).max()} ulp; points equal: "
+                     f"{np.array_equal(p1, st['points1']) and np.array_equal(p2, st['points2'])})" if g.shape == st['gabor2'].shape and p1.shape == st['points1'].shape else ""))
     bad += 0 if ok else 1
 print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
