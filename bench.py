@@ -317,21 +317,25 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # POPPY_BENCH_SHARDED_SELFTEST=1 (with --gpus 1): the N > 1 code path on a world of ONE rank over RCCL — the library's communicator, the sharded
+    # set-up (all three roles on rank 0), the choice between the set-up's forms — for boxes with a single GPU.  Its numbers mean nothing.
+    selftest = world == 1 and os.environ.get("POPPY_BENCH_SHARDED_SELFTEST") == "1"
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     P = W * H
-    if world == 1:
+    if world == 1 and not selftest:
         out = bench_single(args, torch, capi, dev, local)
     else:
         out = bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, rehearsal)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or selftest:
         dist.destroy_process_group()
 
 
@@ -544,6 +548,42 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
 
     shard_setup = link.library and not args.no_shard_setup
 
+    def fence():
+        ctx.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    # The set-up has two forms — spread over ranks 0-2 through the library's communicator, or all of it on rank 0 followed by one broadcast of the
+    # pair state.  Which is faster depends on the links' collective latency; both are run before the warm-up, the point lists they leave on rank 0
+    # are compared, and the faster one (max over ranks) is the one the timed region uses.  Everything is agreed through reductions: no rank
+    # decides alone.
+    variants = None
+    if shard_setup:
+        def run_form(sharded, reps=3):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                if sharded:
+                    ctx.pair_begin_sharded(ta.data_ptr() if rank == 0 else None, tb.data_ptr() if rank == 0 else None, W, H, 0)
+                else:
+                    if rank == 0:
+                        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+                    link.broadcast(root=0)
+            fence()
+            return link.max_time(time.perf_counter() - t0) / reps
+        run_form(True, 1); run_form(False, 1)                          # first calls allocate
+        ms_sharded = run_form(True) * 1e3
+        pts_sharded = ctx.pair_points()
+        ms_rank0 = run_form(False) * 1e3
+        pts_rank0 = ctx.pair_points()
+        same = int(all(np.array_equal(x, y) for x, y in zip(pts_sharded, pts_rank0)))
+        flag = torch.tensor([same], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(int(flag.item()))
+        variants = {"sharded_ms": round(ms_sharded, 3), "rank0_then_broadcast_ms": round(ms_rank0, 3), "same_point_lists_on_every_rank": same}
+        shard_setup = same and ms_sharded <= ms_rank0
+        variants["used"] = "sharded" if shard_setup else "rank 0 + broadcast"
+
     def step():
         t0 = time.perf_counter()
         if shard_setup:          # the set-up itself spread over the ranks (image 1 on rank 0, image 2 on rank 1, the mask field on rank 2), one collective call
@@ -559,11 +599,6 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
         t3 = time.perf_counter()
         t_setup[0] += t1 - t0; t_bcast[0] += t2 - t1; t_frames[0] += t3 - t2
         return n
-
-    def fence():
-        ctx.sync(); torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -624,6 +659,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
                        "broadcast_bytes": link.nbytes},
             "roofline": roofline_of(ctx, warp_ms, warp_n, W, H),
             "frames_only_fps": round(args.steps * total / dt_f, 1),
+            "setup_forms": variants if variants is not None else {"used": "rank 0 + broadcast", "note": "the library's communicator is not in use (or --no-shard-setup): one form only"},
             "amdahl": {"rank0_setup_ms": round(t_setup[0] / k * 1e3, 3), "rank0_broadcast_ms": round(t_bcast[0] / k * 1e3, 3),
                        "rank0_frames_ms": round(t_frames[0] / k * 1e3, 3),
                        "note": "host-side wall time on rank 0 per step; the set-up and the broadcast are the serial part of the job: N GPUs cannot beat "

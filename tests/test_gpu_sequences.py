@@ -1,6 +1,8 @@
 """GPU parity on whole calls of poppy::morph through the C ABI (poppy_hip_morph), against frames of the REAL reference
 (tests/golden, captured from the compiled poppy::morph): every BASELINE.json single-GPU configuration end to end from the raw
 image pair, the phase == 0 / 1 short-circuits, --distance, the no-match fallback expression and shallow pyramids."""
+import os
+
 import numpy as np
 import pytest
 
@@ -325,3 +327,24 @@ def test_sharded_pair_setup_between_contexts_equals_the_one_gpu_setup(n_ctx, roo
     for c in ctxs:
         c.close()
     ref.close()
+
+
+def test_bench_sharded_path_on_a_world_of_one():
+    """bench.py's N > 1 code path (library communicator, the two forms of the pair set-up timed and compared, frame shares, cfg5 pairs) on a
+    world of ONE rank over RCCL (POPPY_BENCH_SHARDED_SELFTEST): the only way this box can execute it.  The forms must leave the same point lists."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POPPY_BENCH_SHARDED_SELFTEST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--total-frames", "64", "--pairs-per-gpu", "2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    f = d["setup_forms"]
+    assert f["same_point_lists_on_every_rank"] is True and f["used"] in ("sharded", "rank 0 + broadcast")
+    assert d["cfg5_pairs"]["value"] > 0
