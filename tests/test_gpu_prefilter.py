@@ -103,17 +103,19 @@ def test_pair_begin_with_radial_mask_vs_oracle():
 def test_setup_alternative_forms_stay_exact():
     """Switches of the pair set-up that are read once per process, each checked in a process of its own against the same fixtures and oracle:
     POPPY_ACC_STEPS (accumulate-and-blur steps per launch of k_acc_gauss23_v4: 1, 2, 4, 6; 0 = the byte-per-thread kernel; the default is 3),
+    POPPY_MED_WAVES / POPPY_MED_SETS (waves per histogram set and sets per launch of the medians),
     POPPY_ORB_GUESS=0 (the detector's first copy brings the counts only, every candidate comes with the second copy),
     POPPY_GABOR2_FIRST (gabor2 beside the first medians instead of behind the second image's)."""
     import subprocess
     import sys
     forms = [{"POPPY_ACC_STEPS": "0"}, {"POPPY_ACC_STEPS": "1"}, {"POPPY_ACC_STEPS": "2"}, {"POPPY_ACC_STEPS": "4"}, {"POPPY_ACC_STEPS": "6"},
+             {"POPPY_MED_WAVES": "1"}, {"POPPY_MED_WAVES": "2"}, {"POPPY_MED_WAVES": "8"}, {"POPPY_MED_SETS": "192"},
              {"POPPY_ORB_GUESS": "0"}, {"POPPY_GABOR2_FIRST": "1"}]
     if any(k in os.environ for f in forms for k in f):
         pytest.skip("a form is already forced in this process")
     here = os.path.dirname(os.path.abspath(__file__))
     for f in forms:
-        acc = "POPPY_ACC_STEPS" in f
+        acc = "POPPY_ACC_STEPS" in f or "POPPY_MED_WAVES" in f or "POPPY_MED_SETS" in f
         args = [os.path.join(here, "test_gpu_prefilter.py"), "-k", "every_stage or ragged or 1080p"] if acc else \
                [os.path.join(here, "test_gpu_astage.py"), os.path.join(here, "test_gpu_sequences.py"), "-k", "orb_detect or cfg1 or cfg2 or sharded"]
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + args, env=dict(os.environ, **f), capture_output=True, text=True, timeout=1200)
