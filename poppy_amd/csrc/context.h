@@ -27,7 +27,8 @@ using namespace poppy_hip;
 constexpr int kWarpStampStride = 7;
 
 struct FrameSlot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream the slot's independent (phase-mode) frames last ran on: its own, or one of the context's three
+    hipStream_t own_stream = nullptr;    // the slot's own (created at its first frame that stays in HBM)
     hipStream_t last_stream = nullptr;   // the stream the frame last rendered here ran on (the context's for chained frames, `stream` otherwise)
     hipEvent_t done = nullptr;           // end of the frame last rendered here
     hipEvent_t prepared = nullptr;       // id map and mask of the frame being rendered here are written
@@ -92,6 +93,7 @@ struct poppy_hip_ctx {
     OrbDetector orb, orb_b;
     Worker setup_worker;                            // the second image's half of a pair set-up (chain, detector)
     Team planners;                                  // the frame planners of multi-frame calls
+    bool writer_attached = false;                   // a multi-frame call with a writer is in progress
     double wait_ms[4] = {0, 0, 0, 0};               // host waits inside submit_frame since the context was made (POPPY_SEQ_TIMING prints the per-sequence share)
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;

@@ -104,14 +104,14 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)poppy_hip_comm_free(c);
-    for (FrameSlot& f : c->slots) if (f.stream) (void)hipStreamSynchronize(f.stream);
+    for (FrameSlot& f : c->slots) { if (f.stream) (void)hipStreamSynchronize(f.stream); if (f.own_stream) (void)hipStreamSynchronize(f.own_stream); }
     free_pair(c);
     for (FrameSlot& f : c->slots) {
         if (f.done) (void)hipEventDestroy(f.done);
         if (f.prepared) (void)hipEventDestroy(f.prepared);
         if (f.downloaded) (void)hipEventDestroy(f.downloaded);
         if (f.uploaded) (void)hipEventDestroy(f.uploaded);
-        if (f.stream) (void)hipStreamDestroy(f.stream);
+        if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
     }
     if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -278,7 +278,10 @@ int finish_pair_load(poppy_hip_ctx* c) {
 // every frame queued on this context has finished (independent frames run on their slots' streams)
 int drain_frames(poppy_hip_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (FrameSlot& f : c->slots) if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
+    for (FrameSlot& f : c->slots) {
+        if (f.stream) HIPCHK(c, hipStreamSynchronize(f.stream));
+        if (f.own_stream && f.own_stream != f.stream) HIPCHK(c, hipStreamSynchronize(f.own_stream));
+    }
     return POPPY_OK;
 }
 
@@ -405,6 +408,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     const size_t slot_bytes = (frame_bytes + 255) & ~(size_t)255;     // ring slots start on 256-byte boundaries
     int written = 0;
     if (write) rc = stage_host(c, slot_bytes * R);
+    c->writer_attached = write != nullptr;                        // (phase-mode frames pick their streams by it: submit_frame)
     // Frame hand-off.  The download of a frame runs on its own stream into a ring of R pinned buffers while the GPU renders the
     // frames behind it, and the writer gets frames in order, R - 1 downloads behind.  A copy whose start depends on an event of
     // ANOTHER stream is launched by the runtime's asynchronous-event thread when that event fires; with two contexts rendering and
@@ -484,6 +488,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         }
         while (written < n && rc == POPPY_OK) deliver(written);
     }
+    c->writer_attached = false;
     next.store(n);                         // on an error: let the workers drain
     c->planners.wait();
     if (seq_times)
@@ -640,7 +645,23 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     //                       hide the upload.  Whoever needs all frames finished drains the slot streams (drain_frames).
     static const bool no_graph = getenv("POPPY_HIP_NOGRAPH") != nullptr;
     const bool chained = chain || c->cur1_ready;
-    if (!f.stream && !chained) HIPCHK(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    if (!chained) {
+        // Independent frames: a stream per slot (created on first use) when the frames stay in HBM — four frames in flight, 10.7k frames/s at 1080p.
+        // With a writer attached the slots take the context's OWN three compute streams in turn — rendering, plan upload, the set-up's second —:
+        // a hardware queue is in order, the runtime spreads streams over four of them as they are created, and a fifth stream lands on the queue
+        // of the download stream, whose packets wait for every frame copy in front of that slot's kernels (one slot in four behind the copies:
+        // a 480-frame sequence with a writer took 80 ms; 74 with the slots on the three queues that carry no copies; without a writer three
+        // queues are slower than four, 8.7k frames/s).  POPPY_PHASE_OWN_STREAMS: a stream per slot in both cases, as before round 3.
+        static const bool own_streams = getenv("POPPY_PHASE_OWN_STREAMS") != nullptr;
+        if (c->writer_attached && !own_streams) {
+            if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            hipStream_t pick[3] = {c->stream, c->copy_stream, c->aux_stream};
+            f.stream = pick[fi % 3];
+        } else {
+            if (!f.own_stream) HIPCHK(c, hipStreamCreateWithFlags(&f.own_stream, hipStreamNonBlocking));
+            f.stream = f.own_stream;
+        }
+    }
     hipStream_t s = chained ? c->stream : f.stream;
     if (f.last_stream && f.last_stream != s) HIPCHK(c, hipEventSynchronize(f.done));     // the mode changed: settle the slot's last frame once, on the host
     f.last_stream = s;
