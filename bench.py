@@ -127,6 +127,14 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
                            "note": "vector issue cycles of the kernel's main path by the measured per-instruction costs of gfx950 (profiles/r03_notes.md section 1: "
                                    "2 cycles full rate, 4 half rate incl. every packed / perm / dot / cvt / min-max, 8 quarter) x waves / 1024 SIMDs / %.1f GHz: the time the "
                                    "arithmetic alone needs; the binding resource beside the HBM fraction" % clk}
+    try:        # the frame's other full-resolution kernels, from the same committed trace: duration, algorithmic bytes (DESIGN.md's kernel table), fraction of 8 TB/s
+        allf = json.load(open(os.path.join(ROOT, "profiles", "r03_warp_facts.json"))).get(f"{w}x{h}", {})
+        others = {v["kernel"]: {k2: v[k2] for k2 in ("what", "algo_bytes_per_px", "trace_avg_us", "achieved_GBps", "frac_of_8_TBps")}
+                  for k, v in allf.items() if k != "k_warp_bin" and "kernel" in v}
+        if others:
+            out["other_kernels_from_profiles"] = others
+    except (OSError, ValueError, KeyError):
+        pass
     out.update({"avg_launch_ms": round(per_launch_ms, 5), "launches_timed": warp_n,
                 "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), ctx.warp_counts())),
                 **dict(zip(("traffic", "traffic_source"), measured_traffic(ctx.warp_kernel_name(), w, h)))})

@@ -56,6 +56,19 @@ def main():
                 entry["trace_calls"] = row[1]
                 entry["trace_source"] = f"profiles/{tag}_trace.md (gpurun_out/{tag}_chain_{w})"
         facts[f"{w}x{h}"] = {"k_warp_bin": entry}
+        # the other full-resolution kernels of a frame: trace duration and the algorithmic bytes DESIGN.md's kernel table states for them
+        others = {"k_unsharp": ("unsharp_mask + convertTo (k_unsharp_tile below 4 Mpx, k_unsharp_stream above)", 15.0),
+                  "k_collapse_level<true>": ("level-0 collapse: three pyrUps + Laplacian + mix + add", 31.0),
+                  "k_pyrdown_level<true>": ("level-0 pyrDown of both warped sources and the mask", 17.0)}
+        if dbs:
+            for pat, (what, bpp) in others.items():
+                row = db.execute("select name, average, total_calls from top_kernels where name like ? order by total_duration desc", ("%" + pat + "%",)).fetchone()
+                if row:
+                    us = row[1] / 1e3 if row[1] > 1000 else row[1]
+                    nb = bpp * w * h
+                    facts[f"{w}x{h}"][pat] = {"what": what, "kernel": row[0].split("(")[0].replace("void ", "").replace("poppy_hip::", "").replace("(anonymous namespace)::", ""),
+                                             "algo_bytes_per_px": bpp, "algo_bytes_per_launch": int(nb), "trace_avg_us": round(us, 3), "trace_calls": row[2],
+                                             "achieved_GBps": round(nb / (us * 1e-6) / 1e9, 1), "frac_of_8_TBps": round(nb / (us * 1e-6) / 8e12, 4)}
         print(f"{w}x{h}: k_warp_bin<{tw}> {n} VALU instructions, {cyc} issue cycles per wave; trace {entry.get('trace_avg_us')} us")
     json.dump(facts, open(os.path.join(ROOT, "profiles", f"{rnd}_warp_facts.json"), "w"), indent=1)
 
