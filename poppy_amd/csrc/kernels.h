@@ -58,6 +58,8 @@ void launch_warp_fast(int32_t* triMap, const float* records, int n_records, cons
 // plan-upload stream); launch_warp_bin warps from those.  Same geometries as launch_warp_fast;
 // tile_w = warp_bin_tile_width(w, h) is also what the host bins with.
 int warp_bin_tile_width(int w, int h);
+void warp_bin_set_variant(int v);                                // see poppy_hip_set_warp_variant
+int warp_bin_variant();
 size_t warp_bin_entry_bytes();
 int warp_bin_max_tile_entries();                                   // a tile's list may not be longer (ids are bytes)
 size_t warp_bin_data_bytes(size_t n_tiles, size_t max_entries);    // size of the tile_data allocation

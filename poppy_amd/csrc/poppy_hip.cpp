@@ -164,6 +164,7 @@ int poppy_hip_time_last_warp(poppy_hip_ctx* c, int reps, float* ms_per_launch) {
     return POPPY_OK;
 }
 
+int poppy_hip_set_warp_variant(int variant) { warp_bin_set_variant(variant); return warp_bin_variant(); }
 int poppy_hip_mask_rider(poppy_hip_ctx* c) { return c ? (c->lazy_mask ? 0 : 1) : POPPY_E_ARG; }
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
