@@ -405,10 +405,17 @@ static void dump_astage() {
     Mat a = read_mat("img1"), b = read_mat("img2");
     vector<double> cfg = read_f64("cfg");   // nframes, phase, levels
     int nframes = (int)cfg[0]; double phase = cfg[1]; int levels = (int)cfg[2];
-    const bool autoAlign = cfg.size() > 3 && cfg[3] != 0;
-    poppy::init(false, nframes, 1.0, autoAlign, false, false, false, false, 30, levels, "FFV1", false, 8);
+    const int flags = cfg.size() > 3 ? (int)cfg[3] : 0;    // bit 0: Settings::enable_auto_align, bit 1: Settings::enable_radial_mask
+    const bool autoAlign = (flags & 1) != 0, radialMask = (flags & 2) != 0;
+    poppy::init(false, nframes, 1.0, autoAlign, radialMask, false, false, false, 30, levels, "FFV1", false, 8);
 
     Extractor ex(a, b);
+    if (radialMask) {                          // the mask Extractor::foreground multiplies in (src/extractor.cpp:178-185), by the same calls
+        Mat radial = Mat::ones(a.rows, a.cols, CV_32F), radialMaskFloat;
+        draw_radial_gradiant(radial);
+        radial.convertTo(radialMaskFloat, CV_32F, 1.0 / 255.0);
+        dump_mat("radialMask", radialMaskFloat);
+    }
     auto gf = ex.prepareFeatures();
     dump_mat("goodFeatures1", gf.first); dump_mat("goodFeatures2", gf.second);
 
@@ -486,7 +493,7 @@ static void dump_astage() {
     for (size_t i = 0; i < out.frames.size(); ++i) dump_mat("frame" + std::to_string(i), out.frames[i]);
     // extra single-frame phase-mode calls: init(numberOfFrames = 1), morph(phase = t)  (what one frame of the sharded job is)
     for (size_t k = 4; k < cfg.size(); ++k) {
-        poppy::init(false, 1, 1.0, autoAlign, false, false, false, false, 30, levels, "FFV1", false, 8);
+        poppy::init(false, 1, 1.0, autoAlign, radialMask, false, false, false, 30, levels, "FFV1", false, 8);
         Mat e1, e2; CollectWriter eo;
         poppy::morph(a, b, e1, e2, cfg[k], false, eo);
         if (eo.frames.size() != 1) { fprintf(stderr, "FATAL: phase call wrote %zu frames\n", eo.frames.size()); exit(2); }

@@ -75,6 +75,9 @@ ASTAGE = {
     "a_1920x1080_chain60": (1920, 1080, 60, -1.0, 64, 0, (0.25, 0.5)),    # configs[1] from the raw pair + two phase-mode frames
     "a_3840x2160_phase": (3840, 2160, 1, 0.5, 64, 0, ()),                 # configs[2]: one 4K phase-mode frame
     "a_256x256_phase01": (256, 256, 3, 0.0, 64, 0, (1.0,)),               # phase == 0 / == 1 short-circuits (src/poppy.hpp:54-70)
+    # round 4: Settings::enable_radial_mask (the CLI's --radial; src/extractor.cpp:178-197, src/draw.cpp:21-38): flags bit 1
+    "a_256x256_radial": (256, 256, 3, -1.0, 64, 2, ()),
+    "a_320x200_radial": (320, 200, 2, -1.0, 64, 2, (0.5,)),
     # (A featureless second image does NOT reach the linear-blend fallback of src/poppy.hpp:125-134: with empty point lists
     #  Matcher::find -> morph_distance -> cv::convexHull throws "total >= 0 && (depth == CV_32F || depth == CV_32S)" first —
     #  tried with the generator.  The fallback expression itself is pinned by x_dissolve_* below.)

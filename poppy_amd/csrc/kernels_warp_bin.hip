@@ -622,6 +622,114 @@ __global__ void __launch_bounds__(256, kWaves) k_warp_run(const float4* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_warp_probe: k_warp_bin with its phases fenced and stamped (s_memtime), for tools/experiments/warp_probe.py.  Per wave 8 values:
+// entry, after the barrier (ids + records there), after the map arithmetic, after the gathers are issued, after they have all
+// returned, after the blends + stores are issued, HW_ID, XCC_ID.  A measuring aid: same results, slightly different schedule
+// (the blends wait for ALL gathers here).
+__device__ __forceinline__ uint64_t stamp() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
+template <int kTileW>
+__global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_probe(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
+                                                  const int* __restrict__ tile_off,
+                                                  const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
+                                                  uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
+                                                  int tiles_x, uint32_t data_bytes, uint64_t* __restrict__ probe) {
+    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
+    __shared__ float4 s_rec[kSlots * 5];
+    const uint64_t ts0 = stamp();
+    const int tid = threadIdx.x;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x), n_tiles = (int)gridDim.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int row = tid / kTileTx, xg = tid % kTileTx;
+    const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
+    const bool active = x0 < W && y < H;
+    const uint32_t g = (uint32_t)y * (uint32_t)(W >> 2) + (uint32_t)(x0 >> 2);
+    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
+    const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
+    const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
+    const uint32_t ids = __builtin_amdgcn_raw_buffer_load_b32(rdata, (uint32_t)tile * kTileIdBytes + (uint32_t)tid * 4u, 0, 0);
+    if (tid < kSlots * 5)
+        s_rec[tid] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                         rdata, (uint32_t)n_tiles * kTileIdBytes + (uint32_t)tile * kTileSlotBytes + (uint32_t)tid * 16u, 0, 0));
+    __syncthreads();
+    uint32_t idsv = ids;
+    asm volatile("" : "+v"(idsv));
+    const uint64_t ts1 = stamp();
+    const float fy = (float)y;
+    FastTap t[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int li = (int)((idsv >> (8 * k)) & 255u);
+        if (li >= kSlots) li = 0;                                // (timing aid: crowded tiles are not what it is run on)
+        const float4 A = s_rec[li * 5], B = s_rec[li * 5 + 1], C = s_rec[li * 5 + 2], D = s_rec[li * 5 + 3], e4 = s_rec[li * 5 + 4];
+        warp_taps(A, B, C, D, f2{e4.x, e4.y}, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(t[0][k].off), "+v"(t[0][k].wt), "+v"(t[0][k].wb)); asm volatile("" : "+v"(t[1][k].off), "+v"(t[1][k].wt), "+v"(t[1][k].wb)); }
+    const uint64_t ts2 = stamp();
+    u3v ra[2][4], rb[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint32_t o4 = t[im][k].off & ~3u;
+            ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
+            rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
+        }
+    }
+    const uint64_t ts3 = stamp();
+    __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) (expcnt 7, lgkmcnt untouched: the stamp has drained it)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(ra[0][k]), "+v"(rb[0][k])); asm volatile("" : "+v"(ra[1][k]), "+v"(rb[1][k])); }
+    const uint64_t ts4 = stamp();
+    uint32_t p[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint32_t bs = t[im][k].off & 3u;
+            const u3v a3 = ra[im][k], b3 = rb[im][k];
+            const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
+            const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
+            p[im][k] = blend_fast(t[im][k], a, b);
+        }
+    }
+    const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
+    const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
+    constexpr uint32_t kNowhere = 0xfffffff0u;
+    __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, active ? g * 12u : kNowhere, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, active ? g * 12u : kNowhere, 0, 0);
+    const uint64_t ts5 = stamp();
+    if ((tid & 63) == 0) {
+        uint64_t* o = probe + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4; o[5] = ts5;
+        o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          // HW_REG_HW_ID
+        o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));         // HW_REG_XCC_ID
+    }
+}
+
+// relaunches a frame's warp as k_warp_probe; `probe` takes 4 * 8 values per tile (device memory)
+size_t warp_probe_values(int tile_w, int w, int h) {
+    const int tiles_x = (w + tile_w - 1) / tile_w, tiles_y = (h + 1024 / tile_w - 1) / (1024 / tile_w);
+    return (size_t)tiles_x * tiles_y * 32;
+}
+void launch_warp_probe(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
+                       const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2, int w, int h, uint64_t* probe, hipStream_t s) {
+    const uint32_t bytes = (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u);
+#define LQ(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
+    hipLaunchKernelGGL(k_warp_probe<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, (const float4*)records, (const uint8_t*)tile_data, tile_off, \
+                       c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, tiles_x, bytes, probe); }
+    if (tile_w == 128) LQ(128) else LQ(64)
+#undef LQ
+}
+
 int warp_bin_tile_width(int w, int h) {
     static const int forced = getenv("POPPY_TILE_W") ? atoi(getenv("POPPY_TILE_W")) : 0;
     if (forced == 64 || forced == 128) return forced;
