@@ -372,15 +372,6 @@ int poppy_hip_warp_counts(poppy_hip_ctx* ctx, unsigned long long* fused, unsigne
  * times back to back with nothing else running; *ms_per_launch = time between two events around the batch / reps.  POPPY_E_STATE when
  * the last frame did not take that kernel. */
 int poppy_hip_time_last_warp(poppy_hip_ctx* ctx, int reps, float* ms_per_launch);
-/* Which form of the fused create_map + remap kernel (src/algo.cpp:146-176,230-238) the frames take, process-wide: 0 = one workgroup per
- * tile (k_warp_bin), v > 0 = the persistent, software-pipelined form (k_warp_pipe): bits 0-3 pixels per pipeline unit (1, 2, 4), bits
- * 4-7 resident workgroups per CU; v < 0 = back to the default (POPPY_WARP_VARIANT, else the library's choice).  Every form returns the
- * same bytes (tests/test_gpu_fused_warp.py runs the frame tests under each); returns the variant now in force. */
-int poppy_hip_set_warp_variant(int variant);
-/* Measurement aid: the last frame's fused warp kernel once more with its phases fenced and stamped (s_memtime): out takes 32 values per tile
- * (4 waves x {entry, ids + records there, map arithmetic done, gathers issued, gathers back, blends + stores issued, HW_ID, XCC_ID});
- * *n_values = values written, *ms = that launch's duration.  tools/experiments/warp_probe.py reads it. */
-int poppy_hip_warp_probe(poppy_hip_ctx* ctx, unsigned long long* out, size_t capacity, size_t* n_values, float* ms);
 /* 1 when the warp kernel of this pair also writes the blend mask (lbmask = clamp((1 - mr) - m2 * mr), src/algo.cpp:262-263) beside the
  * two warped images, 0 when the level-0 blend kernels compute it from the pair's m2 field on the values they load (the normal case:
  * 8 B/px per frame less; POPPY_HIP_LBMASK_RIDER=1 or a geometry the wide blend kernels do not take select the former).           */

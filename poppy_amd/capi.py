@@ -31,7 +31,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_set_warp_variant", "poppy_hip_warp_probe", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -109,8 +109,6 @@ def lib():
         L.poppy_hip_warp_counts.argtypes = [vp, vp, vp, vp]
         L.poppy_hip_mask_rider.argtypes = [vp]
         L.poppy_hip_time_last_warp.argtypes = [vp, i, vp]
-        L.poppy_hip_set_warp_variant.argtypes = [i]
-        L.poppy_hip_warp_probe.argtypes = [vp, vp, sz, vp, vp]
         L.poppy_hip_pool_mask_rider.argtypes = [vp]
         L.poppy_hip_pool_create.restype = C.c_void_p
         L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
@@ -617,19 +615,6 @@ class Context:
         ms = C.c_float(0)
         self._chk(lib().poppy_hip_time_last_warp(self.h, int(reps), C.byref(ms)), "time_last_warp")
         return ms.value
-
-    def warp_probe(self):
-        """(stamps[tiles * 4, 8] uint64, launch ms) of the last frame's fused warp relaunched as the stamped probe kernel."""
-        cap = ((self.w + 63) // 64) * ((self.h_ + 7) // 8) * 32 + 64
-        out = np.zeros(cap, np.uint64)
-        n = C.c_size_t(0); ms = C.c_float(0)
-        self._chk(lib().poppy_hip_warp_probe(self.h, _p(out), cap, C.byref(n), C.byref(ms)), "warp_probe")
-        return out[:n.value].reshape(-1, 8), ms.value
-
-    @staticmethod
-    def set_warp_variant(v):
-        """Process-wide choice of the fused warp kernel's form (0 = a workgroup per tile, 0x<waves><unit> = persistent pipelined, -1 = default)."""
-        return lib().poppy_hip_set_warp_variant(int(v))
 
     def set_gabor_direct(self, on=True):
         """Gabor banks as direct double sums (True) or tiled FFTs (False, the default)."""

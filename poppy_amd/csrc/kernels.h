@@ -58,11 +58,6 @@ void launch_warp_fast(int32_t* triMap, const float* records, int n_records, cons
 // plan-upload stream); launch_warp_bin warps from those.  Same geometries as launch_warp_fast;
 // tile_w = warp_bin_tile_width(w, h) is also what the host bins with.
 int warp_bin_tile_width(int w, int h);
-size_t warp_probe_values(int tile_w, int w, int h);               // measuring aid: see k_warp_probe
-void launch_warp_probe(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
-                       const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2, int w, int h, uint64_t* probe, hipStream_t s);
-void warp_bin_set_variant(int v);                                // see poppy_hip_set_warp_variant
-int warp_bin_variant();
 size_t warp_bin_entry_bytes();
 int warp_bin_max_tile_entries();                                   // a tile's list may not be longer (ids are bytes)
 size_t warp_bin_data_bytes(size_t n_tiles, size_t max_entries);    // size of the tile_data allocation

@@ -23,6 +23,11 @@
 // the warp kernel's dependent memory round trips drop from three (ids -> records -> footprints) to two.  (Round 2 handed the row
 // masks themselves to the warp kernel — 208 bytes per entry behind a tile_off lookup — and resolved painter's order there: timing
 // builds showed that kernel's front end, not its arithmetic, to be what its duration followed: profiles/r03_notes.md.)
+// Round 4 built the persistent forms of k_warp_bin the round-3 review asked for — gathers software-pipelined inside the wave (1, 2 or 4
+// pixels per stage, 3-6 waves per SIMD), and an 8-wave form with the next tile's ids and record slots prefetched by LDS-DMA —, all bit-exact,
+// all SLOWER (4K: 50-57 us against 45-46), and measured why: the kernel's arithmetic ALONE, on register data with 8 waves per SIMD and no
+// memory instruction, takes 0.99 us per tile-wave per SIMD = 31 us at 4K (tools/micro/warp_alu.hip).  The kernels are in the history
+// (commits 17fafdb, a82110b), the measurements in profiles/r04_notes.md.
 #include "warp_fast_device.h"
 #ifndef POPPY_WARP_WAVES
 #define POPPY_WARP_WAVES 8      // waves per SIMD the register allocation must leave room for (64 VGPRs: the 2025 workgroups of a 1080p frame are then ONE round)
@@ -249,487 +254,6 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_warp_pipe (round 4): the same arithmetic as k_warp_bin, PERSISTENT and software-pipelined.  k_warp_bin's duration is a
-// workgroup's lifetime paid once per round of resident workgroups (profiles/r03_notes.md section 3): launch, a round trip for
-// ids + records, a barrier, ~1100 issue cycles of map arithmetic, the gathers' round trip, ~800 cycles of blends, stores — with every
-// round trip covered only by OTHER waves.  Here a grid of 256 CUs x kPipeWaves workgroups stays resident and every WAVE walks an
-// XCD-local run of tiles on its own (wave w of a workgroup takes rows w of every tile of the workgroup's run; no barrier anywhere:
-// each wave keeps a private, double-buffered copy of the tile's record slots in LDS):
-//     ids + record slots of tile i + 2      in flight (only the slots the tile uses: its entry count comes from tile_off by scalar
-//                                           loads, so the 2.5 B/px of slot reads drop to ~0.4)
-//     map arithmetic of unit u + 1          computed WHILE the footprint gathers of unit u are in flight (a unit = kUnit of a thread's
-//                                           four pixels; the unit after a tile's last is the next tile's first)
-//     blends + stores of unit u             behind them
-// so a wave has ~1000 issue cycles of its own arithmetic behind every memory round trip, whatever the other waves do.
-// Results are those of k_warp_bin bit for bit (same device functions); the border redo and the overflow records are unchanged.
-constexpr int kWarpVariantDefault = 0;
-
-struct PipeTap { uint32_t wt, wb, off; };
-
-template <int kTileW, int kUnit, int kWaves>
-__global__ void __launch_bounds__(256, kWaves) k_warp_pipe(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
-                                                           const int* __restrict__ tile_off,
-                                                           const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                                           uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
-                                                           int tiles_x, int n_tiles, uint32_t data_bytes) {
-    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4, kNU = 4 / kUnit;
-    constexpr int kStage = 2;                                    // float4 per lane staged ahead: the first 25 slots; more (rare) are fetched at use
-    __shared__ float4 s_rec[4][2][kSlots * 5];                   // [wave][buffer]: 20 KB per workgroup
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row = tid / kTileTx, xg = tid % kTileTx;
-    // this workgroup's run: XCD x = blockIdx % 8 owns a contiguous range of tiles, its workgroups stride through it side by side
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nwx = (int)gridDim.x >> 3;
-    const int per = n_tiles >> 3, rem = n_tiles & 7;
-    const int base = x * per + (x < rem ? x : rem), cnt = per + (x < rem ? 1 : 0);
-    if (j >= cnt) return;
-    const int n_mine = (cnt - j + nwx - 1) / nwx;
-    const int step_q = nwx / tiles_x, step_r = nwx - step_q * tiles_x;
-
-    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
-    const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
-    const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
-    const uint32_t slot_base = (uint32_t)n_tiles * kTileIdBytes, over_base = (uint32_t)n_tiles * (kTileIdBytes + kTileSlotBytes);
-
-    // float4s of tile t's slots that are in use (slot 0 = identity, slot e + 1 = entry e), at most all 32 slots; 0 = no such tile
-    auto used4 = [&](int t, bool exists) -> int {
-        if (!exists) return 0;
-        const int nb = tile_off[t + 1] - tile_off[t];
-        return (nb + 1 < kSlots ? nb + 1 : kSlots) * 5;
-    };
-    constexpr uint32_t kNowhere = 0xfffffff0u;                  // beyond every descriptor's range: such a load moves nothing and returns 0, such a store is dropped
-    auto load_ids = [&](int t, bool exists) -> uint32_t {
-        return __builtin_amdgcn_raw_buffer_load_b32(rdata, exists ? (uint32_t)t * kTileIdBytes + (uint32_t)tid * 4u : kNowhere, 0, 0);
-    };
-    // no branch around a load: lanes beyond the tile's used slots ask for an address outside the descriptor
-    auto load_stage = [&](int t, int n4, float4 (&st)[kStage]) {
-#pragma unroll
-        for (int s = 0; s < kStage; ++s)
-            st[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rdata, lane + 64 * s < n4 ? slot_base + (uint32_t)t * kTileSlotBytes + (uint32_t)(lane + 64 * s) * 16u : kNowhere, 0, 0));
-    };
-    auto put_stage = [&](int t, int n4, const float4 (&st)[kStage], float4* dst) {
-#pragma unroll
-        for (int s = 0; s < kStage; ++s) dst[lane + 64 * s] = st[s];
-        if (n4 > 64 * kStage && lane < kSlots * 5 - 64 * kStage)  // slots 25..31 of a crowded tile: fetched now (wave-uniform branch, rare)
-            dst[lane + 64 * kStage] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                          rdata, slot_base + (uint32_t)t * kTileSlotBytes + (uint32_t)(lane + 64 * kStage) * 16u, 0, 0));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    // map arithmetic of unit u of a tile: pixels 4 xg + u kUnit .. of row `y`.  A pixel of an entry beyond the 32 slots (a tile crossed by more
-    // than 31 triangles) is mapped by the identity here and marked for the byte-wise redo, which reads its record from the overflow area.
-    auto unit_taps = [&](uint32_t ids, const float4* sr, int x0, int y, int u, PipeTap (&tp)[2][kUnit], uint32_t& edges) {
-        const float fy = (float)y;
-#pragma unroll
-        for (int q = 0; q < kUnit; ++q) {
-            const int k = u * kUnit + q;
-            int li = (int)((ids >> (8 * k)) & 255u);
-#ifndef POPPY_WARP_COUNT_MAIN
-            if (li >= kSlots) { li = 0; edges |= 17u << k; }
-#endif
-            const float4 A = sr[li * 5], B = sr[li * 5 + 1], C = sr[li * 5 + 2], D = sr[li * 5 + 3], e4 = sr[li * 5 + 4];
-            FastTap a, b;
-            warp_taps(A, B, C, D, f2{e4.x, e4.y}, (float)(x0 + k), fy, W, H, a, b);
-            tp[0][q] = PipeTap{a.wt, a.wb, a.off}; tp[1][q] = PipeTap{b.wt, b.wb, b.off};
-            edges |= (a.inside ? 0u : 1u << k) | (b.inside ? 0u : 16u << k);
-        }
-    };
-    auto unit_gather = [&](const PipeTap (&tp)[2][kUnit], u3v (&ra)[2][kUnit], u3v (&rb)[2][kUnit]) {
-#pragma unroll
-        for (int q = 0; q < kUnit; ++q) {
-#pragma unroll
-            for (int im = 0; im < 2; ++im) {
-                const uint32_t o4 = tp[im][q].off & ~3u;
-                ra[im][q] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
-                rb[im][q] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
-            }
-        }
-    };
-    auto unit_blend = [&](const PipeTap (&tp)[2][kUnit], const u3v (&ra)[2][kUnit], const u3v (&rb)[2][kUnit], int u, uint32_t (&p)[2][4]) {
-#pragma unroll
-        for (int q = 0; q < kUnit; ++q) {
-#pragma unroll
-            for (int im = 0; im < 2; ++im) {
-                const uint32_t bs = tp[im][q].off & 3u;
-                const u3v a3 = ra[im][q], b3 = rb[im][q];
-                const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
-                const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
-                FastTap ft; ft.wt = tp[im][q].wt; ft.wb = tp[im][q].wb; ft.off = 0; ft.inside = true;
-                p[im][u * kUnit + q] = blend_fast(ft, a, b);
-            }
-        }
-    };
-
-    float4* const buf0 = s_rec[wv][0];
-    float4* const buf1 = s_rec[wv][1];
-
-    // ---- prologue: tile 0 staged and mapped, tile 1 on its way ------------------------------------------------------------
-    int t_cur = base + j, ty_c = t_cur / tiles_x, tx_c = t_cur - ty_c * tiles_x;
-    int t_nxt = t_cur + nwx, ty_n = ty_c + step_q, tx_n = tx_c + step_r;
-    if (tx_n >= tiles_x) { tx_n -= tiles_x; ++ty_n; }
-    int t_nn = t_nxt + nwx;
-    uint32_t ids_c = load_ids(t_cur, true);
-    float4 st[kStage];
-    int n4 = used4(t_cur, true);
-    load_stage(t_cur, n4, st);
-    put_stage(t_cur, n4, st, buf0);
-    uint32_t ids_n = load_ids(t_nxt, n_mine > 1);
-    n4 = used4(t_nxt, n_mine > 1);
-    load_stage(t_nxt, n4, st);
-    int x0_c = tx_c * kTileW + xg * 4, y_c = ty_c * kTileH + row;
-    PipeTap tp[2][kUnit];
-    uint32_t edges_c = 0;
-    unit_taps(ids_c, buf0, x0_c, y_c, 0, tp, edges_c);
-
-    for (int i = 0; i < n_mine; ++i) {
-        const bool has_next = i + 1 < n_mine, has_nn = i + 2 < n_mine;
-        float4* const sr_c = (i & 1) ? buf1 : buf0;
-        float4* const sr_n = (i & 1) ? buf0 : buf1;
-        const int x0_n = tx_n * kTileW + xg * 4, y_n = ty_n * kTileH + row;
-        uint32_t edges_n = 0, p[2][4];
-        uint32_t ids_nn = 0;
-#pragma unroll
-        for (int u = 0; u < kNU; ++u) {
-            u3v ra[2][kUnit], rb[2][kUnit];
-            unit_gather(tp, ra, rb);
-            __builtin_amdgcn_sched_barrier(0);                   // the scheduler would gather every unit's loads at the top and sink every blend to the bottom (spilling the footprints)
-            PipeTap tq[2][kUnit];
-            if (u == 0) {                                        // tile i + 1's records into the other buffer; tile i + 2 requested
-                put_stage(t_nxt, n4, st, sr_n);
-                ids_nn = load_ids(t_nn, has_nn);
-                n4 = used4(t_nn, has_nn);
-                load_stage(t_nn, n4, st);
-            }
-            if (u + 1 < kNU) unit_taps(ids_c, sr_c, x0_c, y_c, u + 1, tq, edges_c);
-            else if (has_next) unit_taps(ids_n, sr_n, x0_n, y_n, 0, tq, edges_n);
-            __builtin_amdgcn_sched_barrier(0);
-            unit_blend(tp, ra, rb, u, p);
-            // ... and the optimiser sinks the blends (pure arithmetic) to their use at the tile's end: an empty asm pins each result here
-#pragma unroll
-            for (int q = 0; q < kUnit; ++q) { asm volatile("" : "+v"(p[0][u * kUnit + q])); asm volatile("" : "+v"(p[1][u * kUnit + q])); }
-            __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < kNU || has_next) {
-#pragma unroll
-                for (int q = 0; q < kUnit; ++q) { tp[0][q] = tq[0][q]; tp[1][q] = tq[1][q]; }
-            }
-        }
-        // ---- tile i leaves --------------------------------------------------------------------------------------------
-        const bool active = x0_c < W && y_c < H;
-        const uint32_t g = (uint32_t)y_c * (uint32_t)(W >> 2) + (uint32_t)(x0_c >> 2);
-        const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
-        const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
-        __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, active ? g * 12u : kNowhere, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, active ? g * 12u : kNowhere, 0, 0);
-#ifndef POPPY_WARP_COUNT_MAIN
-        if (!active) edges_c = 0;
-        if (__builtin_amdgcn_ballot_w64(edges_c != 0) != 0 && edges_c != 0) {
-            for (int e = 0; e < 8; ++e) {
-                if (!((edges_c >> e) & 1u)) continue;
-                const int k = e & 3, im = e >> 2;
-                const unsigned en = (ids_c >> (8 * k)) & 255u;
-                const float* rp = en == 0 ? (const float*)rec
-                                : en < (unsigned)kSlots ? (const float*)(tile_data + (size_t)slot_base + (size_t)t_cur * kTileSlotBytes + (size_t)en * kEntryBytes)
-                                : (const float*)(tile_data + (size_t)over_base + (size_t)(tile_off[t_cur] + (int)en - 1) * kEntryBytes);
-                const uint32_t v = slow_pixel(rp, im, im ? c2 : c1, W, H, x0_c + k, y_c);
-                uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y_c * W + x0_c + k) * 3;
-                dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
-            }
-        }
-#endif
-        // ---- rotate ---------------------------------------------------------------------------------------------------
-        t_cur = t_nxt; tx_c = tx_n; ty_c = ty_n; x0_c = x0_n; y_c = y_n; ids_c = ids_n; edges_c = edges_n;
-        t_nxt = t_nn; ids_n = ids_nn;
-        tx_n += step_r; ty_n += step_q;
-        if (tx_n >= tiles_x) { tx_n -= tiles_x; ++ty_n; }
-        t_nn = t_nxt + nwx;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_warp_run (round 4): what the measurements of k_warp_pipe left standing.  Pipelining the gathers inside a wave costs registers, hence
-// waves per SIMD, and on this part a SIMD needs its 8 waves (a wave alone issues one instruction per ~5 cycles whatever its dependencies:
-// profiles/r03_notes.md section 1) — every k_warp_pipe variant was slower than k_warp_bin.  This kernel keeps k_warp_bin's instruction stream
-// and its 8 waves per SIMD and removes only the per-tile fixed part: a resident grid, every WAVE walking its own run of tiles, the next
-// tile's ids (one VGPR) and its record slots requested while the current tile is being warped — the slots by LDS-DMA (buffer_load ... lds:
-// no staging registers), only the slots the tile uses, into the wave's other LDS buffer.  No barrier, no workgroup launch per tile, no
-// exposed first round trip.
-
-// The byte-wise redo of one pixel (slow_pixel) through buffer descriptors only: the persistent kernels keep no raw pointer alive across
-// their loop (the scalar registers are what limits them to 8 waves per SIMD).  rec_off = byte offset of the pixel's record in rdata.
-__device__ __forceinline__ uint32_t slow_pixel_rsrc(__amdgpu_buffer_rsrc_t rdata, uint32_t rec_off, int src, __amdgpu_buffer_rsrc_t img, int W, int H, int x, int y) {
-    auto rf = [&](int i) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdata, rec_off + (uint32_t)i * 4u, 0, 0)); };
-    float h[9];
-    if (src == 0) { h[0] = rf(0); h[3] = rf(1); h[1] = rf(2); h[4] = rf(3); h[2] = rf(4); h[5] = rf(5); }
-    else          { h[0] = rf(6); h[3] = rf(7); h[1] = rf(8); h[4] = rf(9); h[2] = rf(10); h[5] = rf(11); }
-    h[6] = rf(12 + src); h[7] = rf(14 + src); h[8] = rf(16 + src);
-    float mx, my;
-    map_point(h, x, y, mx, my);
-    const int sx = cv_round_x86(mx * 32.f), sy = cv_round_x86(my * 32.f);
-    int ix = sx >> 5, iy = sy >> 5;
-    ix = max(-32768, min(32767, ix)); iy = max(-32768, min(32767, iy));
-    int w00, w01, w10, w11;
-    bilinear_weights(sx & 31, sy & 31, w00, w01, w10, w11);
-    const bool x0 = (unsigned)ix < (unsigned)W, x1 = (unsigned)(ix + 1) < (unsigned)W;
-    const bool y0 = (unsigned)iy < (unsigned)H, y1 = (unsigned)(iy + 1) < (unsigned)H;
-    const uint32_t o00 = (uint32_t)(iy * W + ix) * 3u, o10 = o00 + (uint32_t)W * 3u;
-    auto px = [&](bool ok, uint32_t o) -> int { return ok ? (int)__builtin_amdgcn_raw_buffer_load_b8(img, o, 0, 0) : 0; };
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int acc = __mul24(px(x0 && y0, o00 + k), w00) + __mul24(px(x1 && y0, o00 + 3 + k), w01) +
-                        __mul24(px(x0 && y1, o10 + k), w10) + __mul24(px(x1 && y1, o10 + 3 + k), w11);
-        out |= (uint32_t)sat_u8((acc + (1 << 14)) >> 15) << (8 * k);
-    }
-    return out;
-}
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-// lanes [0, n) of this wave copy 16 bytes each from rsrc + voff to LDS at lds_dst + 16 * lane (wave-uniform lds_dst); invisible to the
-// compiler's vmcnt bookkeeping: issue it BEFORE a load the compiler waits for (buffer loads return in order)
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
-}
-
-template <int kTileW, int kWaves>
-__global__ void __launch_bounds__(256, kWaves) k_warp_run(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
-                                                     const int* __restrict__ tile_off,
-                                                     const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                                     uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
-                                                     int tiles_x, int n_tiles, uint32_t data_bytes) {
-    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
-    __shared__ __attribute__((aligned(16))) float4 s_rec[4][2][kSlots * 5];   // [wave][buffer]: 20 KB per workgroup, 8 workgroups per CU
-
-    const int tid0 = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nwx = (int)gridDim.x >> 3;
-    const int per = n_tiles >> 3, rem = n_tiles & 7;
-    const int base = x * per + (x < rem ? x : rem), cnt = per + (x < rem ? 1 : 0);
-    if (j >= cnt) return;
-    const int n_mine = (cnt - j + nwx - 1) / nwx;
-    const int step_q = nwx / tiles_x, step_r = nwx - step_q * tiles_x;
-
-    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
-    const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
-    const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
-    const uint32_t slot_base = (uint32_t)n_tiles * kTileIdBytes, over_base = (uint32_t)n_tiles * (kTileIdBytes + kTileSlotBytes);
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_ptr)&s_rec[wv][0][0]);
-    constexpr uint32_t kBufBytes = kSlots * 5 * 16;
-
-    // the slots tile t uses (slot 0 = identity, slot e + 1 = entry e), by LDS-DMA into buffer b of this wave
-    // (the lane-derived offsets are recomputed from the thread number wherever they are used — `tid` is made opaque once per tile —: hoisted out of
-    // the loop they were spilled to scratch and reloaded every tile, this kernel has no register to spare at 8 waves per SIMD)
-    auto request_slots = [&](int t, int b, int tid) {
-        const int lane = tid & 63;
-        const int nb = tile_off[t + 1] - tile_off[t];
-        const int n4 = (nb + 1 < kSlots ? nb + 1 : kSlots) * 5;
-        const uint32_t src = slot_base + (uint32_t)t * kTileSlotBytes + (uint32_t)lane * 16u, dst = lds0 + (uint32_t)b * kBufBytes;
-        if (lane < n4) lds_dma16(rdata, src, dst);
-        if (n4 > 64) {
-            if (lane + 64 < n4) lds_dma16(rdata, src + 1024u, dst + 1024u);
-            if (n4 > 128 && lane + 128 < n4) lds_dma16(rdata, src + 2048u, dst + 2048u);
-        }
-    };
-    auto load_ids = [&](int t, int tid) -> uint32_t {
-        return __builtin_amdgcn_raw_buffer_load_b32(rdata, (uint32_t)t * kTileIdBytes + (uint32_t)tid * 4u, 0, 0);
-    };
-
-    int t_cur = base + j, ty = t_cur / tiles_x, tx = t_cur - ty * tiles_x;
-    request_slots(t_cur, 0, tid0);
-    uint32_t ids = load_ids(t_cur, tid0);
-    for (int i = 0; i < n_mine; ++i) {
-        int zero = 0;
-        asm volatile("" : "+s"(zero));
-        const int tid = tid0 + zero, row = tid / kTileTx, xg = tid % kTileTx;
-        const float4* const sr = s_rec[wv][i & 1];
-        const int t_nxt = t_cur + nwx;
-        uint32_t ids_n = 0;
-        if (i + 1 < n_mine) {                                    // wave-uniform: the next tile's slots and ids are on their way while this one is warped
-            request_slots(t_nxt, (i + 1) & 1, tid);
-            ids_n = load_ids(t_nxt, tid);
-        }
-        const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
-        const bool active = x0 < W && y < H;
-        const uint32_t g = (uint32_t)y * (uint32_t)(W >> 2) + (uint32_t)(x0 >> 2);
-        const float fy = (float)y;
-        FastTap t[2][4];
-        uint32_t far = 0;                                        // pixels of entries beyond the 32 slots: identity here, exact in the redo below
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int li = (int)((ids >> (8 * k)) & 255u);
-#ifndef POPPY_WARP_COUNT_MAIN
-            if (li >= kSlots) { li = 0; far |= 17u << k; }
-#endif
-            const float4 A = sr[li * 5], B = sr[li * 5 + 1], C = sr[li * 5 + 2], D = sr[li * 5 + 3], e4 = sr[li * 5 + 4];
-            warp_taps(A, B, C, D, f2{e4.x, e4.y}, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
-        }
-        u3v ra[2][4], rb[2][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int im = 0; im < 2; ++im) {
-                const uint32_t o4 = t[im][k].off & ~3u;
-                ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
-                rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
-            }
-        }
-        uint32_t p[2][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int im = 0; im < 2; ++im) {
-                const uint32_t bs = t[im][k].off & 3u;
-                const u3v a3 = ra[im][k], b3 = rb[im][k];
-                const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
-                const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
-                p[im][k] = blend_fast(t[im][k], a, b);
-            }
-        }
-        const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
-        const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
-        constexpr uint32_t kNowhere = 0xfffffff0u;               // beyond the descriptor: dropped
-        __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, active ? g * 12u : kNowhere, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, active ? g * 12u : kNowhere, 0, 0);
-#ifndef POPPY_WARP_COUNT_MAIN
-        uint32_t edges = far;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
-        if (!active) edges = 0;
-        if (__builtin_amdgcn_ballot_w64(edges != 0) != 0 && edges != 0) {
-            for (int e = 0; e < 8; ++e) {
-                if (!((edges >> e) & 1u)) continue;
-                const int k = e & 3, im = e >> 2;
-                const unsigned en = (ids >> (8 * k)) & 255u;          // slot 0 holds the identity record
-                const uint32_t ro = en < (unsigned)kSlots ? slot_base + (uint32_t)t_cur * kTileSlotBytes + en * kEntryBytes
-                                                          : over_base + (uint32_t)(tile_off[t_cur] + (int)en - 1) * kEntryBytes;
-                const uint32_t v = slow_pixel_rsrc(rdata, ro, im, im ? rs2 : rs1, W, H, x0 + k, y);
-                const uint32_t po = ((uint32_t)y * (uint32_t)W + (uint32_t)(x0 + k)) * 3u;
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, im ? ro2 : ro1, po, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(v >> 8), im ? ro2 : ro1, po + 1, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(v >> 16), im ? ro2 : ro1, po + 2, 0, 0);
-            }
-        }
-#endif
-        t_cur = t_nxt; ids = ids_n;
-        tx += step_r; ty += step_q;
-        if (tx >= tiles_x) { tx -= tiles_x; ++ty; }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_warp_probe: k_warp_bin with its phases fenced and stamped (s_memtime), for tools/experiments/warp_probe.py.  Per wave 8 values:
-// entry, after the barrier (ids + records there), after the map arithmetic, after the gathers are issued, after they have all
-// returned, after the blends + stores are issued, HW_ID, XCC_ID.  A measuring aid: same results, slightly different schedule
-// (the blends wait for ALL gathers here).
-__device__ __forceinline__ uint64_t stamp() {
-    uint64_t t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-}
-
-template <int kTileW>
-__global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_probe(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
-                                                  const int* __restrict__ tile_off,
-                                                  const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                                  uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
-                                                  int tiles_x, uint32_t data_bytes, uint64_t* __restrict__ probe) {
-    constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
-    __shared__ float4 s_rec[kSlots * 5];
-    const uint64_t ts0 = stamp();
-    const int tid = threadIdx.x;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x), n_tiles = (int)gridDim.x;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int row = tid / kTileTx, xg = tid % kTileTx;
-    const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
-    const bool active = x0 < W && y < H;
-    const uint32_t g = (uint32_t)y * (uint32_t)(W >> 2) + (uint32_t)(x0 >> 2);
-    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
-    const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
-    const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
-    const uint32_t ids = __builtin_amdgcn_raw_buffer_load_b32(rdata, (uint32_t)tile * kTileIdBytes + (uint32_t)tid * 4u, 0, 0);
-    if (tid < kSlots * 5)
-        s_rec[tid] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                         rdata, (uint32_t)n_tiles * kTileIdBytes + (uint32_t)tile * kTileSlotBytes + (uint32_t)tid * 16u, 0, 0));
-    __syncthreads();
-    uint32_t idsv = ids;
-    asm volatile("" : "+v"(idsv));
-    const uint64_t ts1 = stamp();
-    const float fy = (float)y;
-    FastTap t[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int li = (int)((idsv >> (8 * k)) & 255u);
-        if (li >= kSlots) li = 0;                                // (timing aid: crowded tiles are not what it is run on)
-        const float4 A = s_rec[li * 5], B = s_rec[li * 5 + 1], C = s_rec[li * 5 + 2], D = s_rec[li * 5 + 3], e4 = s_rec[li * 5 + 4];
-        warp_taps(A, B, C, D, f2{e4.x, e4.y}, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(t[0][k].off), "+v"(t[0][k].wt), "+v"(t[0][k].wb)); asm volatile("" : "+v"(t[1][k].off), "+v"(t[1][k].wt), "+v"(t[1][k].wb)); }
-    const uint64_t ts2 = stamp();
-    u3v ra[2][4], rb[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int im = 0; im < 2; ++im) {
-            const uint32_t o4 = t[im][k].off & ~3u;
-            ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
-            rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
-        }
-    }
-    const uint64_t ts3 = stamp();
-    __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) (expcnt 7, lgkmcnt untouched: the stamp has drained it)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(ra[0][k]), "+v"(rb[0][k])); asm volatile("" : "+v"(ra[1][k]), "+v"(rb[1][k])); }
-    const uint64_t ts4 = stamp();
-    uint32_t p[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int im = 0; im < 2; ++im) {
-            const uint32_t bs = t[im][k].off & 3u;
-            const u3v a3 = ra[im][k], b3 = rb[im][k];
-            const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
-            const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
-            p[im][k] = blend_fast(t[im][k], a, b);
-        }
-    }
-    const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
-    const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
-    constexpr uint32_t kNowhere = 0xfffffff0u;
-    __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, active ? g * 12u : kNowhere, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, active ? g * 12u : kNowhere, 0, 0);
-    const uint64_t ts5 = stamp();
-    if ((tid & 63) == 0) {
-        uint64_t* o = probe + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
-        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4; o[5] = ts5;
-        o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          // HW_REG_HW_ID
-        o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));         // HW_REG_XCC_ID
-    }
-}
-
-// relaunches a frame's warp as k_warp_probe; `probe` takes 4 * 8 values per tile (device memory)
-size_t warp_probe_values(int tile_w, int w, int h) {
-    const int tiles_x = (w + tile_w - 1) / tile_w, tiles_y = (h + 1024 / tile_w - 1) / (1024 / tile_w);
-    return (size_t)tiles_x * tiles_y * 32;
-}
-void launch_warp_probe(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
-                       const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2, int w, int h, uint64_t* probe, hipStream_t s) {
-    const uint32_t bytes = (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u);
-#define LQ(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
-    hipLaunchKernelGGL(k_warp_probe<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, (const float4*)records, (const uint8_t*)tile_data, tile_off, \
-                       c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, tiles_x, bytes, probe); }
-    if (tile_w == 128) LQ(128) else LQ(64)
-#undef LQ
-}
-
 int warp_bin_tile_width(int w, int h) {
     static const int forced = getenv("POPPY_TILE_W") ? atoi(getenv("POPPY_TILE_W")) : 0;
     if (forced == 64 || forced == 128) return forced;
@@ -748,53 +272,13 @@ void launch_tile_expand(const float* records, const void* raster_tris, const voi
 #undef LE
 }
 
-// Which kernel launch_warp_bin runs: 0 = k_warp_bin (a workgroup per tile), v > 0 = k_warp_pipe, persistent: bits 0-3 pixels per pipeline unit
-// (1, 2, 4), bits 4-7 resident workgroups per CU.  POPPY_WARP_VARIANT at first use, warp_bin_set_variant() afterwards (A/B in one process).
-static int g_warp_variant = -1;
-static int g_cus = 0;
-void warp_bin_set_variant(int v) { g_warp_variant = v; }
-int warp_bin_variant() {
-    if (g_warp_variant < 0) g_warp_variant = getenv("POPPY_WARP_VARIANT") ? (int)strtol(getenv("POPPY_WARP_VARIANT"), nullptr, 0) : kWarpVariantDefault;
-    return g_warp_variant;
-}
-
 void launch_warp_bin(const float* records, const void* tile_data, size_t tile_data_bytes, const int* tile_off, int tile_w,
                      const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
                      int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-    const int variant = ex.m2 ? 0 : warp_bin_variant();
-    const uint32_t bytes = (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u);
-    if (variant > 0) {
-        if (!g_cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) g_cus = pr.multiProcessorCount; else g_cus = 256; }
-        if ((variant & 15) == 0) {                               // 0x80, 0x70, 0x60: k_warp_run with that many workgroups per CU
-            const int wv = variant >> 4;
-#define LR(TW, WV) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW), n_tiles = tiles_x * tiles_y; \
-    const int grid = std::min((g_cus * WV) & ~7, (n_tiles + 7) & ~7); \
-    hipExtLaunchKernelGGL((k_warp_run<TW, WV>), dim3(grid), dim3(256), 0, s, t0, t1, 0, (const float4*)records, (const uint8_t*)tile_data, tile_off, \
-                          c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, tiles_x, n_tiles, bytes); return; }
-            if (wv == 8) { if (tile_w == 128) LR(128, 8) else LR(64, 8) }
-            if (wv == 7) { if (tile_w == 128) LR(128, 7) else LR(64, 7) }
-            if (wv == 6) { if (tile_w == 128) LR(128, 6) else LR(64, 6) }
-#undef LR
-        }
-        const int unit = variant & 15, waves = (variant >> 4) & 15;
-#define LP(TW, U, WV) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW), n_tiles = tiles_x * tiles_y; \
-    const int grid = std::min((g_cus * WV) & ~7, (n_tiles + 7) & ~7); \
-    hipExtLaunchKernelGGL((k_warp_pipe<TW, U, WV>), dim3(grid), dim3(256), 0, s, t0, t1, 0, (const float4*)records, (const uint8_t*)tile_data, tile_off, \
-                          c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, tiles_x, n_tiles, bytes); return; }
-#define LPW(U, WV) { if (tile_w == 128) LP(128, U, WV) else LP(64, U, WV) }
-        if (unit == 4 && waves == 4) LPW(4, 4)
-        if (unit == 4 && waves == 3) LPW(4, 3)
-        if (unit == 2 && waves == 4) LPW(2, 4)
-        if (unit == 2 && waves == 5) LPW(2, 5)
-        if (unit == 1 && waves == 5) LPW(1, 5)
-        if (unit == 1 && waves == 6) LPW(1, 6)
-#undef LPW
-#undef LP
-    }
 #define LB(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
     hipExtLaunchKernelGGL(k_warp_bin<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const float4*)records, \
                           (const uint8_t*)tile_data, tile_off, c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, \
-                          w, h, tiles_x, bytes, ex); }
+                          w, h, tiles_x, (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u), ex); }
     if (tile_w == 128) LB(128) else LB(64)
 #undef LB
 }

@@ -164,34 +164,6 @@ int poppy_hip_time_last_warp(poppy_hip_ctx* c, int reps, float* ms_per_launch) {
     return POPPY_OK;
 }
 
-// Measuring aid: the last frame's fused warp once more as k_warp_probe (phases fenced and stamped with s_memtime); out takes 32 values per
-// tile (4 waves x {entry, front end done, map arithmetic done, gathers issued, gathers back, end, HW_ID, XCC_ID}); *ms = the launch's duration.
-int poppy_hip_warp_probe(poppy_hip_ctx* c, unsigned long long* out, size_t capacity, size_t* n_values, float* ms) {
-    if (!c || !out || !n_values) return POPPY_E_ARG;
-    if (!c->last_warp.valid) return fail(c, POPPY_E_STATE, "no fused raster + warp launch to repeat");
-    HIPCHK(c, hipSetDevice(c->device));
-    { int rc = drain_frames(c); if (rc) return rc; }
-    const auto& w = c->last_warp;
-    const size_t n = warp_probe_values(w.tile_w, c->W, c->H);
-    *n_values = n;
-    if (capacity < n) return fail(c, POPPY_E_ARG, "probe buffer too small");
-    uint64_t* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, n * 8));
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-    launch_warp_probe(w.rec, w.tile_data, w.tile_bytes, w.toff, w.tile_w, w.c1, w.c2, w.tr1, w.tr2, c->W, c->H, d, c->stream);     // warm
-    HIPCHK(c, hipEventRecord(e0, c->stream));
-    launch_warp_probe(w.rec, w.tile_data, w.tile_bytes, w.toff, w.tile_w, w.c1, w.c2, w.tr1, w.tr2, c->W, c->H, d, c->stream);
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipEventSynchronize(e1));
-    float t = 0.f;
-    HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
-    if (ms) *ms = t;
-    HIPCHK(c, hipMemcpy(out, d, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return POPPY_OK;
-}
-int poppy_hip_set_warp_variant(int variant) { warp_bin_set_variant(variant); return warp_bin_variant(); }
 int poppy_hip_mask_rider(poppy_hip_ctx* c) { return c ? (c->lazy_mask ? 0 : 1) : POPPY_E_ARG; }
 int poppy_hip_set_debug(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->debug = on != 0; return POPPY_OK; }
 int poppy_hip_set_timing(poppy_hip_ctx* c, int on) { if (!c) return POPPY_E_ARG; c->timing = on < 0 ? 0 : on; c->marks_used = 0; return POPPY_OK; }
