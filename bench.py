@@ -13,7 +13,7 @@ per-frame operator alone on a resident pair with the frames left in HBM (what ro
 
 N > 1 (configs[3]): ONE 480-frame phase-mode morph of one pair for EVERY N (`--total-frames`, default 480: north_star's "480-frame 1080p
 morph"): rank 0 runs the pair set-up, the pair state (both images, the mask field's grey complement, the point sets) goes to every rank
-in one broadcast over RCCL/xGMI, rank r renders the r-th contiguous share of the frames t_j = j / 480 — each equal to
+in one broadcast over RCCL/xGMI (`--shard-setup`: the set-up itself spread over ranks 0-2, used when it leaves the same point lists and is faster), rank r renders the r-th contiguous share of the frames t_j = j / 480 — each equal to
 morph(img1, img2, ..., phase = t_j) with number_of_frames = 1 — and hands them to its writer.  No data-path collective afterwards; the
 total work is fixed => "strong".  The N = 1 point of THAT job is the extra key `scaling_baseline_480` of the N = 1 line (the same
 480-frame morph on one GPU, set-up and writer inside), so an N-sweep is read against it and not against the chained headline; every
@@ -220,6 +220,89 @@ def cpu_baseline_and_parity(ctx, a, b, gpu_frames, frames=20):
     return base, par
 
 
+
+def measure_ceilings(torch, dev, w, h):
+    """"also report a measured device-copy ceiling from the same run" — and the ceiling that bounds the END-TO-END metric, pinned
+    device-to-host copies of whole frames (every frame of `value` leaves through one)."""
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {}
+    for key, nbytes, reps in (("device_copy_hbm", 1 << 30, 6), ("device_copy_cache_resident", 64 << 20, 40)):
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+        src.fill_(3); dst.copy_(src); torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        out[key] = {"GBps": round(2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1), "bytes_per_copy": nbytes,
+                    "what": "device-to-device copy, read + written bytes / time" + ("; source and destination (2 GB) exceed the 256 MB memory-side cache" if nbytes >= (1 << 30) else "; fits the memory-side cache")}
+        del src, dst
+    fb = w * h * 3
+    d_frame = torch.empty(fb, dtype=torch.uint8, device=dev); d_frame.fill_(7)
+    h_frame = torch.empty(fb, dtype=torch.uint8).pin_memory()
+    h_frame.copy_(d_frame, non_blocking=True); torch.cuda.synchronize()
+    e0, e1 = ev(), ev()
+    reps = 100
+    e0.record()
+    for _ in range(reps):
+        h_frame.copy_(d_frame, non_blocking=True)
+    e1.record(); torch.cuda.synchronize()
+    rate = fb * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out["pinned_d2h_frames"] = {"GBps": round(rate, 1), "frame_bytes": fb, "frames_per_s_cap": round(rate * 1e9 / fb, 1),
+                                "what": f"{reps} copies of one {w}x{h} frame from HBM into a pinned host buffer, back to back on one stream: what a writer that takes every frame can be handed at most"}
+    del d_frame, h_frame
+    return out
+
+
+def predicted_speedups(job_ms, setup_ms, state_bytes):
+    """The N = 2 / 4 / 8 points of the sharded 480-frame job as the one-GPU terms predict them (Amdahl): T_N = serial + (job - set-up) / N."""
+    frames_ms = max(job_ms - setup_ms, 0.0)
+    bcast_ms = 0.05 + state_bytes / 100e9 * 1e3          # one ncclBroadcast of the pair state: ~100 GB/s per-link-bound ring over xGMI + latency (not measurable on one GPU)
+    forms = {"rank0_then_broadcast": setup_ms + bcast_ms,
+             # sharded set-up: one image's chain alone is 0.66 of the two side by side (POPPY_SETUP_SERIAL, DESIGN.md section 6), + the raw-pair broadcast and five small collectives
+             "sharded_over_ranks_0_2_estimate": 0.66 * setup_ms + 0.4 + bcast_ms}
+    out = {"terms_ms": {"job_on_one_gpu": round(job_ms, 3), "pair_setup": round(setup_ms, 3), "frames_incl_writer": round(frames_ms, 3), "broadcast_estimate": round(bcast_ms, 3)},
+           "note": "speed-up over scaling_baseline_480.fps; the one-GPU job is bound by the writer's PCIe path, each rank of an N-GPU job has its own"}
+    for name, serial in forms.items():
+        out[name] = {f"x{n}": round(job_ms / (serial + frames_ms / n), 2) for n in (2, 4, 8)}
+        out[name]["serial_ms"] = round(serial, 3)
+    return out
+
+
+def content_sensitivity(capi, ctx, w, h):
+    """Pair set-up and chained-frame time on content other than the 40 flat shapes of the synthetic pair: the medians' whole-wave skips and the ORB
+    candidate guess depend on content.  `textured`: poppy_amd/synth.py textured_bgr (hash noise over gradients); `photo`: the reference's own
+    sample pair images/amir1.jpg / amir2.jpg (pixels committed as tests/golden/photo_pair_720x405.npz), upscaled to the frame size in integers."""
+    from poppy_amd import synth
+    cases = {"synthetic_shapes": lambda: synth.gen_pair(w, h, seed=1234),
+             "textured": lambda: (synth.textured_bgr(w, h, 7), synth.textured_bgr(w, h, 8)),
+             "photo": lambda: synth.photo_pair(w, h)}
+    shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
+    out = {}
+    for name, make in cases.items():
+        try:
+            a, b = make()
+            ctx.pair_begin(a, b)
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter(); ctx.pair_begin(a, b); t.append((time.perf_counter() - t0) * 1e3)
+            p1, _ = ctx.pair_points()
+            k0 = ctx.warp_counts()
+            ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.reset(); ctx.render_many(shapes, chain=True)
+            ctx.sync()
+            us = (time.perf_counter() - t0) / (reps * FRAMES) * 1e6
+            k1 = ctx.warp_counts()
+            out[name] = {"pair_setup_ms_from_host_images": round(sorted(t)[len(t) // 2], 3), "point_pairs": int(len(p1)), "chained_frame_us": round(us, 1),
+                         "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), (int(y - x) for x, y in zip(k0, k1))))}
+        except Exception as e:
+            out[name] = {"error": str(e)}
+    return out
+
+
 def run_cfg3_4k(capi, torch, dev, steps, check=True):
     """BASELINE.json configs[2]: 3840x2160 pair, 120 phase-mode frames (t_j = j / 120), set-up and writer hand-off inside."""
     w, h, n = 3840, 2160, 120
@@ -294,7 +377,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="pairs per step at N = 1 (default 6)")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="N > 1: pairs per GPU of the configs[4] object")
     ap.add_argument("--total-frames", type=int, default=480, help="N > 1: frames of the ONE phase-mode morph that is sharded by frame range (fixed for every N: strong scaling); also the size of the N = 1 line's scaling_baseline_480")
-    ap.add_argument("--no-shard-setup", action="store_true", help="N > 1: pair set-up on rank 0 alone + one broadcast of the pair state (round 2's form) instead of the set-up spread over ranks 0-2")
+    ap.add_argument("--shard-setup", action="store_true", help="N > 1: ALSO time the pair set-up spread over ranks 0-2 (poppy_hip_pair_begin_sharded) before the warm-up, compare the point lists it leaves with the rank-0 "
+                    "set-up's on every rank, and use it in the timed region when it is both identical and faster.  Opt-in: its RCCL transport has not run on more than one GPU yet (the default is the pair set-up on rank 0 + one broadcast of the pair state)")
+    ap.add_argument("--no-shard-setup", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the 512x512x30 whole-morph CPU figure (~40 s of oracle time)")
     ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 3 (measured on one box, pairs per step 4 / 8: 2 contexts 5.11k / 5.03k frames/s, 3: 5.35k / 5.51k, 4: 5.26k / 5.36k; the roofline kernel's in-bench launches stretch from 21.6 to 23.5-24.8 and 27 us as more kernels compete)")
     args = ap.parse_args()
@@ -325,9 +410,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # POPPY_BENCH_SHARDED_SELFTEST=1 (with --gpus 1): the N > 1 code path on a world of ONE rank over RCCL — the library's communicator, the sharded
-    # set-up (all three roles on rank 0), the choice between the set-up's forms — for boxes with a single GPU.  Its numbers mean nothing.
+    # POPPY_BENCH_SHARDED_SELFTEST=1 (with --gpus 1): the N > 1 code path on a world of ONE rank over RCCL — the library's communicator, both forms of
+    # the set-up (with --shard-setup the sharded protocol itself: POPPY_HIP_SHARD_WORLD1 makes the library run it on a world of one, all three roles
+    # on rank 0, every broadcast and reduction a real RCCL call), the choice between them — for boxes with a single GPU.  Its numbers mean nothing.
     selftest = world == 1 and os.environ.get("POPPY_BENCH_SHARDED_SELFTEST") == "1"
+    if selftest:
+        os.environ.setdefault("POPPY_HIP_SHARD_WORLD1", "1")
+        args.shard_setup = True
     if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -480,6 +569,7 @@ def bench_single(args, torch, capi, dev, local):
                                    "fps": round(r480 * TOTAL / dt480, 1), "ms_per_job": round(dt480 / r480 * 1e3, 3), "jobs_timed": r480,
                                    "serial_part_ms": out["pair_setup_ms"],
                                    "amdahl_note": "with the set-up serial, N GPUs cannot beat (set-up + frames) / (set-up + frames / N)"}
+    out["scaling_baseline_480"]["predicted_speedup"] = predicted_speedups(dt480 / r480 * 1e3, out["pair_setup_ms"], capi.pair_state_bytes(W, H))
     # the headline step once more with the raw pairs copied from pinned host memory inside the step (the reference's morph() takes host images)
     pinned = [(torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory()) for a, b in pairs_host]
     pool2 = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
@@ -532,10 +622,27 @@ def bench_single(args, torch, capi, dev, local):
                 out["cpu_baseline"]["end_to_end"] = cpu_end_to_end()
         except Exception as e:   # the checker is optional for the measurement, never for parity
             out["cpu_baseline"] = {"value": None, "error": str(e)}
+    try:
+        out["content_sensitivity"] = content_sensitivity(capi, ctx, W, H)
+    except Exception as e:
+        out["content_sensitivity"] = {"error": str(e)}
     ctx.close()
+    try:
+        out["ceilings"] = measure_ceilings(torch, dev, W, H)
+        cap = out["ceilings"]["pinned_d2h_frames"]["frames_per_s_cap"]
+        out["ceilings"]["value_frac_of_d2h_cap"] = round(out["value"] / cap, 3)
+        out["ceilings"]["scaling_baseline_480_frac_of_d2h_cap"] = round(out["scaling_baseline_480"]["fps"] / cap, 3)
+        out["roofline"]["frac_of_device_copy_ceiling"] = round(out["roofline"]["achieved"] / out["ceilings"]["device_copy_hbm"]["GBps"], 4)
+    except Exception as e:
+        out["ceilings"] = {"error": str(e)}
     if not args.no_4k and (W, H) == (1920, 1080):
         try:
             out["cfg3_4k"] = run_cfg3_4k(capi, torch, dev, max(3, min(args.steps, 10)), check=not args.no_cpu_baseline)
+            if "error" not in out.get("ceilings", {}):
+                c4 = measure_ceilings(torch, dev, 3840, 2160)["pinned_d2h_frames"]
+                out["cfg3_4k"]["d2h_cap"] = c4
+                out["cfg3_4k"]["value_frac_of_d2h_cap"] = round(out["cfg3_4k"]["value"] / c4["frames_per_s_cap"], 3)
+                out["cfg3_4k"]["roofline"]["frac_of_device_copy_ceiling"] = round(out["cfg3_4k"]["roofline"]["achieved"] / out["ceilings"]["device_copy_hbm"]["GBps"], 4)
         except Exception as e:
             out["cfg3_4k"] = {"error": str(e)}
     return out
@@ -554,7 +661,7 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     link = sharding.PairLink(torch, dist, capi, ctx, rank, world, W, H, cdev, use_library=not rehearsal)
     t_setup = [0.0]; t_bcast = [0.0]; t_frames = [0.0]
 
-    shard_setup = link.library and not args.no_shard_setup
+    shard_setup = link.library and args.shard_setup and not args.no_shard_setup
 
     def fence():
         ctx.sync(); torch.cuda.synchronize()
@@ -588,7 +695,8 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
         flag = torch.tensor([same], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         same = bool(int(flag.item()))
-        variants = {"sharded_ms": round(ms_sharded, 3), "rank0_then_broadcast_ms": round(ms_rank0, 3), "same_point_lists_on_every_rank": same}
+        variants = {"sharded_ms": round(ms_sharded, 3), "rank0_then_broadcast_ms": round(ms_rank0, 3), "same_point_lists_on_every_rank": same,
+                    "sharded_protocol_runs_on_rank0": capi.sharded_setups()}
         shard_setup = same and ms_sharded <= ms_rank0
         variants["used"] = "sharded" if shard_setup else "rank 0 + broadcast"
 

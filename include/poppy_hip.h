@@ -88,10 +88,15 @@ int poppy_hip_pair_reset(poppy_hip_ctx* ctx);                 /* back to the sta
 const void* poppy_hip_frame_device(poppy_hip_ctx* ctx);       /* device pointer of the last frame (u8x3, tight); see poppy_hip_frame_wait */
 int poppy_hip_sync(poppy_hip_ctx* ctx);                       /* wait for all queued work of this ctx (every frame stream included) */
 void* poppy_hip_stream(poppy_hip_ctx* ctx);                   /* the hipStream_t the pair set-up and CHAINED frames run on */
-/* Independent frames (chain == 0, phase mode) run on per-slot streams of their own, several in flight: work queued on
- * poppy_hip_stream() is NOT ordered behind them.  A caller that renders with dst == NULL and consumes poppy_hip_frame_device() on the
- * device makes its own stream wait for the frame with poppy_hip_frame_wait (a hipStreamWaitEvent on the frame's completion event;
- * stream == NULL: the host waits), or calls poppy_hip_sync().  poppy_hip_frame_stream: the stream the last frame was rendered on. */
+/* Independent frames (chain == 0, phase mode), several in flight, do not run in the order of poppy_hip_stream(): frames that STAY in HBM
+ * (no writer) run on per-slot streams of their own — work queued on poppy_hip_stream() is NOT ordered behind them —; a sequence with a
+ * WRITER attached (poppy_hip_render_many / _phases / _morph with a callback) takes the context's own three compute streams in turn, slot
+ * index mod 3 — poppy_hip_stream(), the plan-upload stream and the set-up's second stream: the three hardware queues that carry no frame
+ * copies —, so work a caller queues on poppy_hip_stream() DURING such a sequence is serialised behind every third frame
+ * (POPPY_PHASE_OWN_STREAMS=1: a stream per slot in both cases, the form before round 3).  Either way a caller that renders with
+ * dst == NULL and consumes poppy_hip_frame_device() on the device makes its own stream wait for the frame with poppy_hip_frame_wait (a
+ * hipStreamWaitEvent on the frame's completion event; stream == NULL: the host waits), or calls poppy_hip_sync().
+ * poppy_hip_frame_stream: the stream the last frame was rendered on.  Every pair loader drains all of them first. */
 int poppy_hip_frame_wait(poppy_hip_ctx* ctx, void* hip_stream);
 void* poppy_hip_frame_stream(poppy_hip_ctx* ctx);
 
@@ -290,9 +295,14 @@ int poppy_hip_pair_broadcast(poppy_hip_ctx* ctx, int root, int width, int height
  * (the serial part of a sharded morph): rank `root` holds the raw pair (device pointers; the other ranks pass NULL) and filters / detects image 1,
  * rank root + 1 does image 2, rank root + 2 the mask field (src/poppy.hpp:52,114-122: independent until the matcher); the raw pair, the
  * two dft_detail2 values, image 2's keypoint positions, the matched point sets and the mask field's grey complement are exchanged through the
- * communicator.  Afterwards every rank holds the resident pair exactly as poppy_hip_pair_begin_device would have produced it on one GPU.
- * POPPY_E_UNSUPPORTED with enable_auto_align.  _local: the same protocol between n contexts of THIS process (host threads; context k = rank k). */
+ * communicator.  Afterwards every rank holds the resident pair exactly as poppy_hip_pair_begin_device would have produced it on one GPU
+ * (one limit of its own: image 2's keypoints travel through the state's point area, 16 383 at most — far above max_keypoints x detail
+ * for every setting of the reference's CLI).  POPPY_E_UNSUPPORTED with enable_auto_align.  Opt-in in poppy_hip_morph_sharded
+ * (POPPY_HIP_SHARD_SETUP=1) and bench.py (--shard-setup) until its RCCL transport has run on three or more GPUs.  _local: the same protocol between n contexts of THIS process (host threads; context k = rank k). */
 int poppy_hip_pair_begin_sharded(poppy_hip_ctx* ctx, const void* d_bgr1, const void* d_bgr2, int width, int height, int root);
+/* How often the sharded protocol itself ran in this process (a world of one takes poppy_hip_pair_begin_device instead unless
+ * POPPY_HIP_SHARD_WORLD1 is set): lets a test on a one-GPU box see that the protocol, over RCCL, is what it exercised. */
+unsigned long long poppy_hip_sharded_setups(void);
 int poppy_hip_pair_begin_sharded_local(poppy_hip_ctx** ctxs, int n, const void* d_bgr1, const void* d_bgr2, int width, int height, int root);
 int poppy_hip_comm_max(poppy_hip_ctx* ctx, double* value);
 int poppy_hip_pair_state_bytes(int width, int height, size_t* bytes);

@@ -31,6 +31,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;            // optional: unblocks the other device threads of poppy_hip_morph_sharded when one of them failed
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -54,6 +55,7 @@ Rccl* rccl() {
         r.CommInitRank = (int (*)(void**, int, Id128, int))sym("ncclCommInitRank");
         r.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
         r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        r.CommAbort = (int (*)(void*))dlsym(r.handle, "ncclCommAbort");
         r.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
@@ -91,6 +93,12 @@ int poppy_hip_comm_init(poppy_hip_ctx* c, int rank, int world, const uint8_t* id
     const int rc = r->CommInitRank(&comm, world, id, rank);
     if (rc != 0) return rccl_fail(c, "ncclCommInitRank", rc);
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    // the small reductions' scratch now, where a failure is this rank's alone: inside a collective sequence an allocation that fails
+    // would leave the other ranks waiting in the reduction this rank never enters
+    if (!c->d_comm_scratch && hipMalloc((void**)&c->d_comm_scratch, 8 * sizeof(double)) != hipSuccess) {
+        (void)r->CommDestroy(comm); c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+        return fail(c, POPPY_E_DEVICE, "allocation of the reduction scratch");
+    }
     return POPPY_OK;
 }
 
@@ -146,12 +154,13 @@ int poppy_hip_pair_broadcast(poppy_hip_ctx* c, int root, int W, int H) {
 // the device scratch is allocated once per context (hipMalloc / hipFree per call cost more than the reduction)
 static int comm_max_n(poppy_hip_ctx* c, double* values, int n) {
     if (n < 1 || n > 8) return fail(c, POPPY_E_ARG, "comm_max_n: 1..8 values");
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_comm_scratch) HIPCHK(c, hipMalloc((void**)&c->d_comm_scratch, 8 * sizeof(double)));
+    // nothing below returns before the collective has been entered: a rank whose device selection or copy-in failed still takes part (and
+    // returns its error afterwards), so that no rank is left alone inside ncclAllReduce
+    if (!c->d_comm_scratch) return fail(c, POPPY_E_STATE, "communicator without its scratch (poppy_hip_comm_init allocates it)");
     double* d = c->d_comm_scratch;
-    hipError_t e = hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-    int nr = 0;
-    if (e == hipSuccess) nr = rccl()->AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclMax, c->comm, c->stream);
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    const int nr = rccl()->AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclMax, c->comm, c->stream);   // entered whatever `e` says: see above
     if (e == hipSuccess && nr == 0) e = hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (nr != 0) return rccl_fail(c, "ncclAllReduce", nr);
@@ -197,8 +206,12 @@ int poppy_hip_pair_import_device(poppy_hip_ctx* c, const void* d_src, size_t byt
 // The exchanges, all through the same communicator: the raw pair from `root` (one broadcast of the c1 | c2 region), the two detail
 // values (one 3-double max-reduction, which also carries an error flag: nfeatures needs both, src/extractor.cpp:40-45), image 2's
 // keypoint positions B -> A (one broadcast through the state's point area), then the matcher on A and two broadcasts that complete the
-// pair state everywhere: header + points from A, m2 from C.  No step can leave a rank alone inside a collective: whatever can fail on
-// one rank is reported through the reduction or through an invalid header that every rank refuses.
+// pair state everywhere: header + points from A, m2 from C.  No step leaves a rank alone inside a collective: whatever can fail on one
+// rank is reported through the reduction, through a count of -1 in the keypoint hand-off or through an invalid header that every rank
+// refuses, and a transport error is remembered while the remaining collectives are still entered (round 4; the reductions' scratch is
+// allocated with the communicator).  One limit the one-GPU set-up does not have: image 2's keypoints travel through the state's point
+// area, so more than kPairMaxPoints - 1 (16 383) of them fail the set-up (the one-GPU path limits only the MATCHED pairs); max_keypoints
+// x detail stays far below that for every setting the reference's CLI accepts.
 // The transport is abstract so that the role logic can run — and be tested bit for bit — with several contexts of ONE process on one
 // GPU (LocalHub: device-to-device copies between the contexts' buffers behind a thread barrier).
 namespace {
@@ -232,7 +245,10 @@ int chain_image(poppy_hip_ctx* c, int i, bool with_gabor, double* detail, const 
     return POPPY_OK;
 }
 
+std::atomic<unsigned long long> g_sharded_setups{0};     // protocol runs in this process (poppy_hip_sharded_setups): lets a test see that the protocol, not a shortcut, ran
+
 int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2, int W, int H, int root) {
+    g_sharded_setups.fetch_add(1);
     if (c->cfg.enable_auto_align) return fail(c, POPPY_E_UNSUPPORTED, "the sharded set-up does not take auto-align (image 2 changes after the match)");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t P = (size_t)W * H;
@@ -287,6 +303,8 @@ int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2
     // 3. ORB::detect where the ORB inputs lie
     std::vector<OrbKeyPoint> k1, k2;
     int r1 = 0, r2 = 0;
+    std::string root_err;                                  // this rank's own reason, kept apart from c->err (adopt_pair_state overwrites that)
+    int bcast_rc = POPPY_OK;                               // a transport error: remembered, the remaining collectives are still entered
     {
         std::thread other;
         if (isB) {
@@ -304,10 +322,16 @@ int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2
         int n2 = r2 < 0 || (int)k2.size() > kPairMaxPoints - 1 ? -1 : (int)k2.size();
         memcpy(&buf[0], &n2, 4);
         for (int i = 0; i < n2; ++i) { buf[2 + 2 * i] = k2[i].x; buf[3 + 2 * i] = k2[i].y; }
-        if (hipMemcpyAsync(xarea, buf.data(), (2 + 2 * (size_t)std::max(n2, 0)) * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "keypoint hand-off");     // (a HIP failure here is fatal for the job anyway)
+        if (n2 < 0) root_err = r2 < 0 ? "orb_detect (image 2): " + c->orb_b.err : "image 2 has more keypoints than the hand-off area holds (" + std::to_string(k2.size()) + " > " + std::to_string(kPairMaxPoints - 1) + ")";
+        bool sent = hipMemcpyAsync(xarea, buf.data(), (2 + 2 * (size_t)std::max(n2, 0)) * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                    hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!sent) {                                       // not a return: A and the other ranks are about to enter the broadcast.  Say "failed" through
+            n2 = -1; r2 = -1;                              // the protocol (count -1) if the device still takes a 4-byte write, and go on into the collective
+            root_err = "keypoint hand-off to the matcher's rank";
+            (void)hipMemcpy(xarea, &n2, 4, hipMemcpyHostToDevice);
+        }
     }
-    if (rA != rB) { rc = T.bcast(c, xarea, xbytes, rB); if (rc) return rc; }
+    if (rA != rB) { rc = T.bcast(c, xarea, xbytes, rB); if (rc) bcast_rc = rc; }
     // 5. the matcher on A (host), then header + points for everybody
     bool valid = true;
     if (isA) {
@@ -323,7 +347,7 @@ int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2
             if (r2 < 0) n2 = -1;
             for (int i = 0; i < n2; ++i) { p2v.push_back(k2[i].x); p2v.push_back(k2[i].y); }
         }
-        if (r1 < 0 || n2 < 0) { valid = false; c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : std::string("the other image's detection failed")); }
+        if (r1 < 0 || n2 < 0) { valid = false; root_err = r1 < 0 ? "orb_detect (image 1): " + c->orb.err : std::string("image 2's rank reported a failed detection or too many keypoints"); }
         if (valid) {
             const size_t n = std::min(k1.size(), (size_t)n2);                   // Extractor::points (extractor.cpp:96-99)
             std::vector<float> p1(n * 2), p2(n * 2), o1((n + 4) * 2), o2((n + 4) * 2);
@@ -332,17 +356,19 @@ int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2
             int mr = poppy_match_points(p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
             if (mr == POPPY_OK) mr = set_points(c, o1.data(), o2.data(), m);
             if (mr == POPPY_OK) mr = stage_pair_state(c);
-            if (mr != POPPY_OK) valid = false;
+            if (mr != POPPY_OK) { valid = false; root_err = "matcher / pair state: " + c->err; }
         }
         if (!valid) {                                                           // a header every rank refuses (adopt_pair_state checks the magic)
             (void)hipMemsetAsync(c->arena, 0, kPairHeadBytes, c->stream);
             (void)hipStreamSynchronize(c->stream);
         }
     }
-    rc = T.bcast(c, c->arena, kPairHeadBytes + xbytes, rA); if (rc) return rc;
-    rc = T.bcast(c, c->m2, P * 4, rC); if (rc) return rc;
+    // both final broadcasts are entered by every rank whatever happened before (a transport error on one rank must not leave the others inside the next one)
+    rc = T.bcast(c, c->arena, kPairHeadBytes + xbytes, rA); if (rc && !bcast_rc) bcast_rc = rc;
+    rc = T.bcast(c, c->m2, P * 4, rC); if (rc && !bcast_rc) bcast_rc = rc;
+    if (bcast_rc) return bcast_rc;
     rc = adopt_pair_state(c);
-    if (rc != POPPY_OK && isA && !valid) return fail(c, POPPY_E_DEVICE, ("sharded set-up: " + c->err).c_str());
+    if (rc != POPPY_OK && !root_err.empty()) return fail(c, POPPY_E_DEVICE, ("sharded set-up: " + root_err).c_str());
     return rc;
 }
 
@@ -352,24 +378,34 @@ struct LocalHub {
     std::mutex mu; std::condition_variable cv; int arrived = 0; unsigned phase = 0;
     const void* src = nullptr; int src_device = 0;
     std::vector<double> vals;
+    bool aborted = false;
     explicit LocalHub(int n_) : n(n_) {}
-    void barrier() {
+    // false = a context left the protocol with an error (abort()): whoever waits here returns an error too instead of waiting for ever
+    bool barrier() {
         std::unique_lock<std::mutex> g(mu);
+        if (aborted) return false;
         const unsigned ph = phase;
         if (++arrived == n) { arrived = 0; ++phase; cv.notify_all(); }
-        else cv.wait(g, [&] { return phase != ph; });
+        else cv.wait(g, [&] { return phase != ph || aborted; });
+        return !aborted;
     }
+    void abort() { { std::lock_guard<std::mutex> g(mu); aborted = true; } cv.notify_all(); }
 };
 
 }  // namespace
 
 extern "C" {
 
+unsigned long long poppy_hip_sharded_setups(void) { return g_sharded_setups.load(); }
+
 int poppy_hip_pair_begin_sharded(poppy_hip_ctx* c, const void* d1, const void* d2, int W, int H, int root) {
     if (!c) return POPPY_E_ARG;
     if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
     if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");
-    if (c->comm_world == 1) return poppy_hip_pair_begin_device(c, d1, d2, W, H);
+    // a world of one needs no exchange — unless POPPY_HIP_SHARD_WORLD1 asks for the protocol anyway: all three roles on this rank, every
+    // broadcast and reduction a real RCCL call on the one-rank communicator (what a box with a single GPU can run of the multi-rank path)
+    static const bool world1_protocol = getenv("POPPY_HIP_SHARD_WORLD1") != nullptr;
+    if (c->comm_world == 1 && !world1_protocol) return poppy_hip_pair_begin_device(c, d1, d2, W, H);
     Transport T;
     T.rank = c->comm_rank; T.world = c->comm_world;
     T.bcast = [](poppy_hip_ctx* cc, void* buf, size_t bytes, int r) -> int {
@@ -396,30 +432,33 @@ int poppy_hip_pair_begin_sharded_local(poppy_hip_ctx** ctxs, int n, const void* 
         T.rank = k; T.world = n;
         T.bcast = [&hub, k](poppy_hip_ctx* cc, void* buf, size_t bytes, int r) -> int {
             if (k == r) { hub.src = buf; hub.src_device = cc->device; }
-            hub.barrier();
+            if (!hub.barrier()) return fail(cc, POPPY_E_STATE, "another context left the sharded set-up with an error");
             hipError_t e = hipSuccess;
             if (k != r) {
                 e = hipMemcpyAsync(buf, hub.src, bytes, hipMemcpyDeviceToDevice, cc->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(cc->stream);
             }
-            hub.barrier();                                             // the root's buffer may change again only now
+            if (!hub.barrier()) return fail(cc, POPPY_E_STATE, "another context left the sharded set-up with an error");   // the root's buffer may change again only now
             return e == hipSuccess ? POPPY_OK : fail(cc, POPPY_E_DEVICE, "local broadcast");
         };
-        T.allmax = [&hub, k](poppy_hip_ctx*, double* v, int m) -> int {
-            hub.barrier();
-            if (k == 0) std::fill(hub.vals.begin(), hub.vals.end(), -1e300);
-            hub.barrier();
-            { std::lock_guard<std::mutex> g(hub.mu); for (int i = 0; i < m; ++i) hub.vals[i] = std::max(hub.vals[i], v[i]); }
-            hub.barrier();
+        T.allmax = [&hub, k](poppy_hip_ctx* cc, double* v, int m) -> int {
+            bool ok = hub.barrier();
+            if (ok && k == 0) std::fill(hub.vals.begin(), hub.vals.end(), -1e300);
+            ok = ok && hub.barrier();
+            if (ok) { std::lock_guard<std::mutex> g(hub.mu); for (int i = 0; i < m; ++i) hub.vals[i] = std::max(hub.vals[i], v[i]); }
+            ok = ok && hub.barrier();
+            if (!ok) return fail(cc, POPPY_E_STATE, "another context left the sharded set-up with an error");
             for (int i = 0; i < m; ++i) v[i] = hub.vals[i];
             return POPPY_OK;
         };
         rcs[k] = setup_sharded(ctxs[k], T, k == root ? d1 : nullptr, k == root ? d2 : nullptr, W, H, root);
+        if (rcs[k] != POPPY_OK) hub.abort();                               // nobody waits for a context that has returned
     };
     std::vector<std::thread> th;
     for (int k = 1; k < n; ++k) th.emplace_back(work, k);
     work(0);
     for (auto& t : th) t.join();
+    for (int k = 0; k < n; ++k) if (rcs[k] != POPPY_OK && rcs[k] != POPPY_E_STATE) return rcs[k];      // the cause before its echoes
     for (int k = 0; k < n; ++k) if (rcs[k] != POPPY_OK) return rcs[k];
     return POPPY_OK;
 }
@@ -453,12 +492,18 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
         const int rc = r->CommInitAll(comms.data(), n_devices, devices);
         if (rc != 0) { set_err(err, err_len, std::string("ncclCommInitAll: ") + (r->GetErrorString ? r->GetErrorString(rc) : "")); cleanup(); return POPPY_E_DEVICE; }
         for (int k = 0; k < n_devices; ++k) { ctx[k]->comm = comms[k]; ctx[k]->comm_rank = k; ctx[k]->comm_world = n_devices; }
+        for (int k = 0; k < n_devices; ++k)               // the reductions' scratch before any thread can be inside a collective
+            if (hipSetDevice(devices[k]) != hipSuccess || hipMalloc((void**)&ctx[k]->d_comm_scratch, 8 * sizeof(double)) != hipSuccess) {
+                set_err(err, err_len, "allocation of the reduction scratch"); cleanup(); return POPPY_E_DEVICE;
+            }
     }
-    // Several devices: the set-up itself is spread over them (poppy_hip_pair_begin_sharded: image 1 on device 0, image 2 on device 1, the mask
-    // field on device 2), unless auto-align is on or POPPY_HIP_SHARD_SETUP=0; otherwise it runs on device 0 before any other device's thread
-    // exists (nobody can be left waiting inside RCCL when it fails) and the pair state is broadcast.
-    static const bool shard_off = getenv("POPPY_HIP_SHARD_SETUP") && atoi(getenv("POPPY_HIP_SHARD_SETUP")) == 0;
-    const bool shard_setup = n_devices > 1 && !cfg.enable_auto_align && !shard_off;
+    // Several devices: the set-up runs on device 0 before any other device's thread exists (nobody can be left waiting inside RCCL when it
+    // fails) and the pair state is broadcast.  POPPY_HIP_SHARD_SETUP=1 spreads the set-up itself over the devices instead
+    // (poppy_hip_pair_begin_sharded: image 1 on device 0, image 2 on device 1, the mask field on device 2; not under auto-align): opt-in
+    // until its RCCL transport has run on a node with three or more GPUs (round-3 advisor finding; the role logic is tested through the
+    // in-process transport, the transport through a world of one).
+    static const bool shard_on = getenv("POPPY_HIP_SHARD_SETUP") && atoi(getenv("POPPY_HIP_SHARD_SETUP")) != 0;
+    const bool shard_setup = n_devices > 1 && !cfg.enable_auto_align && shard_on;
     uint8_t* d_raw = nullptr;
     const size_t P3 = (size_t)W * H * 3;
     if (shard_setup) {
@@ -474,6 +519,17 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
     }
     std::vector<int> rcs(n_devices, POPPY_OK);
     struct Relay { poppy_write_indexed_cb write; void* user; int base; };
+    // a device thread that fails before or inside the collectives must not leave the others waiting in RCCL for ever: it aborts every
+    // communicator of the job once (ncclCommAbort makes pending and later operations on it return an error)
+    std::once_flag abort_once;
+    auto abort_all = [&]() {
+        std::call_once(abort_once, [&]() {
+            Rccl* r = rccl();
+            if (n_devices > 1 && r->CommAbort)
+                for (int k = 0; k < n_devices; ++k) if (ctx[k]->comm) { void* cm = ctx[k]->comm; ctx[k]->comm = nullptr; (void)r->CommAbort(cm); }
+        });
+    };
+    std::atomic<int> past_setup{0};
     auto work = [&](int k) {
         poppy_hip_ctx* c = ctx[k];
         int rc = POPPY_OK;
@@ -481,6 +537,8 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
             rc = poppy_hip_pair_begin_sharded(c, k == 0 ? d_raw : nullptr, k == 0 ? d_raw + P3 : nullptr, W, H, 0);
             if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_NOMATCH, "no point pairs");      // every rank sees the same (empty) point sets
         } else if (n_devices > 1) rc = poppy_hip_pair_broadcast(c, 0, W, H);
+        if (rc != POPPY_OK && past_setup.load() < n_devices) abort_all();      // the exchanges are over once every device is past this point
+        past_setup.fetch_add(1);
         const int lo = (int)((long long)total_frames * k / n_devices), hi = (int)((long long)total_frames * (k + 1) / n_devices);
         if (rc == POPPY_OK && hi > lo) {
             Relay relay{write, user, lo};

@@ -180,7 +180,10 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
             helper2_.run([&]() { for (int l = 2; l < kOrbLevels; ++l) level_job(l); });
         }
         level_job(0);
-        if (split) { helper_.wait(); helper2_.wait(); }
+        if (split) {
+            const bool ok1 = helper_.wait(), ok2 = helper2_.wait();
+            if (!ok1 || !ok2) { err = "keypoint selection helper thread: " + (ok1 ? helper2_.error() : helper_.error()); return -1; }
+        }
         else for (int l = 1; l < kOrbLevels; ++l) level_job(l);
     }
     for (int l = 0; l < kOrbLevels; ++l) {

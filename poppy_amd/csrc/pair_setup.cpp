@@ -224,12 +224,16 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     // Each image's thread goes on to the detector's second half by itself as soon as BOTH details are known (nfeatures, src/extractor.cpp:40-45):
     // the other image's detail is ready long before its own candidates are, so nobody waits for a whole chain.  `details` counts the images
     // whose detail is published (or whose chain failed before it).
-    std::atomic<int> details{0};
+    struct Details {                                                      // a counter two threads wait on (no spinning: the wait can be a chain's length)
+        std::mutex m; std::condition_variable cv; int n = 0;
+        void add() { { std::lock_guard<std::mutex> g(m); ++n; } cv.notify_all(); }
+        void wait_for(int k) { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return n >= k; }); }
+    } details;
     std::vector<OrbKeyPoint> k1, k2;
     int nfeatures = 0;
     struct Publish {                                                      // counts once, at the detail or at whichever exit comes before it
-        std::atomic<int>& n; bool done = false;
-        void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } }
+        Details& d; bool done = false;
+        void now() { if (!done) { done = true; d.add(); } }
         ~Publish() { now(); }
     };
     static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
@@ -257,7 +261,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         OrbDetector& orb = i ? c->orb_b : c->orb;
         if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; return; }
         if (serial_chains) return;                                // (one chain after the other: the second half follows below)
-        while (details.load(std::memory_order_acquire) < 2) std::this_thread::yield();
+        details.wait_for(2);
         if (rcs[i ^ 1]) return;                                   // the other chain failed (its error is reported)
         const int nf = (int)(c->cfg.max_keypoints * (255.0 / std::max(d[0], d[1])));
         if (orb.detect_finish(nf, st, i ? k2 : k1) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
@@ -271,7 +275,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     } else {
         c->setup_worker.run([&]() { chain_of(1); });
         chain_of(0);
-        c->setup_worker.wait();
+        if (!c->setup_worker.wait()) { c->err = "pair set-up helper thread: " + c->setup_worker.error(); return POPPY_E_DEVICE; }
     }
     c->foreground_b.medians_done = nullptr;
     if (!align_first) HIPCHK(c, hipStreamSynchronize(c->copy_stream));                // gabor2 is in place
@@ -285,7 +289,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         int r1 = 0, r2 = 0;
         c->setup_worker.run([&]() { r2 = hipSetDevice(c->device) == hipSuccess ? c->orb_b.detect_finish(nfeatures, c->aux_stream, k2) : -2; });
         r1 = c->orb.detect_finish(nfeatures, c->stream, k1);
-        c->setup_worker.wait();
+        if (!c->setup_worker.wait()) { c->err = "pair set-up helper thread: " + c->setup_worker.error(); return POPPY_E_DEVICE; }
         if (r1 < 0 || r2 < 0) { c->err = "orb_detect: " + (r1 < 0 ? c->orb.err : c->orb_b.err); return POPPY_E_DEVICE; }
     }
     ms_detect = since(t_begin);

@@ -37,6 +37,7 @@ extern "C" {
 void poppy_settings_default(poppy_settings* s) {
     s->number_of_frames = 60; s->match_tolerance = 1.0; s->max_keypoints = 300; s->pyramid_levels = 64; s->enable_radial_mask = 0; s->enable_auto_align = 0;
 }
+static std::atomic<int> g_live_contexts{0};        // contexts alive in this process: they share the host's threads for their frame planners
 const char* poppy_hip_create_error(void) { return g_create_error.c_str(); }
 const char* poppy_hip_last_error(const poppy_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
@@ -75,6 +76,7 @@ poppy_hip_ctx* poppy_hip_create(int device, const poppy_settings* settings) {
             g_create_error = "hipStreamCreate failed"; delete c; return nullptr;
         }
     }
+    g_live_contexts.fetch_add(1);
     return c;
 }
 
@@ -101,6 +103,7 @@ static void free_pair(poppy_hip_ctx* c) {
 
 void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (!c) return;
+    g_live_contexts.fetch_sub(1);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)poppy_hip_comm_free(c);
@@ -389,7 +392,11 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     std::vector<std::atomic<int>> ready(n);
     for (auto& r : ready) r.store(0);
     std::atomic<int> next{0};
-    const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency() - 1}));
+    // planner threads of this call: at most 16, and the contexts alive in this process share the host's threads between them (a pool of 3 contexts
+    // x 8 devices would otherwise park ~400 planner threads; the planners of one context keep up with its GPU from ~4 threads: 0.3 ms per plan)
+    const int alive = std::max(1, g_live_contexts.load());
+    const int share = std::max(4, ((int)std::thread::hardware_concurrency() - 1) / alive);
+    const int nthreads = std::max(1, std::min({n, 16, share, (int)std::thread::hardware_concurrency() - 1}));
     const int bin_tw = warp_fast_geometry(W, H) ? warp_bin_tile_width(W, H) : 0;
     auto worker = [&]() {
         for (;;) {
@@ -490,7 +497,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     }
     c->writer_attached = false;
     next.store(n);                         // on an error: let the workers drain
-    c->planners.wait();
+    if (!c->planners.wait() && rc == POPPY_OK) rc = fail(c, POPPY_E_DEVICE, ("frame planner thread: " + c->planners.error()).c_str());
     if (seq_times)
         fprintf(stderr, "sequence of %d frames: %.2f ms; waiting for plans %.2f, submit_frame %.2f (of which waiting for: the slot's download %.2f, its pinned plan %.2f, "
                 "its last frame %.2f, upload + expansion %.2f), waiting for frames to finish %.2f, waiting for downloads %.2f ms\n",

@@ -4,7 +4,9 @@
 #pragma once
 #include <condition_variable>
 #include <functional>
+#include <exception>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -25,11 +27,16 @@ public:
         lk.unlock();
         cv_.notify_all();
     }
-    // returns when the job started last has finished (at once when there is none)
-    void wait() {
+    // returns when the job started last has finished (at once when there is none); false = that job threw (what() in error()): a
+    // std::bad_alloc on a helper thread reaches the caller as a status instead of std::terminate
+    bool wait() {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this]() { return !busy_; });
+        const bool ok = !failed_;
+        failed_ = false;
+        return ok;
     }
+    std::string error() { std::lock_guard<std::mutex> lk(m_); return what_; }
     void stop() {
         {
             std::unique_lock<std::mutex> lk(m_);
@@ -51,8 +58,11 @@ private:
             std::function<void()> job = std::move(job_);
             job_ = nullptr;
             lk.unlock();
-            job();
+            bool threw = false;
+            std::string what;
+            try { job(); } catch (const std::exception& e) { threw = true; what = e.what(); } catch (...) { threw = true; what = "unknown exception"; }
             lk.lock();
+            if (threw) { failed_ = true; what_ = what; }
             busy_ = false;
             cv_.notify_all();
         }
@@ -61,7 +71,8 @@ private:
     std::condition_variable cv_;
     std::thread thread_;
     std::function<void()> job_;
-    bool busy_ = false, quit_ = false;
+    std::string what_;
+    bool busy_ = false, quit_ = false, failed_ = false;
 };
 
 // A team of persistent threads that all run the same job (the frame planners of a multi-frame call: sixteen std::thread per call were
@@ -86,10 +97,15 @@ public:
         lk.unlock();
         cv_.notify_all();
     }
-    void wait() {
+    // false = a member's job threw (error()): see Worker::wait
+    bool wait() {
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [this]() { return pending_ == 0; });
+        const bool ok = !failed_;
+        failed_ = false;
+        return ok;
     }
+    std::string error() { std::lock_guard<std::mutex> lk(m_); return what_; }
     void stop() {
         {
             std::unique_lock<std::mutex> lk(m_);
@@ -112,8 +128,11 @@ private:
             if (id >= active_) continue;                    // this round uses fewer threads
             std::function<void()> job = job_;
             lk.unlock();
-            job();
+            bool threw = false;
+            std::string what;
+            try { job(); } catch (const std::exception& e) { threw = true; what = e.what(); } catch (...) { threw = true; what = "unknown exception"; }
             lk.lock();
+            if (threw) { failed_ = true; what_ = what; }
             if (--pending_ == 0) done_.notify_all();
         }
     }
@@ -121,9 +140,10 @@ private:
     std::condition_variable cv_, done_;
     std::vector<std::thread> threads_;
     std::function<void()> job_;
+    std::string what_;
     unsigned long generation_ = 0;
     int active_ = 0, pending_ = 0;
-    bool quit_ = false;
+    bool quit_ = false, failed_ = false;
 };
 
 }  // namespace poppy_hip

@@ -127,6 +127,31 @@ def point_pairs(w, h, n, seed=5, dup=2, oob=2):
     return a, b
 
 
+def upscale_bgr(img, w, h):
+    """Integer bilinear resize of a u8 image to w x h (16.16 fixed-point source coordinates, pixel centres aligned, result rounded to nearest):
+    defined here, in integers, so that every box makes the same pixels from the committed photo fixture (tests/golden/photo_pair_720x405.npz)."""
+    sh, sw = img.shape[:2]
+    def axis(n_out, n_in):
+        c = ((2 * np.arange(n_out, dtype=np.int64) + 1) * n_in * 32768) // n_out - 32768       # source coordinate of the pixel centre, 16.16
+        c = np.clip(c, 0, (n_in - 1) << 16)
+        i0 = (c >> 16).astype(np.int64)
+        return i0, np.minimum(i0 + 1, n_in - 1), (c & 0xffff).astype(np.int64)
+    y0, y1, fy = axis(h, sh)
+    x0, x1, fx = axis(w, sw)
+    a = img.astype(np.int64)
+    top = a[y0][:, x0] * (65536 - fx)[None, :, None] + a[y0][:, x1] * fx[None, :, None]
+    bot = a[y1][:, x0] * (65536 - fx)[None, :, None] + a[y1][:, x1] * fx[None, :, None]
+    out = (top * (65536 - fy)[:, None, None] + bot * fy[:, None, None] + (1 << 31)) >> 32
+    return out.astype(np.uint8)
+
+
+def photo_pair(w, h):
+    """The reference's own sample photographs (images/amir1.jpg, amir2.jpg; committed as pixels: tests/golden/photo_pair_720x405.npz) at w x h."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "photo_pair_720x405.npz"))
+    return upscale_bgr(z["a"], w, h), upscale_bgr(z["b"], w, h)
+
+
 def fnv1a64(buf):
     """FNV-1a over the raw bytes of an array (used by the golden manifests)."""
     data = np.ascontiguousarray(buf).view(np.uint8).ravel()

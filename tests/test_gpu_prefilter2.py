@@ -63,6 +63,34 @@ def test_pair_begin_from_raw_images_reproduces_poppy_morph(case):
     c.close()
 
 
+@pytest.mark.parametrize("case", ["a_256x256_radial", "a_320x200_radial"])
+def test_pair_begin_with_radial_mask_reproduces_poppy_morph(case):
+    """Settings::enable_radial_mask (the CLI's --radial; src/extractor.cpp:178-197, src/draw.cpp:21-38) against the REAL reference run with the
+    option (fixtures of round 4): the mask table, both foregrounds, nfeatures, the prepared point pairs and every frame of poppy::morph, bit for bit."""
+    from poppy_amd import capi
+    inp = G.astage_inputs(case)
+    assert int(inp["cfg"][3]) == 2                                     # flags: bit 1 = the radial mask
+    h, w = inp["img1"].shape[:2]
+    G.check(case, "radialMask", capi.radial_mask(w, h))
+    c = capi.Context(0, number_of_frames=int(inp["cfg"][0]), enable_radial_mask=1)
+    G.check(case, "goodFeatures1", c.foreground(inp["img1"]))
+    G.check(case, "goodFeatures2", c.foreground(inp["img2"]))
+    nf, det = c.pair_begin(inp["img1"], inp["img2"])
+    ref = G.full(case, "detail")
+    assert nf == int(ref[3]) and det == (ref[0], ref[1])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
+    frames = c.morph_frames(-1.0)
+    assert len(frames) == int(inp["cfg"][0])
+    for j, f in enumerate(frames):
+        G.check(case, f"frame{j}", f)
+    c.close()
+    plain = capi.Context(0, number_of_frames=int(inp["cfg"][0]))       # and the option changes the outcome: without it other features are found
+    assert not np.array_equal(plain.foreground(inp["img1"]), G.full(case, "goodFeatures1"))
+    plain.close()
+
+
 def test_pair_begin_descriptors_mode():
     """Opt-in descriptor matching: the point pairs must be what the reference's sketch (knnMatch k=2 both ways,
     ratioTest 0.7, symmetryTest; src/experiments.hpp:14-144) selects from the reference pipeline's own keypoints, in query

@@ -127,6 +127,55 @@ def test_cfg3_4k_sequence_in_flight_equals_single_frames():
     c.close()
 
 
+def test_cfg3_4k_frames_against_the_oracle():
+    """configs[2]: frames 1, 60 and 120 of the 120-frame 3840x2160 phase-mode sequence, as the GPU hands them to a writer, against the oracle's
+    frames from the same pair state (three oracle frames at 4K: ~10 s)."""
+    import oracle_lib as O
+    from poppy_amd import synth
+    w, h, n = 3840, 2160, 120
+    a, b = synth.gen_pair(w, h, seed=1234)
+    c = _ctx(number_of_frames=1)
+    c.pair_begin(a, b)
+    p1, p2 = c.pair_points()
+    g = c.fetch("gabor2")
+    ts = np.arange(1, n + 1) / float(n + 1)
+    got = {}
+    k = [0]
+
+    def write(f):
+        if k[0] in (0, 59, 119):
+            got[k[0]] = f.copy()
+        k[0] += 1
+    c.render_many(ts, chain=False, write=write)
+    assert k[0] == n and sorted(got) == [0, 59, 119]
+    for j, f in got.items():
+        want, _ = O.morph_images(a, b, g, p1, p2, float(ts[j]), float(ts[j]), 64)
+        assert np.array_equal(want, f), j
+    c.close()
+
+
+def test_writer_and_resident_sequences_alternate_with_a_set_up_between():
+    """Phase-mode sequences WITH a writer run on the context's three compute streams (which are also the pair set-up's), sequences whose frames stay
+    in HBM on per-slot streams: alternating the two kinds, with a pair set-up in between, must not change a frame (the loaders drain every stream)."""
+    case = "a_256x256_phase"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=1)
+    ts = np.arange(1, 10) / 10.0
+    c.pair_begin(inp["img1"], inp["img2"])
+    want = [c.render(float(t), float(t), chain=False).copy() for t in ts]
+    for rnd in range(3):
+        got = []
+        c.render_many(ts, chain=False, write=lambda f: got.append(f.copy()))          # writer: context streams
+        assert len(got) == len(ts) and all(np.array_equal(x, y) for x, y in zip(want, got)), rnd
+        c.render_many(ts, chain=False)                                                  # resident: slot streams
+        assert np.array_equal(c.render(float(ts[-1]), float(ts[-1]), chain=False), want[-1])
+        c.pair_begin(inp["img2"], inp["img1"])                                          # another pair on the same streams ...
+        other = c.render(0.5, 0.5, chain=False).copy()
+        c.pair_begin(inp["img1"], inp["img2"])                                          # ... and back
+        assert not np.array_equal(other, want[4])
+    c.close()
+
+
 def test_distance_flag_writes_nothing():
     case = "a_512x512_chain30"
     inp = G.astage_inputs(case)
@@ -331,7 +380,9 @@ def test_sharded_pair_setup_between_contexts_equals_the_one_gpu_setup(n_ctx, roo
 
 def test_bench_sharded_path_on_a_world_of_one():
     """bench.py's N > 1 code path (library communicator, the two forms of the pair set-up timed and compared, frame shares, cfg5 pairs) on a
-    world of ONE rank over RCCL (POPPY_BENCH_SHARDED_SELFTEST): the only way this box can execute it.  The forms must leave the same point lists."""
+    world of ONE rank over RCCL (POPPY_BENCH_SHARDED_SELFTEST): the only way this box can execute it.  The self-test sets POPPY_HIP_SHARD_WORLD1, so
+    the sharded form IS the protocol (all three roles on rank 0, every broadcast and reduction an RCCL call of the library's dlopen'ed copy, with
+    torch's own RCCL initialised in the same process: the two-copies case), not the world-of-one shortcut.  The forms must leave the same point lists."""
     import json
     import subprocess
     import sys
@@ -347,4 +398,5 @@ def test_bench_sharded_path_on_a_world_of_one():
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
     f = d["setup_forms"]
     assert f["same_point_lists_on_every_rank"] is True and f["used"] in ("sharded", "rank 0 + broadcast")
+    assert f["sharded_protocol_runs_on_rank0"] >= 4          # 1 + 3 timed runs of the protocol itself
     assert d["cfg5_pairs"]["value"] > 0

@@ -144,3 +144,22 @@ def test_oracle_foreground_radial_mask_only_lowers_the_mask():
     assert np.array_equal(rad["acc12"], plain["acc12"]) and np.array_equal(rad["blur12"], plain["blur12"])
     assert (rad["finalMask"] <= plain["finalMask"]).all() and (rad["finalMask"] < plain["finalMask"]).any()
     assert np.array_equal(O.foreground(img)["foreground"], plain["foreground"])    # the switch is off again
+
+
+@pytest.mark.parametrize("case", ["a_256x256_radial", "a_320x200_radial"])
+def test_radial_mask_against_the_reference_run(case):
+    """Round 4: the option is pinned by a run of the real reference with Settings::enable_radial_mask (oracle/golden_gen: flags bit 1): the mask
+    table of the library and of the oracle, and the oracle's foregrounds of both images, against the fixture — bit for bit."""
+    import golden_util as G
+    import oracle_lib as O
+    from poppy_amd import capi
+    inp = G.astage_inputs(case)
+    h, w = inp["img1"].shape[:2]
+    G.check(case, "radialMask", capi.radial_mask(w, h))
+    G.check(case, "radialMask", O.radial_mask(w, h))
+    O.set_radial_mask(True)
+    try:
+        G.check(case, "goodFeatures1", O.foreground(inp["img1"])["foreground"])
+        G.check(case, "goodFeatures2", O.foreground(inp["img2"])["foreground"])
+    finally:
+        O.set_radial_mask(False)

@@ -71,11 +71,13 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_over_gloo(world):
+    """Two and three ranks (three = the number of roles of the sharded pair set-up: image 1, image 2, the mask field)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    world, port = 2, _free_port()
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
