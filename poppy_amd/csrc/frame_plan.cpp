@@ -482,6 +482,8 @@ bool warp_matrix_ok(const float* m, int x0, int x1, int y0, int y1, bool& zero) 
     for (int i = 0; i < 9; ++i) {
         if (!std::isfinite(m[i]) || std::fabs(m[i]) > 1099511627776.f) return false;
         if (m[i] != 0.f) zero = false;
+        // rows 0 and 1 reach the kernel scaled by 32 (pack_warp_records): exact as long as no product is subnormal before the scaling
+        if (i < 6 && m[i] != 0.f && std::fabs(m[i]) < 0x1p-100f) return false;
     }
     if (zero) return true;
     double zlo = 0, zhi = 0;
@@ -513,8 +515,11 @@ bool pack_warp_records(const float* inv1, const float* inv2, int n_tris, int w, 
         bool za, zb;
         ok = warp_matrix_ok(a, x0, x1, y0, y1, za) && ok;
         ok = warp_matrix_ok(b, x0, x1, y0, y1, zb) && ok;
-        rec[0] = a[0]; rec[1] = a[3]; rec[2] = a[1]; rec[3] = a[4]; rec[4] = a[2]; rec[5] = a[5];
-        rec[6] = b[0]; rec[7] = b[3]; rec[8] = b[1]; rec[9] = b[4]; rec[10] = b[2]; rec[11] = b[5];
+        // The numerator rows carry remap's sub-pixel scale: cvRound(32 (m0 x + m1 y + m2) / z) = cvRound((32 m0 x + 32 m1 y + 32 m2) / z) bit for bit — a
+        // power of two commutes with every rounding of the expression (no product is subnormal: warp_matrix_ok) —, which saves the kernels the
+        // multiplication by 32 per coordinate pair (round 4: the fused warp kernel is bound by its arithmetic, profiles/r04_notes.md section 2).
+        rec[0] = 32.f * a[0]; rec[1] = 32.f * a[3]; rec[2] = 32.f * a[1]; rec[3] = 32.f * a[4]; rec[4] = 32.f * a[2]; rec[5] = 32.f * a[5];
+        rec[6] = 32.f * b[0]; rec[7] = 32.f * b[3]; rec[8] = 32.f * b[1]; rec[9] = 32.f * b[4]; rec[10] = 32.f * b[2]; rec[11] = 32.f * b[5];
         rec[12] = a[6]; rec[13] = b[6]; rec[14] = a[7]; rec[15] = b[7];
         rec[16] = za ? 0.00001f : a[8]; rec[17] = zb ? 0.00001f : b[8];
         rec[18] = rec[19] = 0.f;

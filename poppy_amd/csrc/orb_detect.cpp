@@ -67,7 +67,8 @@ hipError_t OrbDetector::prepare(int w, int h) {
         off = (off + 255) & ~(size_t)255; soff = (soff + 255) & ~(size_t)255;
     }
     atlas_bytes = off;
-    cap = std::max(4096, w * h / 16);
+    static const int forced_cap = getenv("POPPY_ORB_CAP") ? std::max(16, atoi(getenv("POPPY_ORB_CAP"))) : 0;   // tests: make the first lists too short
+    cap = forced_cap ? forced_cap : std::max(4096, w * h / 16);
     kp_cap = 1 << 16;
     hipError_t e;
     if ((e = hipMalloc((void**)&d_img, (size_t)w * h)) != hipSuccess) return e;
@@ -89,6 +90,21 @@ hipError_t OrbDetector::prepare(int w, int h) {
     return hipSuccess;
 }
 
+// room for new_cap candidates per level (device lists + their pinned mirror); the level geometry stays
+hipError_t OrbDetector::grow_candidates(int new_cap) {
+    if (new_cap <= cap) return hipSuccess;
+    if (d_counters) (void)hipFree(d_counters);
+    if (h_cand) (void)hipHostFree(h_cand);
+    d_counters = d_cand = nullptr; h_cand = nullptr;
+    cap = new_cap;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_counters, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
+    d_cand = d_counters + kCandHeader;
+    if ((e = hipHostMalloc((void**)&h_cand, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
+    last_total = 0;
+    return hipSuccess;
+}
+
 #define ORB_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return -2; } } while (0)
 
 int OrbDetector::detect(const uint8_t* gray, size_t stride, int w, int h, int nfeatures, hipStream_t s, std::vector<OrbKeyPoint>& out,
@@ -107,19 +123,29 @@ int OrbDetector::detect_begin(const uint8_t* gray, size_t stride, int w, int h, 
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin_).count(); };
     ORB_CHK(hipMemcpy2DAsync(d_img, w, gray, stride, w, h, gray_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_orb_pyramid(d_img, w, h, w, d_atlas, S, s);
-    launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, d_nms, s);
-    // The counts and the candidates come back in one copy: its length is a guess — a quarter more than the last image's candidates (pairs
-    // follow each other with similar images), 1/32 of the pixels the first time — and a second copy fetches the rest when the guess was short.
-    const size_t room = (size_t)kOrbLevels * cap;
     static const long forced_guess = getenv("POPPY_ORB_GUESS") ? atol(getenv("POPPY_ORB_GUESS")) : -1;       // tests: make the first copy short
-    const size_t guess = std::min(room, forced_guess >= 0 ? (size_t)forced_guess : last_total ? last_total + last_total / 4 + 1024 : (size_t)w * h / 32 + 1024);
-    ORB_CHK(hipMemcpyAsync(h_cand, d_counters, (kCandHeader + guess * 2) * sizeof(int), hipMemcpyDeviceToHost, s));
-    ORB_CHK(hipStreamSynchronize(s));
+    size_t guess = 0, total = 0;
+    const int* h_counts = nullptr;
+    // The candidate lists have room for one pixel in sixteen per level (flat shapes: 1 in 80; a photograph: 1 in 300).  Noise-like content after
+    // the pre-filter's equalizeHist can exceed that (strict 3 x 3 maxima: at most 1 in 4): the counters hold the true counts, so the lists are
+    // then re-allocated for what was counted and FAST runs once more — a slow first image of such content instead of an error.
+    for (int attempt = 0; ; ++attempt) {
+        launch_fast(d_atlas, S, d_scores, fastThreshold, edge, d_counters, d_cand, cap, d_nms, s);
+        // The counts and the candidates come back in one copy: its length is a guess — a quarter more than the last image's candidates (pairs
+        // follow each other with similar images), 1/32 of the pixels the first time — and a second copy fetches the rest when the guess was short.
+        const size_t room = (size_t)kOrbLevels * cap;
+        guess = std::min(room, forced_guess >= 0 ? (size_t)forced_guess : last_total ? last_total + last_total / 4 + 1024 : (size_t)w * h / 32 + 1024);
+        ORB_CHK(hipMemcpyAsync(h_cand, d_counters, (kCandHeader + guess * 2) * sizeof(int), hipMemcpyDeviceToHost, s));
+        ORB_CHK(hipStreamSynchronize(s));
+        h_counts = h_cand;
+        int most = 0;
+        for (int l = 0; l < kOrbLevels; ++l) most = std::max(most, h_counts[l]);
+        if (most <= cap) break;
+        if (attempt) { err = "FAST candidate buffer overflow"; return -1; }
+        ORB_CHK(grow_candidates(most + most / 8 + 1024));
+    }
     ms_fast_ = since();
-    const int* h_counts = h_cand;
-    size_t total = 0;
     for (int l = 0; l < kOrbLevels; ++l) {
-        if (h_counts[l] > cap) { err = "FAST candidate buffer overflow"; return -1; }
         level_base_[l] = total;
         total += (size_t)h_counts[l];
     }

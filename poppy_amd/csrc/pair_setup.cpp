@@ -177,6 +177,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     if (!c) return POPPY_E_ARG;
     if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    const auto t_enter = std::chrono::steady_clock::now();
     int rc = alloc_pair(c, W, H); if (rc) return rc;
     c->pair_ready = false;
     c->c2_raw_valid = false;
@@ -358,8 +359,8 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     rc = finish_pair_load(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (stage_times)
-        fprintf(stderr, "pair set-up %dx%d: upload %.3f, chains %.3f, detect %.3f, match %.3f, finish %.3f ms (cumulative)\n", W, H, ms_upload, ms_chains,
-                ms_detect, ms_match, since(t_begin));
+        fprintf(stderr, "pair set-up %dx%d: upload %.3f, chains %.3f, detect %.3f, match %.3f, finish %.3f ms (cumulative); before them (drain + queueing the raw pair's copies) %.3f ms\n", W, H, ms_upload, ms_chains,
+                ms_detect, ms_match, since(t_begin), std::chrono::duration<double, std::milli>(t_begin - t_enter).count());
     return POPPY_OK;
 }
 

@@ -22,12 +22,11 @@ __device__ __forceinline__ f2 div_core(f2 n, f2 d, f2 r1) {
     return __builtin_elementwise_fma(s1, r1, q1);
 }
 
-// (sx, sy) = cvRound(q * 32) for both coordinates; out-of-range values come back far outside any image
+// (sx, sy) = cvRound(v) for both coordinates, v = 32 x the map coordinate (the records' numerator rows are scaled by 32 on the host:
+// pack_warp_records); out-of-range values come back far outside any image
 // (Dropping the two clamps behind a host-side bound on the quotients was measured: same kernel time, and the bound sent 8 % of the
 // frames of a real pair — sliver triangles — to the general kernel.)
-__device__ __forceinline__ void to_fixed(f2 q, int& sx, int& sy) {
-    const f2 k32 = {32.f, 32.f};
-    f2 v = q * k32;
+__device__ __forceinline__ void to_fixed(f2 v, int& sx, int& sy) {
     v.x = __builtin_amdgcn_fmed3f(v.x, -2097152.f, 2097152.f);
     v.y = __builtin_amdgcn_fmed3f(v.y, -2097152.f, 2097152.f);
     const f2 magic = {12582912.f, 12582912.f};
@@ -77,8 +76,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 // footprint on or over the image border: the byte-wise definition, from the record's matrix
 __device__ __forceinline__ uint32_t slow_pixel(const float* __restrict__ rec, int src, const uint8_t* __restrict__ img, int W, int H, int x, int y) {
     float h[9];
-    if (src == 0) { h[0] = rec[0]; h[3] = rec[1]; h[1] = rec[2]; h[4] = rec[3]; h[2] = rec[4]; h[5] = rec[5]; }
-    else          { h[0] = rec[6]; h[3] = rec[7]; h[1] = rec[8]; h[4] = rec[9]; h[2] = rec[10]; h[5] = rec[11]; }
+    const float u = 0.03125f;                                     // the numerator rows are stored times 32: exact to undo
+    if (src == 0) { h[0] = rec[0] * u; h[3] = rec[1] * u; h[1] = rec[2] * u; h[4] = rec[3] * u; h[2] = rec[4] * u; h[5] = rec[5] * u; }
+    else          { h[0] = rec[6] * u; h[3] = rec[7] * u; h[1] = rec[8] * u; h[4] = rec[9] * u; h[2] = rec[10] * u; h[5] = rec[11] * u; }
     h[6] = rec[12 + src]; h[7] = rec[14 + src]; h[8] = rec[16 + src];
     float mx, my;
     map_point(h, x, y, mx, my);
@@ -147,8 +147,21 @@ __device__ __forceinline__ void warp_taps(float4 A, float4 B, float4 C, float4 D
     const f2 r0 = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
     const f2 e0 = __builtin_elementwise_fma(-z, r0, one2);
     const f2 r1 = __builtin_elementwise_fma(e0, r0, r0);
-    const f2 q1 = div_core(n1, f2{z.x, z.x}, f2{r1.x, r1.x});
-    const f2 q2 = div_core(n2, f2{z.y, z.y}, f2{r1.y, r1.y});
+    // the two sources' division chains step by step side by side: a dependent packed-fp32 instruction directly behind its producer costs a hazard
+    // s_nop (0.8 issue cycles each beside half-rate instructions: tools/micro/issue_mix.hip), 10 of them per pixel when one chain follows the other
+    const f2 d1 = {z.x, z.x}, d2 = {z.y, z.y}, ra = {r1.x, r1.x}, rb = {r1.y, r1.y};
+    // (the empty asm statements pin the lock-step order: left alone, the scheduler runs one chain after the other)
+#define POPPY_PAIR_HERE(a, b) asm volatile("" : "+v"(a), "+v"(b))
+    f2 qa = n1 * ra, qb = n2 * rb;
+    POPPY_PAIR_HERE(qa, qb);
+    f2 sa = __builtin_elementwise_fma(-d1, qa, n1), sb = __builtin_elementwise_fma(-d2, qb, n2);
+    POPPY_PAIR_HERE(sa, sb);
+    qa = __builtin_elementwise_fma(sa, ra, qa); qb = __builtin_elementwise_fma(sb, rb, qb);
+    POPPY_PAIR_HERE(qa, qb);
+    sa = __builtin_elementwise_fma(-d1, qa, n1); sb = __builtin_elementwise_fma(-d2, qb, n2);
+    POPPY_PAIR_HERE(sa, sb);
+    const f2 q1 = __builtin_elementwise_fma(sa, ra, qa), q2 = __builtin_elementwise_fma(sb, rb, qb);
+#undef POPPY_PAIR_HERE
     int sx, sy;
     to_fixed(q1, sx, sy);
     t0 = make_fast_tap(sx, sy, W, H);

@@ -142,7 +142,7 @@ def upscale_bgr(img, w, h):
     top = a[y0][:, x0] * (65536 - fx)[None, :, None] + a[y0][:, x1] * fx[None, :, None]
     bot = a[y1][:, x0] * (65536 - fx)[None, :, None] + a[y1][:, x1] * fx[None, :, None]
     out = (top * (65536 - fy)[:, None, None] + bot * fy[:, None, None] + (1 << 31)) >> 32
-    return out.astype(np.uint8)
+    return np.ascontiguousarray(out.astype(np.uint8))            # (the fancy indexing above leaves a transposed memory order)
 
 
 def photo_pair(w, h):

@@ -129,11 +129,12 @@ def test_warp_records_layout_and_admission():
     i1 = plan["inv1"].reshape(-1, 9); i2 = plan["inv2"].reshape(-1, 9)
     rec, ok = capi.warp_records(i1, i2, w, h)
     assert ok and rec.shape == (len(i1) + 1, 20)
-    ident = np.zeros(20, np.float32); ident[[0, 3, 6, 9, 16, 17]] = 1
+    ident = np.zeros(20, np.float32); ident[[0, 3, 6, 9]] = 32; ident[[16, 17]] = 1
     assert np.array_equal(rec[0], ident)
-    # a = inv1, b = inv2: {h0,h3}a {h1,h4}a {h2,h5}a {h0,h3}b {h1,h4}b {h2,h5}b {h6a,h6b} {h7a,h7b} {h8a,h8b} pad pad
+    # a = inv1, b = inv2: 32 x {h0,h3}a {h1,h4}a {h2,h5}a {h0,h3}b {h1,h4}b {h2,h5}b, then {h6a,h6b} {h7a,h7b} {h8a,h8b} pad pad
+    # (the numerator rows carry remap's sub-pixel scale of 32: an exact scaling, round 4)
     order_a = [0, 3, 1, 4, 2, 5]
-    assert np.array_equal(rec[1:, 0:6], i1[:, order_a]) and np.array_equal(rec[1:, 6:12], i2[:, order_a])
+    assert np.array_equal(rec[1:, 0:6], np.float32(32) * i1[:, order_a]) and np.array_equal(rec[1:, 6:12], np.float32(32) * i2[:, order_a])
     assert np.array_equal(rec[1:, 12:18:2], i1[:, 6:9]) and np.array_equal(rec[1:, 13:18:2], i2[:, 6:9])
     assert not rec[:, 18:].any()
 
@@ -141,6 +142,7 @@ def test_warp_records_layout_and_admission():
     zero = np.zeros((1, 9), np.float32)
     rec, ok = capi.warp_records(zero, one, w, h)              # singular triangle: all-zero inverse, z := 1e-5
     assert ok and rec[1, 16] == np.float32(0.00001) and rec[1, 17] == 1 and not rec[1, 0:6].any()
+    assert not capi.warp_records(np.asarray([[1e-35, 0, 0, 0, 1, 0, 0, 0, 1]], np.float32), one, w, h)[1]    # a numerator entry whose products could be subnormal
 
     def admitted(m):
         return capi.warp_records(np.asarray([m], np.float32), one, w, h)[1]
