@@ -23,11 +23,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Source rows requested POPPY_US_AHEAD steps ahead (1, 3 or 9) and the waves per SIMD the registers must leave room for.  Round 3 ran 3 / 4 (104 VGPRs);
+// round 4: one step ahead needs 88 VGPRs = FIVE waves per SIMD — the 5120 waves of a 4K frame (64 strips x 80 segments of 27 rows) are then resident at once —
+// and the fifth wave hides what the shorter prefetch exposes: 4K 64.4-67.6 -> 60.6-61.0 us on one box (tools/experiments/ab_lib.sh).
 #ifndef POPPY_US_AHEAD
-#define POPPY_US_AHEAD 3
+#define POPPY_US_AHEAD 1
 #endif
 #ifndef POPPY_US_WAVES
-#define POPPY_US_WAVES 4
+#define POPPY_US_WAVES 5
 #endif
 
 namespace poppy_hip {
