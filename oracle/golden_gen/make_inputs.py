@@ -78,6 +78,9 @@ ASTAGE = {
     # round 4: Settings::enable_radial_mask (the CLI's --radial; src/extractor.cpp:178-197, src/draw.cpp:21-38): flags bit 1
     "a_256x256_radial": (256, 256, 3, -1.0, 64, 2, ()),
     "a_320x200_radial": (320, 200, 2, -1.0, 64, 2, (0.5,)),
+    # round 4: content that is not flat shapes — the reference's own sample photographs (tests/golden/photo_pair_720x405.npz, synth.photo_pair) and hash-noise textures
+    "a_320x180_photo": (320, 180, 3, -1.0, 64, 0, (0.5,), "photo"),
+    "a_256x192_textured": (256, 192, 3, -1.0, 64, 0, (), "textured"),
     # (A featureless second image does NOT reach the linear-blend fallback of src/poppy.hpp:125-134: with empty point lists
     #  Matcher::find -> morph_distance -> cv::convexHull throws "total >= 0 && (depth == CV_32F || depth == CV_32S)" first —
     #  tried with the generator.  The fallback expression itself is pinned by x_dissolve_* below.)
@@ -162,6 +165,10 @@ def astage_inputs(name):
     extra = list(t[6]) if len(t) > 6 else []
     variant = t[7] if len(t) > 7 else ""
     a, b = synth.gen_pair(w, h)
+    if variant == "photo":
+        a, b = synth.photo_pair(w, h)
+    if variant == "textured":
+        a, b = synth.textured_bgr(w, h, 7), synth.textured_bgr(w, h, 8)
     if variant == "flat2":                          # a featureless second image: ORB finds nothing, the point lists come back empty
         b = np.full_like(a, 77)                     # (the reference throws on it, see ASTAGE; kept for the library's own error test)
     cfg = [nframes, phase, levels] + ([align] if (align or len(t) > 6) else []) + extra

@@ -106,3 +106,22 @@ def test_printed_morph_distance_host(case):
     u1 = O.make_uniq(O.clip_points(p1, w, h)); u2 = O.make_uniq(O.clip_points(p2, w, h))
     k = min(len(u1), len(u2))
     assert O.morph_distance(u1[:k], u2[:k], w, h) == want
+
+
+@pytest.mark.parametrize("case", ["a_320x180_photo", "a_256x192_textured"])
+def test_whole_morph_on_non_synthetic_content(case):
+    """The oracle on content that is not flat shapes (round 4): the reference's own sample photographs at 320 x 180 and hash-noise textures, against runs of the real
+    reference on the same pixels: nfeatures, details, prepared point pairs, every chained frame bit for bit; gabor2 bit for bit outside the reference's DFT noise around exact
+    zeros (flat regions of the photograph: |value| <= 1e-13 there, 0 in the oracle's direct sums)."""
+    inp = G.astage_inputs(case)
+    n = int(inp["cfg"][0])
+    s = O.pair_setup(inp["img1"], inp["img2"])
+    ref = G.full(case, "detail")
+    assert s["nfeatures"] == int(ref[3]) and s["detail"] == (ref[0], ref[1])
+    G.check(case, "prepared1", s["points1"])
+    G.check(case, "prepared2", s["points2"])
+    g = G.full(case, "gabor2")
+    bad = g.view(np.uint32) != s["gabor2"].view(np.uint32)
+    assert ((np.abs(g[bad]) <= 1e-12) & (np.abs(s["gabor2"][bad]) <= 1e-12)).all(), int(bad.sum())
+    for j, f in enumerate(O.morph(inp["img1"], inp["img2"], n, setup=s)):
+        G.check(case, f"frame{j}", f)
