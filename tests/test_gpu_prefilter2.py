@@ -92,10 +92,15 @@ def test_pair_begin_with_radial_mask_reproduces_poppy_morph(case):
 
 
 def _gabor2_matches(ref, got):
-    """gabor2 against the reference's: bit for bit, except where the exact correlation sum is 0 (flat regions of a photograph): there the reference holds the noise of
-    its double-precision DFTs (|value| <= 1e-13) and a restatement holds 0 or its own noise — both vanish in m2 = 1 - gray(gabor2)."""
+    """gabor2 against the reference's: bit for bit, with two documented exceptions.  (1) Where the exact correlation sum is 0 (flat regions of a
+    photograph) the reference holds the noise of its double-precision DFTs (|value| <= 1e-13) and a restatement holds 0 or its own noise — both vanish in
+    m2 = 1 - gray(gabor2).  (2) Where the exact sum sits within the DFT noise of a float rounding boundary, a double-precision FFT correlation (the reference's, the library's
+    default form) can land on either neighbour: one ulp, about one float in 1e8.  Returns (ok, floats of kind 1, floats of kind 2)."""
     bad = ref.view(np.uint32) != got.view(np.uint32)
-    return bool(((np.abs(ref[bad]) <= 1e-12) & (np.abs(got[bad]) <= 1e-12)).all()), int(bad.sum())
+    zero_noise = bad & (np.abs(ref) <= 1e-12) & (np.abs(got) <= 1e-12)
+    rest = bad & ~zero_noise
+    one_ulp = rest & (np.abs(ref.view(np.int32).astype(np.int64) - got.view(np.int32).astype(np.int64)) <= 1)
+    return bool((rest == one_ulp).all()) and int(one_ulp.sum()) <= 4, int(zero_noise.sum()), int(one_ulp.sum())
 
 
 @pytest.mark.parametrize("case", ["a_320x180_photo", "a_256x192_textured"])
@@ -115,8 +120,14 @@ def test_whole_morph_on_non_synthetic_content(case):
     p1, p2 = c.pair_points()
     G.check(case, "prepared1", p1)
     G.check(case, "prepared2", p2)
-    ok, ndiff = _gabor2_matches(G.full(case, "gabor2"), c.fetch("gabor2"))
-    assert ok, ndiff
+    ok, n_zero, n_ulp = _gabor2_matches(G.full(case, "gabor2"), c.fetch("gabor2"))
+    assert ok, (n_zero, n_ulp)
+    cd = capi.Context(0, number_of_frames=n)                           # the direct double sums: no one-ulp case left
+    cd.set_gabor_direct(True)
+    cd.pair_begin(inp["img1"], inp["img2"])
+    ok, n_zero, n_ulp = _gabor2_matches(G.full(case, "gabor2"), cd.fetch("gabor2"))
+    assert ok and n_ulp == 0, (n_zero, n_ulp)
+    cd.close()
     frames = c.morph_frames(-1.0)
     assert len(frames) == n
     for j, f in enumerate(frames):
