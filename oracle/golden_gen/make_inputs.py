@@ -81,6 +81,7 @@ ASTAGE = {
     # round 4: content that is not flat shapes — the reference's own sample photographs (tests/golden/photo_pair_720x405.npz, synth.photo_pair) and hash-noise textures
     "a_320x180_photo": (320, 180, 3, -1.0, 64, 0, (0.5,), "photo"),
     "a_256x192_textured": (256, 192, 3, -1.0, 64, 0, (), "textured"),
+    "a_1920x1080_photo60": (1920, 1080, 60, -1.0, 64, 0, (), "photo"),    # BASELINE.json configs[1] on the photographs: frames pinned by sha256
     # (A featureless second image does NOT reach the linear-blend fallback of src/poppy.hpp:125-134: with empty point lists
     #  Matcher::find -> morph_distance -> cv::convexHull throws "total >= 0 && (depth == CV_32F || depth == CV_32S)" first —
     #  tried with the generator.  The fallback expression itself is pinned by x_dissolve_* below.)

@@ -69,7 +69,8 @@ hipError_t OrbDetector::prepare(int w, int h) {
     atlas_bytes = off;
     static const int forced_cap = getenv("POPPY_ORB_CAP") ? std::max(16, atoi(getenv("POPPY_ORB_CAP"))) : 0;   // tests: make the first lists too short
     cap = forced_cap ? forced_cap : std::max(4096, w * h / 16);
-    kp_cap = 1 << 16;
+    static const int forced_kp = getenv("POPPY_ORB_KPCAP") ? std::max(16, atoi(getenv("POPPY_ORB_KPCAP"))) : 0;    // tests: make the keypoint buffers too small
+    kp_cap = forced_kp ? forced_kp : 1 << 16;
     hipError_t e;
     if ((e = hipMalloc((void**)&d_img, (size_t)w * h)) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&d_atlas, off)) != hipSuccess) return e;
@@ -87,6 +88,25 @@ hipError_t OrbDetector::prepare(int w, int h) {
     if ((e = hipHostMalloc((void**)&h_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
     if ((e = hipHostMalloc((void**)&h_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
     W = w; H = h;
+    return hipSuccess;
+}
+
+// room for n keypoints (positions, responses / angles, descriptors; device buffers and their pinned mirrors)
+hipError_t OrbDetector::grow_keypoints(int n) {
+    if (n <= kp_cap) return hipSuccess;
+    if (d_kp) (void)hipFree(d_kp);
+    if (d_val) (void)hipFree(d_val);
+    if (d_desc) (void)hipFree(d_desc);
+    if (h_kp) (void)hipHostFree(h_kp);
+    if (h_val) (void)hipHostFree(h_val);
+    d_kp = nullptr; d_val = nullptr; d_desc = nullptr; h_kp = nullptr; h_val = nullptr;
+    kp_cap = n;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&d_desc, (size_t)kp_cap * 32)) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc((void**)&h_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -218,7 +238,9 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
     }
     ms_sort = since();
     if (all.empty()) return 0;
-    if ((int)all.size() > kp_cap) { err = "keypoint buffer overflow"; return -1; }
+    // retainBest keeps every tie with the n-th response (keypoint.cpp:69-90) and FAST scores are small integers: on noise-like content the survivors
+    // of the first selection can outnumber any fixed buffer — the keypoint buffers grow to what was selected
+    if ((int)all.size() > kp_cap) ORB_CHK(grow_keypoints((int)all.size() + (int)all.size() / 4));
 
     auto upload = [&](const std::vector<Cand>& v) -> hipError_t {
         for (size_t i = 0; i < v.size(); ++i) { h_kp[3 * i] = v[i].level; h_kp[3 * i + 1] = v[i].x; h_kp[3 * i + 2] = v[i].y; }
@@ -264,7 +286,7 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
 int OrbDetector::describe(const uint8_t* gray, size_t stride, int w, int h, const float* kps7, int n, hipStream_t s, uint8_t* desc_out) {
     if (n <= 0) return 0;
     ORB_CHK(prepare(w, h));
-    if (n > kp_cap) { err = "keypoint buffer overflow"; return -1; }
+    if (n > kp_cap) ORB_CHK(grow_keypoints(n));
     int nlev = 0;
     for (int i = 0; i < n; ++i) {
         int oct = (int)kps7[(size_t)i * 7 + 5];

@@ -46,6 +46,7 @@ public:
 private:
     hipError_t prepare(int w, int h);
     hipError_t grow_candidates(int new_cap);
+    hipError_t grow_keypoints(int n);
     Worker helper_, helper2_;                // take level 1 and levels 2..7 of the first retainBest while the caller does level 0
     std::chrono::steady_clock::time_point t_begin_{};
     double ms_fast_ = 0, ms_cand_ = 0;

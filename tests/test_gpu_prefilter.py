@@ -106,13 +106,14 @@ def test_setup_alternative_forms_stay_exact():
     POPPY_MED_WAVES / POPPY_MED_SETS (waves per histogram set and sets per launch of the medians),
     POPPY_ORB_GUESS=0 (the detector's first copy brings the counts only, every candidate comes with the second copy),
     POPPY_ORB_CAP=50 (candidate lists far too short for any image: the detector re-allocates them for the counted candidates and runs FAST again —
-    what noise-like content does to the default lists: round 4, found by timing the set-up on textured images),
+    what noise-like content does to the default lists: round 4, found by timing the set-up on textured images), POPPY_ORB_KPCAP=64 (the
+    same for the keypoint buffers behind the first retainBest, whose ties are unbounded),
     POPPY_GABOR2_FIRST (gabor2 beside the first medians instead of behind the second image's)."""
     import subprocess
     import sys
     forms = [{"POPPY_ACC_STEPS": "0"}, {"POPPY_ACC_STEPS": "1"}, {"POPPY_ACC_STEPS": "2"}, {"POPPY_ACC_STEPS": "4"}, {"POPPY_ACC_STEPS": "6"},
              {"POPPY_MED_WAVES": "1"}, {"POPPY_MED_WAVES": "2"}, {"POPPY_MED_WAVES": "8"}, {"POPPY_MED_SETS": "192"},
-             {"POPPY_ORB_GUESS": "0"}, {"POPPY_ORB_CAP": "50"}, {"POPPY_GABOR2_FIRST": "1"}]
+             {"POPPY_ORB_GUESS": "0"}, {"POPPY_ORB_CAP": "50"}, {"POPPY_ORB_KPCAP": "64"}, {"POPPY_GABOR2_FIRST": "1"}]
     if any(k in os.environ for f in forms for k in f):
         pytest.skip("a form is already forced in this process")
     here = os.path.dirname(os.path.abspath(__file__))

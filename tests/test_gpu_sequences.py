@@ -96,6 +96,26 @@ def test_cfg2_1080p_60_chained_frames_and_phase_frames():
     c1.close()
 
 
+def test_cfg2_1080p_60_chained_frames_of_the_sample_photographs():
+    """BASELINE.json configs[1] on content that is not synthetic: the reference's own sample photographs (images/amir1.jpg / amir2.jpg, committed as pixels, upscaled to
+    1920 x 1080 in integers) through the whole of poppy::morph — nfeatures, the prepared point pairs, the printed morph distance and all 60 chained frames against a run
+    of the real reference on the same pixels (fixture a_1920x1080_photo60, frames by sha256)."""
+    case = "a_1920x1080_photo60"
+    inp = G.astage_inputs(case)
+    c = _ctx(number_of_frames=60)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"])
+    assert rc == 0 and len(frames) == 60
+    nf, det = c.pair_begin_info()
+    ref = G.full(case, "detail")
+    assert nf == int(ref[3]) and det == (ref[0], ref[1])
+    assert dist == float(G.full(case, "printedMorphDist")[0])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1); G.check(case, "prepared2", p2)
+    bad = [j for j, f in enumerate(frames) if G.sha(f) != G.entries(case)[f"frame{j}"]["sha256"]]
+    assert not bad, f"frames {bad} differ from the reference"
+    c.close()
+
+
 def test_cfg3_4k_phase_mode_frame():
     """BASELINE.json configs[2] geometry: one 3840x2160 phase-mode frame of the real reference, from the raw pair."""
     case = "a_3840x2160_phase"
