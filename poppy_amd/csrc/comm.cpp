@@ -537,7 +537,8 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
             rc = poppy_hip_pair_begin_sharded(c, k == 0 ? d_raw : nullptr, k == 0 ? d_raw + P3 : nullptr, W, H, 0);
             if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_NOMATCH, "no point pairs");      // every rank sees the same (empty) point sets
         } else if (n_devices > 1) rc = poppy_hip_pair_broadcast(c, 0, W, H);
-        if (rc != POPPY_OK && past_setup.load() < n_devices) abort_all();      // the exchanges are over once every device is past this point
+        // (POPPY_E_NOMATCH is every device's outcome at once, after its last collective: nothing to unblock)
+        if (rc != POPPY_OK && rc != POPPY_E_NOMATCH && past_setup.load() < n_devices) abort_all();      // the exchanges are over once every device is past this point
         past_setup.fetch_add(1);
         const int lo = (int)((long long)total_frames * k / n_devices), hi = (int)((long long)total_frames * (k + 1) / n_devices);
         if (rc == POPPY_OK && hi > lo) {
