@@ -243,9 +243,13 @@ int poppy_hip_pair_begin_info(poppy_hip_ctx* ctx, int* nfeatures, double* detail
 int poppy_hip_orb_input(poppy_hip_ctx* ctx, const uint8_t* good_features, int width, int height, uint8_t* g, float* us, float* gb, double* detail);
 int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height, float* gabor);
 /* The two Gabor banks (src/util.cpp:31-61: filter2D per angle -> OCV/imgproc/src/templmatch.cpp:566-760, double-precision DFT
- * correlation) run as tiled double-precision FFTs by default; on != 0 selects the direct double sums instead (same planes up to
- * ~1e-15 relative before their rounding to float; the tests compare the two). */
+ * correlation) run as tiled double-precision FFTs by default; on != 0 selects the direct double sums instead.  The two forms give the
+ * same planes in every bit: the transforms are ~1e-15 from the direct sums before the one rounding to float, and the FFT form hands
+ * every pixel with a plane value that close to a float rounding boundary (or to zero) to the direct sums (the tests compare the two).
+ * poppy_hip_gabor_doubt (diagnostic): since the last call on the current device, out[0] plane values near zero, out[1] near a
+ * midpoint, out[2] pixels formed again because of them. */
 int poppy_hip_set_gabor_direct(poppy_hip_ctx* ctx, int on);
+int poppy_hip_gabor_doubt(unsigned long long out[3]);
 int poppy_radial_gradient(int width, int height, float* out);
 int poppy_radial_mask(int width, int height, float* out);
 /* Host-side tables behind two device kernels, exposed for tests that run without a GPU (no reference counterpart):

@@ -50,6 +50,7 @@ private:
     float *f_a = nullptr, *f_b = nullptr, *f_c = nullptr, *f_d = nullptr, *radial = nullptr, *taps17 = nullptr;
     double *bank31 = nullptr, *bank13 = nullptr;
     double *fft31 = nullptr, *fft13 = nullptr;      // the banks' paired kernel spectra (kernels_gabor_fft.hip), null: direct sums only
+    unsigned *doubt_list31 = nullptr, *doubt_list13 = nullptr;   // pixels the FFT form of a bank hands to the direct sums (2 + P, 2 + 3 P words); one per bank: gabor2 runs on another stream beside the image's own chain
     float *mag = nullptr, *c3_in = nullptr, *c3_out = nullptr;
     void* spec = nullptr;
     unsigned* minmax = nullptr;

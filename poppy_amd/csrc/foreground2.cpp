@@ -116,9 +116,9 @@ void radial_gradient(int width, int height, std::vector<float>& out) {
 
 int ForegroundFilter::ensure2(int w, int h) {
     if (w == W2 && h == H2) return 0;
-    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, fft31, fft13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
+    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, fft31, fft13, doubt_list31, doubt_list13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    f_a = f_b = f_c = f_d = radial = taps17 = mag = c3_in = c3_out = nullptr; bank31 = bank13 = fft31 = fft13 = nullptr; spec = nullptr;
+    f_a = f_b = f_c = f_d = radial = taps17 = mag = c3_in = c3_out = nullptr; bank31 = bank13 = fft31 = fft13 = nullptr; doubt_list31 = doubt_list13 = nullptr; spec = nullptr;
     minmax = nullptr; powsum = nullptr; g_tmp = g_out[0] = g_out[1] = nullptr;
     for (void* b : {(void*)spec_tmp, (void*)spec_out, (void*)d_itab[0], (void*)d_itab[1], (void*)d_wave[0], (void*)d_wave[1]}) if (b) (void)hipFree(b);
     spec_tmp = spec_out = nullptr; d_itab[0] = d_itab[1] = nullptr; d_wave[0] = d_wave[1] = nullptr;
@@ -149,6 +149,7 @@ int ForegroundFilter::ensure2(int w, int h) {
         static const std::vector<double> t31 = gabor_fft_tables(b31, 31), t13 = gabor_fft_tables(b13, 13);      // geometry-independent: once per process
         if (!gabor_fft_prepare()) { err = "gabor_fft_prepare failed"; return -2; }
         F2_CHK(hipMalloc((void**)&fft31, t31.size() * 8)); F2_CHK(hipMalloc((void**)&fft13, t13.size() * 8));
+        F2_CHK(hipMalloc((void**)&doubt_list31, (2 + P) * 4)); F2_CHK(hipMalloc((void**)&doubt_list13, (2 + P * 3) * 4));
         F2_CHK(hipMemcpy(fft31, t31.data(), t31.size() * 8, hipMemcpyHostToDevice));
         F2_CHK(hipMemcpy(fft13, t13.data(), t13.size() * 8, hipMemcpyHostToDevice));
     }
@@ -172,7 +173,7 @@ int ForegroundFilter::ensure2(int w, int h) {
 }
 
 void ForegroundFilter::release2() {
-    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, fft31, fft13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
+    void* bufs[] = {f_a, f_b, f_c, f_d, radial, bank31, bank13, fft31, fft13, doubt_list31, doubt_list13, taps17, spec, mag, minmax, powsum, g_tmp, g_out[0], g_out[1], c3_in, c3_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : {(void*)spec_tmp, (void*)spec_out, (void*)d_itab[0], (void*)d_itab[1], (void*)d_wave[0], (void*)d_wave[1]}) if (b) (void)hipFree(b);
     W2 = H2 = 0;
@@ -215,7 +216,7 @@ const uint8_t* ForegroundFilter::orb_input(const uint8_t* d_gf, int w, int h, in
     if (ensure(w, h) || ensure2(w, h)) return nullptr;
     const int n = w * h;
     launch_unsharp1_gray(d_gf, f_a, f_b, f_c, f_d, taps17, w, h, s);       // f_d = us (grey of the unsharp-masked triple)
-    if (fft31 && !gabor_direct) launch_gabor_fft31(f_d, fft31, f_a, w, h, s);                 // f_a = gabor mean
+    if (fft31 && !gabor_direct) launch_gabor_fft31(f_d, fft31, bank31, doubt_list31, f_a, w, h, s);                 // f_a = gabor mean
     else launch_gabor_bank31(f_d, bank31, f_a, w, h, s);
     if (h_us) (void)hipMemcpyAsync(h_us, f_d, (size_t)n * 4, hipMemcpyDeviceToHost, s);
     if (h_gb) (void)hipMemcpyAsync(h_gb, f_a, (size_t)n * 4, hipMemcpyDeviceToHost, s);
@@ -228,7 +229,7 @@ const uint8_t* ForegroundFilter::orb_input(const uint8_t* d_gf, int w, int h, in
 const float* ForegroundFilter::gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s) {
     if (ensure(w, h) || ensure2(w, h)) return nullptr;
     launch_u8_to_f32(d_bgr_packed, c3_in, w * h * 3, s);
-    if (fft13 && !gabor_direct) launch_gabor_fft13_c3(c3_in, fft13, c3_out, w, h, s);
+    if (fft13 && !gabor_direct) launch_gabor_fft13_c3(c3_in, fft13, bank13, doubt_list13, c3_out, w, h, s);
     else launch_gabor_bank13_c3(c3_in, bank13, c3_out, w, h, s);
     if (hipGetLastError() != hipSuccess) { err = "gabor_field launch failed"; return nullptr; }
     return c3_out;

@@ -17,8 +17,10 @@
 // them; a pass reads 8 values of a line from LDS and writes them back in place.  The forward transform leaves frequency
 // k1 + 8 k2 at position 8 k1 + k2; the kernel spectra are stored in that order and the inverse transform consumes it.
 // ~2.3 kFLOP per pixel instead of 30.7 k.  Error: ~1e-15 relative to the magnitude of the sums, two orders below the reference's
-// own DFT noise; the planes are rounded to float afterwards, so the output differs from the direct sums only where an exact sum lies
-// within that distance of a float rounding boundary (none on the fixtures; tests/test_gpu_prefilter2.py compares the two paths).
+// own DFT noise; the planes are rounded to float afterwards, so a plane value could differ from the direct sum's only where the exact
+// sum lies within that distance of a float rounding boundary (one float in ~1e8, seen in round 4's fuzz and on the photograph
+// fixtures) or of zero (the borders of all-black regions).  Those values are detected (rounding_in_doubt) and formed as the direct
+// kernel forms them (k_gabor_redo): the two forms give the same bits; tests/test_gpu_prefilter2.py compares them.
 #include "kernels_prefilter.h"
 #include "pyramid_device.h"
 #include <cmath>
@@ -89,22 +91,119 @@ __device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid) {
     }
 }
 
+// ---- the values whose float could differ from the direct sum's -----------------------------------------------------------------------
+// The transform's planes are ~1e-15 x (the size of the patch) from the direct kernel's sums (k_gabor_bank: an fma chain in double over
+// the taps, row by row; measured on the GPU over ~1e5 such values of photographs, textures and flat shapes at 1080p: at most 1.1e-14 x
+// max(1, the patch's largest magnitude), rms ~1.5e-15).  Rounded to float and clamped to [0, 1], a plane value v contributes the same
+// as the direct sum unless it lies within that distance of the midpoint between two floats, or of zero (the clamp's corner: the noise
+// around an exact zero at the border of a black region would survive it).  `band` is 1e-13 x max(1, the patch's largest magnitude).
+// Not in doubt: v below -band or above 1 + band (clamped either way) and the planes of a window that holds only zeros (exact zeros in
+// the direct sums; the kernel knows such windows from ballots taken while it loads the patch and adds nothing for them).  A pixel
+// with a value in doubt — 1 value in ~1e4, most of them small: a float's neighbours are 2^-24 of its size apart — goes on a list, and
+// k_gabor_redo, launched behind the transform kernel, forms the listed pixels again as the direct kernel forms them: 16 lanes per
+// pixel, one orientation's chain each.  (Re-forming a value inside the transform kernel holds its whole tile at a barrier for the
+// length of a 961-step chain: 0.27 -> 1.1 ms at 1080p; all listed pixels of an image side by side take ~20 us.)
+__device__ unsigned long long g_doubt[3];                     // since the last read: values near zero, near a midpoint; pixels re-formed (poppy_hip_gabor_doubt)
+__device__ __forceinline__ int rounding_in_doubt(double v, double band) {      // 0: no, 1: near zero, 2: near a midpoint
+    if (v < -band || v > 1.0 + band) return 0;
+    if (v < band) return 1;
+    const float f = (float)v;
+    const double lo = (double)__int_as_float(__float_as_int(f) - 1), hi = (double)__int_as_float(__float_as_int(f) + 1), m = (double)f;
+    return (fabs(v - 0.5 * (lo + m)) < band || fabs(v - 0.5 * (m + hi)) < band) ? 2 : 0;
+}
+
+// list[0]: entries, list[2 + e]: (y * W + x) * CN + ch.  A group of 16 lanes takes an entry; lane o of the group runs orientation o's chain.
+// A chain is KS * KS dependent steps, so everything it reads is staged where a step costs an LDS read: the 16 windows of a workgroup's
+// entries once (all loads in flight together), the bank's taps row by row, two rows in LDS, the next one fetched while a row is summed.
+// (With the operands read from global memory as the chain went, a launch took one memory latency per window row: 76 us at 1080p however
+// few the entries; 120 - 145 us with ~7 000.)
 template <int KS>
-__global__ void __launch_bounds__(kFT) k_gabor_fft(const float* __restrict__ src, const cd* __restrict__ G, float* __restrict__ dst,
-                                                   int W, int H, int CN, int tiles_x) {
+__global__ void __launch_bounds__(256) k_gabor_redo(const float* __restrict__ src, const double* __restrict__ bank, const unsigned* __restrict__ list,
+                                                    float* __restrict__ dst, int W, int H, int CN) {
+    constexpr int R = KS / 2, N = KS * KS, RT = KS * 16;      // RT: taps of one window row, [dx][orientation]
+    extern __shared__ __attribute__((aligned(16))) double redo_lds[];
+    double* const taps = redo_lds;                            // [2][RT]
+    float* const win = (float*)(redo_lds + 2 * RT);           // [16][N]
+    const unsigned n = list[0];
+    const int tid = threadIdx.x, o = tid & 15, g = tid >> 4;
+    if (n && blockIdx.x == 0 && tid == 0) atomicAdd(&g_doubt[2], (unsigned long long)n);
+    for (unsigned e0 = blockIdx.x * 16; e0 < n; e0 += gridDim.x * 16) {                 // uniform over the workgroup
+        const bool have = e0 + g < n;
+        const unsigned idx = have ? list[2 + e0 + g] : 0;
+        const int ch = idx % CN, p = idx / CN, y = p / W, x = p - y * W;
+        __syncthreads();                                      // the previous batch's windows and taps have been read
+        if (have)
+            for (int k0 = o; k0 < N; k0 += 16 * 16) {        // 16 loads in flight per lane (a load waited for before the next one is issued costs a latency each: 60 of them)
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = min(k0 + 16 * u, N - 1), dy = k / KS, dx = k - dy * KS;
+                    v[u] = src[((size_t)reflect101(y - R + dy, H) * W + reflect101(x - R + dx, W)) * CN + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (k0 + 16 * u < N) win[g * N + k0 + 16 * u] = v[u];
+            }
+        for (int k = tid; k < RT; k += 256) taps[k] = bank[k];
+        double acc = 0.0;
+#pragma unroll 1                                              // (unrolled, the 961 steps are 30 KB of straight-line code fetched once per batch)
+        for (int dy = 0; dy < KS; ++dy) {
+            __syncthreads();                                  // row dy's taps (and, the first time, the windows) are in LDS
+            double nx0 = 0.0, nx1 = 0.0;                      // row dy + 1's taps: RT <= 512 doubles, at most two per thread
+            if (dy + 1 < KS) {
+                if (tid < RT) nx0 = bank[(size_t)(dy + 1) * RT + tid];
+                if (tid + 256 < RT) nx1 = bank[(size_t)(dy + 1) * RT + tid + 256];
+            }
+            const double* tr = taps + (dy & 1) * RT + o;
+            const float* wr = win + g * N + dy * KS;
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) acc = fma(tr[dx * 16], (double)wr[dx], acc);
+            __builtin_amdgcn_sched_barrier(0);                // the wait for the next row's taps stays behind this row's chain
+            if (dy + 1 < KS) {
+                double* tn = taps + ((dy + 1) & 1) * RT;      // last read two barriers ago
+                if (tid < RT) tn[tid] = nx0;
+                if (tid + 256 < RT) tn[tid + 256] = nx1;
+            }
+        }
+        const float f = fminf(fmaxf((float)acc, 0.f), 1.f);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += __shfl(f, (tid & 48) + k);         // dst += plane, orientation by orientation
+        if (have && o == 0) dst[idx] = sum * 0.0625f;
+    }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ src, const cd* __restrict__ G, unsigned* __restrict__ list,
+                                                   float* __restrict__ dst, int W, int H, int CN, int tiles_x) {
     constexpr int R = KS / 2, B = kFN - KS + 1, kOut = (B * B + kFT - 1) / kFT, kEl = kFN * kFN / kFT;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];      // 64 x 65 complex doubles: just over the static 64 KB limit
     cd* const L = (cd*)lds_raw;
-    const int tid = threadIdx.x;
+    unsigned long long* const rowmask = (unsigned long long*)(lds_raw + 2 * kFN * kFS);   // [64] which pixels of a patch row are not zero; [64..64+B) the same over KS rows
+    float* const wavemax = (float*)(rowmask + 2 * kFN);                                   // [8] the largest magnitude each wave has loaded
+    const int tid = threadIdx.x, lane = tid & 63;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, ch = blockIdx.y;
     const int bx = tx * B, by = ty * B;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < kEl; ++i) {
         const int e = tid + kFT * i, y = e >> 6, x = e & 63;
         const float v = src[((size_t)reflect101(by - R + y, H) * W + reflect101(bx - R + x, W)) * CN + ch];
         L[y * kFS + x] = cd{(double)v, 0.0};
+        const unsigned long long nz = __ballot(v != 0.f);                  // a wave holds one patch row (x = lane)
+        if (x == 0) rowmask[y] = nz;
+        if (KS != 13) amax = fmaxf(amax, fabsf(v));                        // the 13 x 13 bank runs on bytes / 255: at most 1
+    }
+    if (KS != 13) {
+#pragma unroll
+        for (int d = 32; d; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+        if (lane == 0) wavemax[tid >> 6] = amax;
     }
     __syncthreads();
+    if (tid < B) {                                                         // the rows of output row tid's windows together
+        unsigned long long m = 0;
+        for (int dy = 0; dy < KS; ++dy) m |= rowmask[tid + dy];
+        rowmask[kFN + tid] = m;
+    }
     fft_pass<-1, true, true, false>(L, tid);  __syncthreads();
     fft_pass<-1, false, false, false>(L, tid); __syncthreads();
     fft_pass<-1, true, true, true>(L, tid);   __syncthreads();
@@ -112,9 +211,20 @@ __global__ void __launch_bounds__(kFT) k_gabor_fft(const float* __restrict__ src
     cd P[kEl];
 #pragma unroll
     for (int i = 0; i < kEl; ++i) { const int e = tid + kFT * i; P[i] = L[(e >> 6) * kFS + (e & 63)]; }
-    float acc[kOut];
+    amax = 1.f;
+    if (KS != 13) {
 #pragma unroll
-    for (int i = 0; i < kOut; ++i) acc[i] = 0.f;
+        for (int w = 0; w < kFT / 64; ++w) amax = fmaxf(amax, wavemax[w]);
+    }
+    const double band = KS != 13 ? 1e-13 * (double)amax : 1e-13;
+    float acc[kOut];
+    unsigned state = 0;                                                    // bit 2 i: output i is inside the image and not an all-zero window (whose planes are exact zeros: nothing to add); bit 2 i + 1: on the list
+#pragma unroll
+    for (int i = 0; i < kOut; ++i) {
+        acc[i] = 0.f;
+        const int o = tid + kFT * i, ny = o / B, nx = o - ny * B;
+        if (o < B * B && bx + nx < W && by + ny < H && ((rowmask[kFN + min(ny, B - 1)] >> nx) & ((1ull << KS) - 1)) != 0) state |= 1u << (2 * i);
+    }
     for (int j = 0; j < 8; ++j) {
         __syncthreads();                                    // the previous pair's planes (or the spectrum) have been read
         const cd* Gj = G + (size_t)j * (kFN * kFN);
@@ -127,10 +237,15 @@ __global__ void __launch_bounds__(kFT) k_gabor_fft(const float* __restrict__ src
         fft_pass<1, true, false, false>(L, tid);  __syncthreads();
 #pragma unroll
         for (int i = 0; i < kOut; ++i) {
-            const int o = tid + kFT * i;
-            if (o < B * B) {
-                const int ny = o / B, nx = o - ny * B;
+            if (state & (1u << (2 * i))) {
+                const int o = tid + kFT * i, ny = o / B, nx = o - ny * B;
                 const cd c = L[ny * kFS + nx];
+                const int dx_ = rounding_in_doubt(c.x, band), dy_ = rounding_in_doubt(c.y, band);
+                if ((dx_ | dy_) && list) {                                  // rare
+                    if (dx_) atomicAdd(&g_doubt[dx_ - 1], 1ull);
+                    if (dy_) atomicAdd(&g_doubt[dy_ - 1], 1ull);
+                    if (!(state & (2u << (2 * i)))) { state |= 2u << (2 * i); list[2 + atomicAdd(list, 1u)] = (unsigned)(((by + ny) * W + bx + nx) * CN + ch); }
+                }
                 acc[i] += fminf(fmaxf((float)c.x, 0.f), 1.f);            // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
                 acc[i] += fminf(fmaxf((float)c.y, 0.f), 1.f);            // ... orientation 2 j, then 2 j + 1
             }
@@ -193,25 +308,45 @@ std::vector<double> gabor_fft_tables(const std::vector<float>& bank, int ks) {
     return out;
 }
 
-constexpr size_t kFftLds = (size_t)kFN * kFS * sizeof(cd);
+constexpr size_t kFftLds = (size_t)kFN * kFS * sizeof(cd) + (size_t)2 * kFN * sizeof(unsigned long long) + (kFT / 64) * sizeof(float);
+
+// Since the last call, on the current device: plane values of the FFT form [0] within the band of zero, [1] within the band of a float
+// midpoint; [2] pixels formed again as direct sums because of them (diagnostic: tools/experiments/setup_content.py prints them).
+bool gabor_fft_doubt(unsigned long long out[3]) {
+    const unsigned long long zero[3] = {0, 0, 0};
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_doubt), sizeof(zero)) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_doubt), zero, sizeof(zero)) == hipSuccess;
+}
+
+constexpr size_t redo_lds_bytes(int ks) { return (size_t)2 * ks * 16 * sizeof(double) + (size_t)16 * ks * ks * sizeof(float); }
 
 bool gabor_fft_prepare() {                                     // the twiddle table and the kernels' LDS limit on this device (idempotent)
     double w[2 * kFN];
     for (int m = 0; m < kFN; ++m) { w[2 * m] = (double)cosl(2.0L * M_PIl * m / kFN); w[2 * m + 1] = (double)-sinl(2.0L * M_PIl * m / kFN); }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_w64), w, sizeof(w)) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void*)k_gabor_fft<31>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLds) != hipSuccess) return false;
-    return hipFuncSetAttribute((const void*)k_gabor_fft<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLds) == hipSuccess;
+    if (hipFuncSetAttribute((const void*)k_gabor_fft<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLds) != hipSuccess) return false;
+    return hipFuncSetAttribute((const void*)k_gabor_redo<31>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)redo_lds_bytes(31)) == hipSuccess;
 }
 
-void launch_gabor_fft31(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s) {
+// POPPY_GABOR_NO_REDO (measurement aid): the transform alone, as until round 4 — a plane value in ~1e8 then lands on the other neighbouring float
+static bool gabor_redo_on() { static const bool on = getenv("POPPY_GABOR_NO_REDO") == nullptr; return on; }
+
+// list: 2 + w * h * channels words, device (this launch resets and fills it; k_gabor_redo reads it)
+void launch_gabor_fft31(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s) {
     constexpr int B = kFN - 31 + 1;
     const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
-    hipLaunchKernelGGL(k_gabor_fft<31>, dim3(tiles_x * tiles_y, 1), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, dst, w, h, 1, tiles_x);
+    if (!gabor_redo_on()) d_list = nullptr;
+    if (d_list) (void)hipMemsetAsync(d_list, 0, 4, s);
+    hipLaunchKernelGGL(k_gabor_fft<31>, dim3(tiles_x * tiles_y, 1), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 1, tiles_x);
+    if (d_list) hipLaunchKernelGGL(k_gabor_redo<31>, dim3(512), dim3(256), redo_lds_bytes(31), s, src, d_bank, d_list, dst, w, h, 1);
 }
-void launch_gabor_fft13_c3(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s) {
+void launch_gabor_fft13_c3(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s) {
     constexpr int B = kFN - 13 + 1;
     const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
-    hipLaunchKernelGGL(k_gabor_fft<13>, dim3(tiles_x * tiles_y, 3), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, dst, w, h, 3, tiles_x);
+    if (!gabor_redo_on()) d_list = nullptr;
+    if (d_list) (void)hipMemsetAsync(d_list, 0, 4, s);
+    hipLaunchKernelGGL(k_gabor_fft<13>, dim3(tiles_x * tiles_y, 3), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 3, tiles_x);
+    if (d_list) hipLaunchKernelGGL(k_gabor_redo<13>, dim3(512), dim3(256), redo_lds_bytes(13), s, src, d_bank, d_list, dst, w, h, 3);
 }
 
 }  // namespace poppy_hip

@@ -61,9 +61,12 @@ void launch_gabor_bank13_c3(const float* src, const double* d_bank, float* dst, 
 // The same banks by tiled 64 x 64 double-precision FFTs (kernels_gabor_fft.hip).  gabor_fft_tables: the paired, conjugated kernel
 // spectra of a bank ([orientation][ks * ks] floats), 8 x 4096 complex doubles, computed on the host; gabor_fft_prepare: per device.
 std::vector<double> gabor_fft_tables(const std::vector<float>& bank, int ks);
+// d_list (2 + w * h * channels words): the pixels with a plane value too close to a float rounding boundary for the transform to decide; the
+// launch re-forms them as the direct sums (d_bank: the direct kernels' table), so both forms give the same bits.
 bool gabor_fft_prepare();
-void launch_gabor_fft31(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s);
-void launch_gabor_fft13_c3(const float* src, const double* d_tables, float* dst, int w, int h, hipStream_t s);
+bool gabor_fft_doubt(unsigned long long out[3]);
+void launch_gabor_fft31(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s);
+void launch_gabor_fft13_c3(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s);
 void launch_u8_to_f32(const uint8_t* src, float* dst, int n, hipStream_t s);
 // out = equalizeHist(u8(gb * us * radial * 255))
 void launch_orb_input(const float* gb, const float* us, const float* radial, uint8_t* tmp_u8, unsigned* hist, uint8_t* lut, uint8_t* out,

@@ -417,6 +417,8 @@ int poppy_hip_set_gabor_direct(poppy_hip_ctx* c, int on) {
     return POPPY_OK;
 }
 
+int poppy_hip_gabor_doubt(unsigned long long out[3]) { return out && gabor_fft_doubt(out) ? POPPY_OK : POPPY_E_DEVICE; }
+
 // gabor_filter(bgr / 255) with the default arguments (host in / out, f32x3)
 int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, int W, int H, float* out) {
     if (!c || !bgr || !out || W <= 0 || H <= 0 || stride < (size_t)W * 3) return POPPY_E_ARG;

@@ -35,19 +35,10 @@ for i in range(cases):
     else:
         ok = (nf == st["nfeatures"] and p1.shape == st["points1"].shape and np.array_equal(p1.view(np.uint32), st["points1"].view(np.uint32))
               and np.array_equal(p2.view(np.uint32), st["points2"].view(np.uint32)) and np.array_equal(g.view(np.uint32), st["gabor2"].view(np.uint32)))
-        if not ok and nf == st["nfeatures"] and p1.shape == st["points1"].shape and np.array_equal(p1, st["points1"]) and np.array_equal(p2, st["points2"]):
-            # everything but gabor2 agrees: the documented cases of the FFT form — a float within the DFT noise of a rounding boundary lands on the
-            # other neighbour (1 ulp), or an exact zero comes back as noise — are counted apart from mismatches
-            gb = g.view(np.uint32) != st["gabor2"].view(np.uint32)
-            ulp = np.abs(g.view(np.int32).astype(np.int64) - st["gabor2"].view(np.int32).astype(np.int64))
-            if bool(((ulp[gb] <= 1) | ((np.abs(g[gb]) <= 1e-12) & (np.abs(st["gabor2"][gb]) <= 1e-12))).all()) and int(gb.sum()) <= 4:
-                print(f"case {i} {w}x{h} seed {s}: gabor2 differs in {int(gb.sum())} float(s) by at most one ulp / zero noise (FFT form), everything else equal")
-                tolerated = globals().get("tolerated", 0) + 1; globals()["tolerated"] = tolerated
-                ok = True
         if not ok:
             print(f"case {i} {w}x{h} seed {s}: MISMATCH nfeatures {nf} vs {st['nfeatures']}, points {p1.shape} vs {st['points1'].shape}, "
                   f"gabor2 differing {(g.view(np.uint32) != st['gabor2'].view(np.uint32)).sum() if g.shape == st['gabor2'].shape else 'shape'}"
                   + (f" (largest difference {np.abs(g.view(np.int32).astype(np.int64) - st['gabor2'].view(np.int32).astype(np.int64)).max()} ulp; points equal: "
                      f"{np.array_equal(p1, st['points1']) and np.array_equal(p2, st['points2'])})" if g.shape == st['gabor2'].shape and p1.shape == st['points1'].shape else ""))
     bad += 0 if ok else 1
-print(f"{cases} cases, {bad} mismatches, {globals().get('tolerated', 0)} with a one-ulp gabor2 float, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")

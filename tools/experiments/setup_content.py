@@ -13,6 +13,7 @@ a, b = {"synthetic": lambda: synth.gen_pair(w, h, seed=1234), "textured": lambda
         "photo": lambda: synth.photo_pair(w, h)}[kind]()
 c = capi.Context(0, number_of_frames=60)
 c.pair_begin(a, b)
+print(f"Gabor banks in one set-up (plane values near zero, near a midpoint, pixels formed again as direct sums): {capi.gabor_doubt()}")
 t = []
 for _ in range(reps):
     t0 = time.perf_counter(); nf, det = c.pair_begin(a, b); t.append((time.perf_counter() - t0) * 1e3)
