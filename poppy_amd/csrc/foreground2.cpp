@@ -150,8 +150,16 @@ int ForegroundFilter::ensure2(int w, int h) {
         if (!gabor_fft_prepare()) { err = "gabor_fft_prepare failed"; return -2; }
         F2_CHK(hipMalloc((void**)&fft31, t31.size() * 8)); F2_CHK(hipMalloc((void**)&fft13, t13.size() * 8));
         F2_CHK(hipMalloc((void**)&doubt_list31, (2 + P) * 4)); F2_CHK(hipMalloc((void**)&doubt_list13, (2 + P * 3) * 4));
-        F2_CHK(hipMemcpy(fft31, t31.data(), t31.size() * 8, hipMemcpyHostToDevice));
-        F2_CHK(hipMemcpy(fft13, t13.data(), t13.size() * 8, hipMemcpyHostToDevice));
+        // on the device each pair's spectrum lies transposed ([column][row]): the kernel holds the patch spectrum as row `lane`, columns 8 g + i
+        auto transposed = [](const std::vector<double>& t) {
+            std::vector<double> o(t.size());
+            for (int j = 0; j < 8; ++j) for (int r = 0; r < 64; ++r) for (int c = 0; c < 64; ++c)
+                for (int k = 0; k < 2; ++k) o[(((size_t)j * 64 + c) * 64 + r) * 2 + k] = t[(((size_t)j * 64 + r) * 64 + c) * 2 + k];
+            return o;
+        };
+        static const std::vector<double> d31 = transposed(t31), d13 = transposed(t13);
+        F2_CHK(hipMemcpy(fft31, d31.data(), d31.size() * 8, hipMemcpyHostToDevice));
+        F2_CHK(hipMemcpy(fft13, d13.data(), d13.size() * 8, hipMemcpyHostToDevice));
     }
     F2_CHK(hipMemcpy(radial, rad.data(), P * 4, hipMemcpyHostToDevice));
     dftN = dft_optimal_size(w); dftM = dft_optimal_size(h);

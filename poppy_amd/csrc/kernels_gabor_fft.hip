@@ -13,6 +13,11 @@
 //   per PAIR of orientations (a, b): spectrum x (conj K_a^ + i conj K_b^) / 4096, inverse 2-D FFT: the real part is orientation a's
 //   plane, the imaginary part orientation b's (both are real) — 8 inverse transforms serve the 16 orientations;
 //   clamp, accumulate in float in the reference's order (a then b), write mean.
+// Round 4: the forward transform runs columns then rows and the inverse ones rows then columns, so that (1) the patch spectrum stays in
+// the registers of the forward transform's last pass — the inverse transforms' first pass is the same job on the same elements — and is
+// multiplied by a pair's kernel spectrum there, and (2) the planes leave the last inverse pass in registers with a wave's lanes along x:
+// clamp, accumulate and the final store need no LDS.  56 LDS phases per tile instead of 89, 9 barriers fewer: alone on the GPU at 1080p
+// 257 -> 226 us (31 x 31), 306 -> 252 us (13 x 13 x 3) (`tools/experiments/gabor_ab.sh`).
 // A 64-point transform is two passes of 8-point butterflies held in registers (64 = 8 x 8) with the twiddle W64^(n2 k1) between
 // them; a pass reads 8 values of a line from LDS and writes them back in place.  The forward transform leaves frequency
 // k1 + 8 k2 at position 8 k1 + k2; the kernel spectra are stored in that order and the inverse transform consumes it.
@@ -64,32 +69,35 @@ __device__ __forceinline__ void fft8(cd (&v)[8]) {
 // One pass over all 64 lines of the 64 x 64 array: 512 jobs (line, g), two per thread; a job transforms the 8 elements
 // {8 i + g} (STRIDED) or {8 g + i} of its line in place and, with TWIDDLE, multiplies output i by W64^(SIGN g i).
 // COLS: the lines are the columns.  A wave's 64 lanes are 64 consecutive lines with one g.
-template <int SIGN, bool STRIDED, bool TWIDDLE, bool COLS>
-__device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid) {
+// LOAD = false: the job's inputs are in `reg` already; STORE = false: its outputs stay in `reg` (one job per thread: kFT == 512).  The
+// forward transform's last pass and the inverse transforms' first pass are the same jobs on the same elements ({8 g + i} of column
+// `line`), so the patch spectrum never goes back to LDS: it is multiplied by a pair's kernel spectrum in the registers it was born in.
+template <int SIGN, bool STRIDED, bool TWIDDLE, bool COLS, bool LOAD = true, bool STORE = true>
+__device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid, cd (&reg)[8]) {
+    static_assert(kFT == 512, "one job per thread");
+    const int line = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int at[8];
 #pragma unroll
-    for (int s = 0; s < 512 / kFT; ++s) {
-        const int q = tid + kFT * s;
-        const int line = q & 63, g = __builtin_amdgcn_readfirstlane(q >> 6);
-        cd v[8];
-        int at[8];
+    for (int i = 0; i < 8; ++i) {
+        const int idx = STRIDED ? 8 * i + g : 8 * g + i;
+        at[i] = COLS ? idx * kFS + line : line * kFS + idx;
+        if (LOAD) reg[i] = L[at[i]];
+    }
+    fft8<SIGN>(reg);
+    if (TWIDDLE) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = STRIDED ? 8 * i + g : 8 * g + i;
-            at[i] = COLS ? idx * kFS + line : line * kFS + idx;
-            v[i] = L[at[i]];
+        for (int i = 1; i < 8; ++i) {
+            const int m = (g * i) & 63;
+            reg[i] = cmul(reg[i], cd{c_w64[2 * m], SIGN < 0 ? c_w64[2 * m + 1] : -c_w64[2 * m + 1]});
         }
-        fft8<SIGN>(v);
-        if (TWIDDLE) {
+    }
+    if (STORE) {
 #pragma unroll
-            for (int i = 1; i < 8; ++i) {
-                const int m = (g * i) & 63;
-                v[i] = cmul(v[i], cd{c_w64[2 * m], SIGN < 0 ? c_w64[2 * m + 1] : -c_w64[2 * m + 1]});
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) L[at[i]] = v[i];
+        for (int i = 0; i < 8; ++i) L[at[i]] = reg[i];
     }
 }
+template <int SIGN, bool STRIDED, bool TWIDDLE, bool COLS>
+__device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid) { cd v[8]; fft_pass<SIGN, STRIDED, TWIDDLE, COLS>(L, tid, v); }
 
 // ---- the values whose float could differ from the direct sum's -----------------------------------------------------------------------
 // The transform's planes are ~1e-15 x (the size of the patch) from the direct kernel's sums (k_gabor_bank: an fma chain in double over
@@ -107,9 +115,14 @@ __device__ unsigned long long g_doubt[3];                     // since the last 
 __device__ __forceinline__ int rounding_in_doubt(double v, double band) {      // 0: no, 1: near zero, 2: near a midpoint
     if (v < -band || v > 1.0 + band) return 0;
     if (v < band) return 1;
+    // v = f + d with f the nearest float; the midpoints lie half a spacing away: 2^(e - 24) above f and below it, except below a power of two
+    // (2^(e - 25)).  In doubt when d comes within `band` of one of them.
     const float f = (float)v;
-    const double lo = (double)__int_as_float(__float_as_int(f) - 1), hi = (double)__int_as_float(__float_as_int(f) + 1), m = (double)f;
-    return (fabs(v - 0.5 * (lo + m)) < band || fabs(v - 0.5 * (m + hi)) < band) ? 2 : 0;
+    const double d = v - (double)f;
+    const int fb = __float_as_int(f);
+    float h = __int_as_float((fb & 0x7f800000) - (24 << 23));
+    if ((fb & 0x007fffff) == 0 && d < 0.0) h *= 0.5f;
+    return fabs(d) > (double)h - band ? 2 : 0;
 }
 
 // list[0]: entries, list[2 + e]: (y * W + x) * CN + ch.  A group of 16 lanes takes an entry; lane o of the group runs orientation o's chain.
@@ -175,7 +188,7 @@ __global__ void __launch_bounds__(256) k_gabor_redo(const float* __restrict__ sr
 template <int KS>
 __global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ src, const cd* __restrict__ G, unsigned* __restrict__ list,
                                                    float* __restrict__ dst, int W, int H, int CN, int tiles_x) {
-    constexpr int R = KS / 2, B = kFN - KS + 1, kOut = (B * B + kFT - 1) / kFT, kEl = kFN * kFN / kFT;
+    constexpr int R = KS / 2, B = kFN - KS + 1, kEl = kFN * kFN / kFT;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];      // 64 x 65 complex doubles: just over the static 64 KB limit
     cd* const L = (cd*)lds_raw;
     unsigned long long* const rowmask = (unsigned long long*)(lds_raw + 2 * kFN * kFS);   // [64] which pixels of a patch row are not zero; [64..64+B) the same over KS rows
@@ -204,47 +217,48 @@ __global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ 
         for (int dy = 0; dy < KS; ++dy) m |= rowmask[tid + dy];
         rowmask[kFN + tid] = m;
     }
-    fft_pass<-1, true, true, false>(L, tid);  __syncthreads();
-    fft_pass<-1, false, false, false>(L, tid); __syncthreads();
-    fft_pass<-1, true, true, true>(L, tid);   __syncthreads();
+    // forward: columns, then rows; the last pass leaves the spectrum in registers: row `lane`, columns 8 g + i (g = tid / 64)
+    fft_pass<-1, true, true, true>(L, tid);    __syncthreads();
     fft_pass<-1, false, false, true>(L, tid);  __syncthreads();
-    cd P[kEl];
-#pragma unroll
-    for (int i = 0; i < kEl; ++i) { const int e = tid + kFT * i; P[i] = L[(e >> 6) * kFS + (e & 63)]; }
+    fft_pass<-1, true, true, false>(L, tid);   __syncthreads();
+    cd P[8];
+    fft_pass<-1, false, false, false, true, false>(L, tid, P);
     amax = 1.f;
     if (KS != 13) {
 #pragma unroll
         for (int w = 0; w < kFT / 64; ++w) amax = fmaxf(amax, wavemax[w]);
     }
     const double band = KS != 13 ? 1e-13 * (double)amax : 1e-13;
-    float acc[kOut];
-    unsigned state = 0;                                                    // bit 2 i: output i is inside the image and not an all-zero window (whose planes are exact zeros: nothing to add); bit 2 i + 1: on the list
+    // inverse: rows, then columns; the last pass leaves the planes in registers: column `lane`, rows g + 8 i — output pixel (lane, g + 8 i) of
+    // the tile's B x B block, a wave's lanes along x
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float acc[8];
+    unsigned state = 0;                                                    // bit 2 i: output i is inside the block and the image and not an all-zero window (whose planes are exact zeros: nothing to add); bit 2 i + 1: on the list
 #pragma unroll
-    for (int i = 0; i < kOut; ++i) {
+    for (int i = 0; i < 8; ++i) {
         acc[i] = 0.f;
-        const int o = tid + kFT * i, ny = o / B, nx = o - ny * B;
-        if (o < B * B && bx + nx < W && by + ny < H && ((rowmask[kFN + min(ny, B - 1)] >> nx) & ((1ull << KS) - 1)) != 0) state |= 1u << (2 * i);
+        const int ny = g + 8 * i;
+        if (lane < B && ny < B && bx + lane < W && by + ny < H && ((rowmask[kFN + min(ny, B - 1)] >> lane) & ((1ull << KS) - 1)) != 0) state |= 1u << (2 * i);
     }
     for (int j = 0; j < 8; ++j) {
-        __syncthreads();                                    // the previous pair's planes (or the spectrum) have been read
-        const cd* Gj = G + (size_t)j * (kFN * kFN);
+        const cd* Gj = G + (size_t)j * (kFN * kFN) + (size_t)g * 8 * kFN + lane;       // the kernel spectra lie transposed: [column][row]
+        cd v[8];
 #pragma unroll
-        for (int i = 0; i < kEl; ++i) { const int e = tid + kFT * i; L[(e >> 6) * kFS + (e & 63)] = cmul(P[i], Gj[e]); }
-        __syncthreads();
-        fft_pass<1, false, true, true>(L, tid);   __syncthreads();
-        fft_pass<1, true, false, true>(L, tid);   __syncthreads();
-        fft_pass<1, false, true, false>(L, tid);  __syncthreads();
-        fft_pass<1, true, false, false>(L, tid);  __syncthreads();
+        for (int i = 0; i < 8; ++i) v[i] = cmul(P[i], Gj[i * kFN]);
+        __syncthreads();                                    // the previous pair's last pass (or the forward transform's) has read its inputs
+        fft_pass<1, false, true, false, false, true>(L, tid, v);  __syncthreads();
+        fft_pass<1, true, false, false>(L, tid);   __syncthreads();
+        fft_pass<1, false, true, true>(L, tid);    __syncthreads();
+        fft_pass<1, true, false, true, true, false>(L, tid, v);
 #pragma unroll
-        for (int i = 0; i < kOut; ++i) {
+        for (int i = 0; i < 8; ++i) {
             if (state & (1u << (2 * i))) {
-                const int o = tid + kFT * i, ny = o / B, nx = o - ny * B;
-                const cd c = L[ny * kFS + nx];
+                const cd c = v[i];
                 const int dx_ = rounding_in_doubt(c.x, band), dy_ = rounding_in_doubt(c.y, band);
                 if ((dx_ | dy_) && list) {                                  // rare
                     if (dx_) atomicAdd(&g_doubt[dx_ - 1], 1ull);
                     if (dy_) atomicAdd(&g_doubt[dy_ - 1], 1ull);
-                    if (!(state & (2u << (2 * i)))) { state |= 2u << (2 * i); list[2 + atomicAdd(list, 1u)] = (unsigned)(((by + ny) * W + bx + nx) * CN + ch); }
+                    if (!(state & (2u << (2 * i)))) { state |= 2u << (2 * i); list[2 + atomicAdd(list, 1u)] = (unsigned)(((by + g + 8 * i) * W + bx + lane) * CN + ch); }
                 }
                 acc[i] += fminf(fmaxf((float)c.x, 0.f), 1.f);            // plane.setTo(1, plane > 1); setTo(0, plane < 0); dst += plane
                 acc[i] += fminf(fmaxf((float)c.y, 0.f), 1.f);            // ... orientation 2 j, then 2 j + 1
@@ -252,13 +266,9 @@ __global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ 
         }
     }
 #pragma unroll
-    for (int i = 0; i < kOut; ++i) {
-        const int o = tid + kFT * i;
-        if (o < B * B) {
-            const int ny = o / B, nx = o - ny * B;
-            const int x = bx + nx, y = by + ny;
-            if (x < W && y < H) dst[((size_t)y * W + x) * CN + ch] = acc[i] * 0.0625f;   // dst /= 16
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int ny = g + 8 * i;
+        if (lane < B && ny < B && bx + lane < W && by + ny < H) dst[((size_t)(by + ny) * W + bx + lane) * CN + ch] = acc[i] * 0.0625f;   // dst /= 16
     }
 }
 
