@@ -13,10 +13,17 @@ for i in range(cases):
     w = int(rng.integers(96, 420)); h = int(rng.integers(80, 200))       # (from 256 x 64 up, widths divisible by 4 take the fused accumulate kernel)
     if rng.random() < 0.5: w &= ~3
     s = int(rng.integers(1, 10000))
-    if rng.random() < 0.5:
+    kind = rng.random()
+    if kind < 0.4:
         a, b = synth.gen_pair(w, h, seed=s)
-    else:
+    elif kind < 0.7:
         a, b = synth.textured_bgr(w, h, s), synth.textured_bgr(w, h, s + 1)
+    else:                                                                  # a random crop of the reference's sample photographs at a random scale
+        sc = float(rng.uniform(1.0, 3.0))
+        pw, ph = int(w * sc) + 1, int(h * sc) + 1
+        pa, pb = synth.photo_pair(pw, ph)
+        x0, y0 = int(rng.integers(0, pw - w + 1)), int(rng.integers(0, ph - h + 1))
+        a, b = np.ascontiguousarray(pa[y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(pb[y0:y0 + h, x0:x0 + w])
     c = capi.Context(0, number_of_frames=4)
     try:
         nf, det = c.pair_begin(a, b)
