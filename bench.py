@@ -479,8 +479,11 @@ def bench_single(args, torch, capi, dev, local):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     written = 0
+    step_ms = []
     for _ in range(args.steps):
+        ts0 = time.perf_counter()
         written += step()      # returns after every frame of the batch was handed to the writer
+        step_ms.append((time.perf_counter() - ts0) * 1e3)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     warp_ms, warp_n = next(((ms, c) for nm, ms, c in pool.timing_summary() if nm == "warp"), (0.0, 0))
@@ -494,6 +497,8 @@ def bench_single(args, torch, capi, dev, local):
         "metric": "morph frames/sec at 1080p, 60-frame sequence; Mpix/s warped" if (W, H, FRAMES) == (1920, 1080, 60) else f"morph frames/sec at {W}x{H}, {FRAMES}-frame sequence; Mpix/s warped",
         "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "step_ms": {"min": round(min(step_ms), 3), "median": round(sorted(step_ms)[len(step_ms) // 2], 3), "max": round(max(step_ms), 3),
+                    "what": "the timed steps one by one (diagnostic: `value` is all of them over their total time)"},
         "timed_region_s": round(dt, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "scaling_note": "the --gpus N lines shard ONE fixed 480-frame 1080p morph by frame range (total work fixed: strong); the N = 1 point of that series is "
