@@ -311,7 +311,9 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
         if (yy < y_begin + r) load_row(row_ptr(yy + 1), ra);
         apply_row(cur, true);
     }
+    uint32_t ra2[NDW], rs2[NDW];                              // the rows of the step after the next one: two steps of prefetch
     if (y_begin + 1 < y_end) { load_row(row_ptr(y_begin + r + 1), ra); load_row(row_ptr(y_begin - r), rs); }
+    if (y_begin + 2 < y_end) { load_row(row_ptr(y_begin + r + 2), ra2); load_row(row_ptr(y_begin + 1 - r), rs2); }
     // The warm-up is ksize * ksize additions per lane — 40 % of a segment's atomics at ksize 89 — and none of them cancels; its coarse level is
     // therefore not kept by atomics but summed from the fine bins once, every wave a share of the 16 groups (256 reads per lane instead of
     // ksize * ksize atomics).
@@ -358,8 +360,8 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
         if (y + 1 < y_end) {
             uint32_t ca[NDW], cs[NDW];
 #pragma unroll
-            for (int i = WV; i < NDW; i += NW) { ca[i] = ra[i]; cs[i] = rs[i]; }
-            if (y + 2 < y_end) { load_row(row_ptr(y + r + 2), ra); load_row(row_ptr(y + 1 - r), rs); }   // rows of the NEXT step
+            for (int i = WV; i < NDW; i += NW) { ca[i] = ra[i]; cs[i] = rs[i]; ra[i] = ra2[i]; rs[i] = rs2[i]; }
+            if (y + 3 < y_end) { load_row(row_ptr(y + r + 3), ra2); load_row(row_ptr(y + 2 - r), rs2); }   // rows of the step after the next
             apply_step(ca, cs);
         }
     }
