@@ -271,6 +271,15 @@ __device__ __forceinline__ void median_body(uint32_t* __restrict__ hist, const u
         for (int i = WV; i < NDW; i += NW) {
             {
                 const int nb = (i == ndw - 1) ? tail : 4;
+                // On the plateaus the chain's later stages consist of, the four bytes of a dword are one value in every lane: one update of 4 instead of four
+                // (wave-uniform test; the warm-up is ksize * ksize additions per lane and none of them cancels)
+                const uint32_t w4 = regs[i];
+                if (nb == 4 && add && __all(w4 == (w4 & 255u) * 0x01010101u)) {
+                    const uint32_t v = w4 & 255u;
+                    atomicAdd(reinterpret_cast<uint32_t*>(lane_base + v * kMedBinBytes), 4u * unit);
+                    if (!kSumCoarse) atomicAdd(reinterpret_cast<uint32_t*>(lane_base + kMedCoarseOff + (v >> 4) * kMedBinBytes), 4u * unit);
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < nb) {
