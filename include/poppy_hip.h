@@ -200,6 +200,11 @@ typedef struct poppy_foreground_debug {
 } poppy_foreground_debug;
 int poppy_hip_foreground(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, int width, int height,
                          uint8_t* good_features, const poppy_foreground_debug* debug);
+/* One link of that chain on its own: cv::medianBlur(src, dst, ksize) on a tight 8-bit single-channel host image, odd 3 <= ksize <= 89
+ * (src/extractor.cpp:149; OCV/imgproc/src/median_blur.simd.hpp:84-346).  form selects the kernel (diagnostics, tests): 0 = what the chain
+ * takes for this ksize, 1 = a lane per image column (k_median_u8), 2 = column histograms with the tiles' presence maps, 3 = column
+ * histograms with every tile on all 256 values, 4 = as 2 without the 64-rank form.  All forms return the same bytes.                                                         */
+int poppy_hip_median_blur(poppy_hip_ctx* ctx, const uint8_t* src, int width, int height, int ksize, int form, uint8_t* dst);
 
 /* Pair set-up from the two ORB input images g1/g2 (what Extractor::keypoints feeds the detector,
  * src/extractor.cpp:50-78) and gabor2 (src/poppy.hpp:119-122): ORB x2 -> truncate to the shorter list

@@ -34,7 +34,7 @@ SYMBOLS = [
     "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_sharded_setups", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
         L.poppy_hip_render_many.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
         L.poppy_hip_foreground.argtypes = [vp, vp, sz, i, i, vp, vp]
+        L.poppy_hip_median_blur.argtypes = [vp, vp, i, i, i, i, vp]
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_begin_info.argtypes = [vp, vp, vp]
         L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
@@ -512,6 +513,14 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().poppy_hip_orb_detect(self.h, _p(g), w, w, h, nfeatures, _p(kp), cap, C.byref(n)), "orb_detect")
         return kp[:n.value].copy()
+
+    def median_blur(self, img, ksize, form=0):
+        """cv::medianBlur on a single-channel u8 image; form: 0 chain default, 1 lane per column, 2 column histograms + presence maps, 3 column histograms on 256 values."""
+        a = np.ascontiguousarray(img, np.uint8)
+        h, w = a.shape
+        out = np.zeros((h, w), np.uint8)
+        self._chk(lib().poppy_hip_median_blur(self.h, _p(a), w, h, int(ksize), int(form), _p(out)), "median_blur")
+        return out
 
     def foreground(self, bgr, debug=False):
         """Extractor::foreground for one BGR image -> goodFeatures (u8); with debug=True a dict with every intermediate."""

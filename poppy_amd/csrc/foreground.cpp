@@ -21,13 +21,14 @@ ForegroundFilter::~ForegroundFilter() {
     release();
     release2();
     if (logtab) (void)hipFree(logtab);
+    if (h_easy) (void)hipHostFree(h_easy);
 }
 
 void ForegroundFilter::release() {
-    void* bufs[] = {padded, d_bgr, grey, meds, acc[0], acc[1], flows, masked, out, lut, tmp16, dbgf, hist, radial12};
+    void* bufs[] = {padded, d_bgr, grey, meds, acc[0], acc[1], flows, masked, out, lut, tmp16, dbgf, hist, radial12, med_pres};
     for (void* b : bufs) if (b) (void)hipFree(b);
     d_bgr = grey = meds = acc[0] = acc[1] = flows = masked = out = lut = nullptr;
-    tmp16 = nullptr; padded = nullptr; dbgf = nullptr; hist = nullptr; radial12 = nullptr;
+    tmp16 = nullptr; padded = nullptr; dbgf = nullptr; hist = nullptr; radial12 = nullptr; med_pres = nullptr;
     W = H = 0;
 }
 
@@ -60,6 +61,8 @@ int ForegroundFilter::ensure(int w, int h) {
     FG_CHK(hipMalloc((void**)&tmp16, P * 2));
     FG_CHK(hipMalloc((void**)&padded, 2 * median_padded_bytes(w, h)));        // two: a median reads one and writes the next one's
     FG_CHK(hipMalloc((void**)&hist, 256 * sizeof(unsigned)));
+    FG_CHK(hipMalloc((void**)&med_pres, (2 * median_presence_words(w, h) + 4) * sizeof(uint32_t)));   // presence maps of a median's source and result tiles + a counter
+    if (!h_easy) FG_CHK(hipHostMalloc((void**)&h_easy, 16));
     W = w; H = h;
     return 0;
 }
@@ -79,15 +82,36 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     const uint8_t* inputs[kMog2Steps];
     inputs[0] = grey;
     uint8_t* pad[2] = {padded, padded + median_padded_bytes(w, h)};
-    int pc = 0;
+    int pc = 0, pp = 0;
+    bool pres_valid = false;
+    uint32_t* pres[2] = {med_pres, med_pres + median_presence_words(w, h)};
+    // which kernel the large windows take (see foreground.h): the caller's hint, or the device's own count of tiles with few values
+    static const int forced_cols = getenv("POPPY_MED_COLS_FORCE") ? atoi(getenv("POPPY_MED_COLS_FORCE")) : -1;
+    int use_cols = forced_cols >= 0 ? forced_cols : median_cols_hint;
+    median_cols_hint = -1;
+    if (median_cols_min_ksize() > 89) use_cols = 0;
+    if (use_cols < 0) {
+        uint32_t* d_easy = med_pres + 2 * median_presence_words(w, h);
+        chk(hipMemsetAsync(d_easy, 0, 4, s), "memset");
+        launch_median_presence(grey, pres[pp], w, h, d_easy, s);
+        chk(hipMemcpyAsync(h_easy, d_easy, 4, hipMemcpyDeviceToHost, s), "copy");
+        chk(hipStreamSynchronize(s), "sync");
+        const MedianColsGeom g = median_cols_geom(w, h);
+        use_cols = (unsigned long long)h_easy[0] * 10 >= (unsigned long long)g.tiles_x * g.tiles_y * 9;
+        pres_valid = true;                                    // (of the grey image: the first median's source)
+    }
     launch_pad_cols(grey, pad[pc], w, h, s);                  // medianBlur(ksize 1) is a copy: the first real median reads the grey image
     for (int i = 0; i < 12; ++i) {
         uint8_t* med = meds + (size_t)i * P;
         const int ksize = i * 8 + 1;
         if (ksize <= 1) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy");
-        else {                                                // every median writes its result twice: tight (MOG2's input) and padded (the next median's)
+        else if (use_cols && ksize >= median_cols_min_ksize()) {   // by column histograms: every launch also leaves the presence map of its result's tiles
+            if (!pres_valid) { launch_median_presence(inputs[i], pres[pp], w, h, nullptr, s); pres_valid = true; }
+            launch_median_cols(pad[pc], med, i < 11 ? pad[pc ^ 1] : nullptr, w, h, ksize, pres[pp], pres[pp ^ 1], 0, s);
+            pc ^= 1; pp ^= 1;
+        } else {                                              // every median writes its result twice: tight (MOG2's input) and padded (the next median's)
             launch_median_padded(pad[pc], med, i < 11 ? pad[pc ^ 1] : nullptr, w, h, ksize, s);
-            pc ^= 1;
+            pc ^= 1; pres_valid = false;
         }
         inputs[i + 1] = med;
     }
@@ -150,10 +174,29 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     return err.empty() ? out : nullptr;
 }
 
+int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int form, hipStream_t s, uint8_t* dst) {
+    if (!src || !dst || w <= 0 || h <= 0 || ksize < 3 || ksize > 89 || !(ksize & 1) || form < 0 || form > 4) { err = "bad arguments"; return -1; }
+    if (ensure(w, h)) return -2;
+    const size_t P = (size_t)w * h;
+    FG_CHK(hipMemcpyAsync(grey, src, P, hipMemcpyHostToDevice, s));
+    launch_pad_cols(grey, padded, w, h, s);
+    if (form == 0) form = ksize >= median_cols_min_ksize() ? 2 : 1;
+    if (form == 1) launch_median_padded(padded, meds, nullptr, w, h, ksize, s);
+    else {
+        if (form != 3) launch_median_presence(grey, med_pres, w, h, nullptr, s);
+        launch_median_cols(padded, meds, nullptr, w, h, ksize, form != 3 ? med_pres : nullptr, med_pres + median_presence_words(w, h), form == 3 ? 1 : form == 4 ? 2 : 0, s);
+    }
+    FG_CHK(hipGetLastError());
+    FG_CHK(hipMemcpyAsync(dst, meds, P, hipMemcpyDeviceToHost, s));
+    FG_CHK(hipStreamSynchronize(s));
+    return 0;
+}
+
 int ForegroundFilter::run(const uint8_t* bgr, size_t stride, int w, int h, hipStream_t s, uint8_t* dst, const ForegroundDebugOut* dbg) {
     if (!bgr || !dst || w <= 0 || h <= 0 || stride < (size_t)w * 3) { err = "bad arguments"; return -1; }
     if (ensure(w, h)) return -2;
     FG_CHK(hipMemcpy2DAsync(d_bgr, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, s));
+    median_cols_hint = median_cols_hint_from_host(bgr, stride, w, h);
     const uint8_t* r = run_device(d_bgr, (size_t)w * 3, w, h, s, dbg);
     if (!r) return -2;
     FG_CHK(hipMemcpyAsync(dst, r, (size_t)w * h, hipMemcpyDeviceToHost, s));

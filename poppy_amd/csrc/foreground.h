@@ -34,11 +34,19 @@ public:
     int detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out);
     const uint8_t* orb_input(const uint8_t* d_gf, int w, int h, int which, hipStream_t s, float* h_us = nullptr, float* h_gb = nullptr);
     const float* gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s);
-    uint8_t* bgr_staging() { return d_bgr; }         // w*h*3 bytes once ensure() ran
+    uint8_t* bgr_staging() { return d_bgr; }
+    // medianBlur(src, ksize) on a host image by one of the two kernels (diagnostics / tests): form 1 = a lane per column (k_median_u8), 2 = column
+    // histograms with the presence map, 3 = column histograms, every tile on all 256 values, 4 = with the map but no tile on 64 ranks; 0 = what the chain
+    // would take for this ksize
+    int median(const uint8_t* src, int w, int h, int ksize, int form, hipStream_t s, uint8_t* dst);         // w*h*3 bytes once ensure() ran
     int prepare(int w, int h) { return ensure(w, h); }
     std::string err;
 
     hipEvent_t medians_done = nullptr;   // when set, run_device records it on its stream behind the last median (the pair set-up starts gabor2 there)
+    // Which kernel the chain's medians take from median_cols_min_ksize() on: 1 = column histograms (images of few values per neighbourhood), 0 = a lane per
+    // column, -1 = ask the device (a presence pass over the grey image and a 4-byte read-back).  Set per image by the caller that holds host pixels
+    // (median_cols_hint_from_host); reset to -1 by run_device.  POPPY_MED_COLS_FORCE = 0 / 1 overrides.  Every choice gives the same bytes.
+    int median_cols_hint = -1;
     bool radial_mask_on = false;         // Settings::enable_radial_mask (src/extractor.cpp:178-197): set before the first run of a geometry or any time after
     bool gabor_direct = false;           // run the Gabor banks as direct double sums even when the FFT spectra exist (tests compare the two)
 private:
@@ -67,6 +75,8 @@ private:
     uint8_t* padded = nullptr;           // median source with replicated side columns
     float *logtab = nullptr, *dbgf = nullptr, *radial12 = nullptr;      // radial12: the radial mask of the current geometry, built on first use
     unsigned* hist = nullptr;
+    uint32_t* med_pres = nullptr;        // two presence maps (kernels_median_cols.hip): the current median's source and result; then the counter of easy tiles
+    uint32_t* h_easy = nullptr;          // pinned: that counter read back
     bool prepared = false;
 };
 

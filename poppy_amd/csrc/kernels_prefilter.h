@@ -28,6 +28,19 @@ void launch_median_u8(const uint8_t* src, uint8_t* padded_tmp, uint8_t* dst, int
 // dst (tight rows) and, when padded_next is not null, ALSO writes the result as the padded source of the next median (one launch per link of the chain).
 void launch_pad_cols(const uint8_t* src, uint8_t* padded, int w, int h, hipStream_t s);
 void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, hipStream_t s);
+// The same filter by column histograms (kernels_median_cols.hip; the reference's own scheme for these windows, median_blur.simd.hpp:84-346): the cost
+// of a pixel does not depend on ksize.  The image is cut into tiles of median_cols_geom(); pres_in (may be null) = the 256-bit presence map of every
+// tile of the SOURCE (median_presence_words() dwords: launch_median_presence, or the pres_out of the median that made the source): tiles whose
+// footprint holds at most 64 different values are filtered on the values' ranks, at a third of the cost.  pres_out (may be null): the map of dst.
+struct MedianColsGeom { int run, rows, tiles_x, tiles_y; };
+MedianColsGeom median_cols_geom(int w, int h);
+size_t median_presence_words(int w, int h);
+// easy_or_null: a device counter (zeroed by the caller) of the tiles that hold few different values: nine tenths of an image's tiles -> the column-histogram form pays
+void launch_median_presence(const uint8_t* src_tight, uint32_t* pres, int w, int h, uint32_t* easy_or_null, hipStream_t s);
+int median_cols_hint_from_host(const uint8_t* bgr, size_t stride, int w, int h);      // the same decision from a sparse sample of a host image (1 / 0)
+void launch_median_cols(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, const uint32_t* pres_in, uint32_t* pres_out,
+                        int force, hipStream_t s);             // force: 0 = by content, 1 = every tile on all 256 values, 2 = no tile on 64 ranks
+int median_cols_min_ksize();            // windows from this size on take the column-histogram form (POPPY_MED_COLS_MIN overrides)
 
 // GaussianBlur(src, dst, 23x23, sigma 1) on 8 bit (the fixed-point path); tmp = w*h uint16
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);

@@ -433,6 +433,10 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
 #undef MED
 }
 size_t median_padded_bytes(int w, int h) { return (size_t)(w + 2 * kMedPad) * h + 16; }
+int median_cols_min_ksize() {
+    static const int v = getenv("POPPY_MED_COLS_MIN") ? atoi(getenv("POPPY_MED_COLS_MIN")) : 25;      // (below: k_median_u8 is as fast or faster on every content)
+    return v;
+}
 bool prepare_median_u8() { return true; }
 
 // ---- GaussianBlur 23x23, sigma 1, 8 bit: taps 1 14 62 102 62 14 1 (the other 16 taps are 0 in 8.8 fixed point) ------------

@@ -171,6 +171,14 @@ int poppy_hip_foreground(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, in
     return POPPY_OK;
 }
 
+int poppy_hip_median_blur(poppy_hip_ctx* c, const uint8_t* src, int W, int H, int ksize, int form, uint8_t* dst) {
+    if (!c) return POPPY_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = c->foreground.median(src, W, H, ksize, form, c->stream, dst);
+    if (rc) { c->err = "median: " + c->foreground.err; return rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE; }
+    return POPPY_OK;
+}
+
 // Pair set-up from the raw images: the pre-ORB filter chain on the GPU, then the same steps as pair_begin_prefiltered.
 static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, const uint8_t* bgr2, size_t s2, int W, int H, float ratio,
                            bool on_device = false) {
@@ -238,6 +246,10 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         ~Publish() { now(); }
     };
     static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
+    if (!on_device) {                                                    // which median kernel each image's chain takes: from a sample of the host pixels
+        c->foreground.median_cols_hint = median_cols_hint_from_host(bgr1, s1, W, H);
+        c->foreground_b.median_cols_hint = median_cols_hint_from_host(bgr2, s2, W, H);
+    }
     auto chain_of = [&](int i) {
         Publish publish{details};
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
