@@ -336,6 +336,14 @@ typedef int (*poppy_pair_source_cb)(void* user, int pair_index, int device, cons
 typedef void (*poppy_write_pair_cb)(void* user, int pair_index, int frame_index, const uint8_t* bgr, int width, int height, size_t stride);
 poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
                                       char* err, size_t err_len);
+/* The same, with the start-up check a long-lived service makes once: the contexts of a pool get their streams, hardware queues and buffers from the
+ * runtime, and about one pool in ten runs every batch 10-25 % slower for as long as it lives.  Up to max_candidates (1..8) pools are made, each renders a
+ * built-in calibration batch of the given geometry (two pairs per context, once untimed, twice timed); two pools that agree within 4 % end the search;
+ * the fastest is returned, the others are destroyed.  candidates_ms (may be NULL, room for max_candidates): the batch time of every pool made, in order;
+ * *n_made, *kept (may be NULL): how many were made, which one was kept.                                                                             */
+poppy_hip_pool* poppy_hip_pool_create_tuned(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
+                                            int width, int height, int max_candidates, float* candidates_ms, int* n_made, int* kept,
+                                            char* err, size_t err_len);
 void poppy_hip_pool_destroy(poppy_hip_pool* pool);
 int poppy_hip_pool_morph_pairs(poppy_hip_pool* pool, int n_pairs, int width, int height, double phase, int inputs_on_device,
                                poppy_pair_source_cb source, poppy_write_pair_cb write, void* user, char* err, size_t err_len);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_sharded_setups", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -113,6 +113,8 @@ def lib():
         L.poppy_hip_pool_mask_rider.argtypes = [vp]
         L.poppy_hip_pool_create.restype = C.c_void_p
         L.poppy_hip_pool_create.argtypes = [vp, i, i, vp, vp, sz]
+        L.poppy_hip_pool_create_tuned.restype = C.c_void_p
+        L.poppy_hip_pool_create_tuned.argtypes = [vp, i, i, vp, i, i, i, vp, vp, vp, vp, sz]
         L.poppy_hip_pool_destroy.argtypes = [vp]
         L.poppy_hip_render_phases.argtypes = [vp, vp, i, vp, vp]
         L.poppy_sink_open.restype = C.c_void_p
@@ -363,13 +365,22 @@ def pair_begin_sharded_local(ctxs, d1, d2, w, h, root=0):
 class Pool:
     """Persistent contexts for batches of independent pairs (poppy_hip_pool_*)."""
 
-    def __init__(self, devices, contexts_per_device=2, **settings):
+    def __init__(self, devices, contexts_per_device=2, tuned_for=None, max_candidates=3, **settings):
+        """tuned_for=(width, height): poppy_hip_pool_create_tuned — the library makes up to max_candidates pools, times a calibration batch on each and keeps
+        the fastest (self.candidates_ms: every pool's batch time in the order made, self.kept: the index kept)."""
         s = PoppySettings(); lib().poppy_settings_default(C.byref(s))
         for k, v in settings.items():
             setattr(s, k, v)
         dv = (C.c_int * len(devices))(*devices)
         err = C.create_string_buffer(512)
-        self.h = lib().poppy_hip_pool_create(dv, len(devices), contexts_per_device, C.byref(s), err, 512)
+        self.candidates_ms, self.kept = None, None
+        if tuned_for is None:
+            self.h = lib().poppy_hip_pool_create(dv, len(devices), contexts_per_device, C.byref(s), err, 512)
+        else:
+            ms = (C.c_float * max_candidates)(); n = C.c_int(0); kept = C.c_int(-1)
+            self.h = lib().poppy_hip_pool_create_tuned(dv, len(devices), contexts_per_device, C.byref(s), int(tuned_for[0]), int(tuned_for[1]), max_candidates,
+                                                       ms, C.byref(n), C.byref(kept), err, 512)
+            self.candidates_ms, self.kept = [float(ms[k]) for k in range(n.value)], kept.value
         if not self.h:
             raise PoppyError("poppy_hip_pool_create: " + err.value.decode())
 

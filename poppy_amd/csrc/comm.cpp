@@ -107,7 +107,7 @@ int poppy_hip_comm_free(poppy_hip_ctx* c) {
     if (c->comm) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
-        (void)rccl()->CommDestroy(c->comm);
+        if (!c->comm_aborted.exchange(false)) (void)rccl()->CommDestroy(c->comm);
         c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     }
     return POPPY_OK;
@@ -206,10 +206,12 @@ int poppy_hip_pair_import_device(poppy_hip_ctx* c, const void* d_src, size_t byt
 // The exchanges, all through the same communicator: the raw pair from `root` (one broadcast of the c1 | c2 region), the two detail
 // values (one 3-double max-reduction, which also carries an error flag: nfeatures needs both, src/extractor.cpp:40-45), image 2's
 // keypoint positions B -> A (one broadcast through the state's point area), then the matcher on A and two broadcasts that complete the
-// pair state everywhere: header + points from A, m2 from C.  No step leaves a rank alone inside a collective: whatever can fail on one
-// rank is reported through the reduction, through a count of -1 in the keypoint hand-off or through an invalid header that every rank
-// refuses, and a transport error is remembered while the remaining collectives are still entered (round 4; the reductions' scratch is
-// allocated with the communicator).  One limit the one-GPU set-up does not have: image 2's keypoints travel through the state's point
+// pair state everywhere: header + points from A, m2 from C.  What can fail on ONE rank (an image, a detection, the matcher) never leaves the
+// others inside a collective: it is reported through the reduction, through a count of -1 in the keypoint hand-off or through an invalid
+// header that every rank refuses; from the keypoint hand-off on a TRANSPORT error is remembered while the remaining collectives are still
+// entered (and nothing it left in the hand-off area is used).  The first two exchanges (the raw pair's broadcast, the reductions) return
+// at once on a transport error: every rank sees the failed collective itself there — RCCL fails a collective on all its ranks, the local
+// hub raises its abort flag — so none waits in a later one.  One limit the one-GPU set-up does not have: image 2's keypoints travel through the state's point
 // area, so more than kPairMaxPoints - 1 (16 383) of them fail the set-up (the one-GPU path limits only the MATCHED pairs); max_keypoints
 // x detail stays far below that for every setting the reference's CLI accepts.
 // The transport is abstract so that the role logic can run — and be tested bit for bit — with several contexts of ONE process on one
@@ -342,6 +344,9 @@ int setup_sharded(poppy_hip_ctx* c, Transport& T, const void* d1, const void* d2
             if (hipMemcpyAsync(buf.data(), xarea, buf.size() * 4 > xbytes ? xbytes : buf.size() * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) valid = false;
             memcpy(&n2, &buf[0], 4);
+            // a hand-off broadcast that failed leaves stale floats in the area: nothing of it may be used (n2 would be an unbounded count)
+            if (bcast_rc) { valid = false; root_err = "keypoint hand-off to the matcher's rank failed"; }
+            if (n2 > kPairMaxPoints - 1) n2 = -1;
             if (valid && n2 >= 0) p2v.assign(buf.begin() + 2, buf.begin() + 2 + 2 * (size_t)n2);
         } else {
             if (r2 < 0) n2 = -1;
@@ -526,7 +531,9 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
         std::call_once(abort_once, [&]() {
             Rccl* r = rccl();
             if (n_devices > 1 && r->CommAbort)
-                for (int k = 0; k < n_devices; ++k) if (ctx[k]->comm) { void* cm = ctx[k]->comm; ctx[k]->comm = nullptr; (void)r->CommAbort(cm); }
+                // (the communicator pointers stay where they are — the device threads read c->comm without a lock, and an aborted communicator
+                // fails their collectives —; the flag tells poppy_hip_comm_free that the abort already released it)
+                for (int k = 0; k < n_devices; ++k) if (ctx[k]->comm && !ctx[k]->comm_aborted.exchange(true)) (void)r->CommAbort(ctx[k]->comm);
         });
     };
     std::atomic<int> past_setup{0};
@@ -641,6 +648,73 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, dou
     for (auto& t : th) t.join();
     if (failed.load() != POPPY_OK) set_err(err, err_len, first_err);
     return failed.load();
+}
+
+// A pool whose contexts came out well.  The contexts of a pool get their streams, hardware queues and buffers from the runtime when they are made, and about
+// one pool in ten then runs every batch 10 - 25 % slower for as long as it lives.  What a service does about that once, at start-up, is done
+// here: up to max_candidates pools are made, each renders a small calibration batch (a built-in synthetic pair of the given geometry, two pairs per context, the
+// frames handed to a counting writer) once untimed and twice timed; the fastest pool is returned, the others are destroyed.  Two pools that agree within 4 %
+// end the search — that is the normal state.  candidates_ms (may be NULL, room for max_candidates) receives the timed batch time of every pool made, in the
+// order they were made; *n_made their number; *kept the index of the one returned.
+namespace {
+void calibration_pair(int W, int H, std::vector<uint8_t>& a, std::vector<uint8_t>& b) {
+    // flat rectangles on grey, the second image's shifted by a few pixels: corners for the detector, plateaus like the bench's own content
+    a.assign((size_t)W * H * 3, 96); b = a;
+    auto hash = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+    for (uint32_t k = 0; k < 40; ++k) {
+        const int w = 24 + (int)(hash(k * 7 + 1) % (uint32_t)std::max(8, W / 10)), h = 24 + (int)(hash(k * 7 + 2) % (uint32_t)std::max(8, H / 10));
+        const int x0 = (int)(hash(k * 7 + 3) % (uint32_t)std::max(1, W - w - 16)), y0 = (int)(hash(k * 7 + 4) % (uint32_t)std::max(1, H - h - 16));
+        const int dx = 2 + (int)(hash(k * 7 + 5) % 7), dy = 2 + (int)(hash(k * 7 + 6) % 7);
+        const uint32_t col = hash(k * 7);
+        for (int im = 0; im < 2; ++im) {
+            std::vector<uint8_t>& img = im ? b : a;
+            const int ox = x0 + (im ? dx : 0), oy = y0 + (im ? dy : 0);
+            for (int y = oy; y < std::min(oy + h, H); ++y)
+                for (int x = ox; x < std::min(ox + w, W); ++x) {
+                    uint8_t* px = &img[((size_t)y * W + x) * 3];
+                    px[0] = (uint8_t)col; px[1] = (uint8_t)(col >> 8); px[2] = (uint8_t)(col >> 16);
+                }
+        }
+    }
+}
+}  // namespace
+
+poppy_hip_pool* poppy_hip_pool_create_tuned(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings, int W, int H,
+                                            int max_candidates, float* candidates_ms, int* n_made, int* kept, char* err, size_t err_len) {
+    if (n_made) *n_made = 0;
+    if (kept) *kept = -1;
+    if (W <= 0 || H <= 0 || max_candidates < 1 || max_candidates > 8) { set_err(err, err_len, "bad arguments"); return nullptr; }
+    std::vector<uint8_t> a, b;
+    calibration_pair(W, H, a, b);
+    struct Src { const uint8_t *a, *b; size_t stride; long long frames; } src{a.data(), b.data(), (size_t)W * 3, 0};
+    auto source = +[](void* u, int, int, const uint8_t** p1, size_t* s1, const uint8_t** p2, size_t* s2) { Src* s = (Src*)u; *p1 = s->a; *p2 = s->b; *s1 = *s2 = s->stride; return 0; };
+    auto count = +[](void* u, int, int, const uint8_t*, int, int, size_t) { __atomic_fetch_add(&((Src*)u)->frames, 1ll, __ATOMIC_RELAXED); };
+    std::vector<std::pair<poppy_hip_pool*, double>> made;
+    auto drop_all = [&]() { for (auto& m : made) poppy_hip_pool_destroy(m.first); };
+    for (int k = 0; k < max_candidates; ++k) {
+        poppy_hip_pool* p = poppy_hip_pool_create(devices, n_devices, contexts_per_device, settings, err, err_len);
+        if (!p) { drop_all(); return nullptr; }
+        const int batch = 2 * (int)p->ctx.size();
+        int rc = poppy_hip_pool_morph_pairs(p, batch, W, H, -1.0, 0, source, count, &src, err, err_len);      // allocates
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int q = 0; q < 2 && rc == POPPY_OK; ++q) rc = poppy_hip_pool_morph_pairs(p, batch, W, H, -1.0, 0, source, count, &src, err, err_len);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 2;
+        if (rc != POPPY_OK) { poppy_hip_pool_destroy(p); drop_all(); return nullptr; }
+        made.emplace_back(p, ms);
+        if (candidates_ms) candidates_ms[k] = (float)ms;
+        if (made.size() >= 2) {
+            std::vector<double> t;
+            for (auto& m : made) t.push_back(m.second);
+            std::sort(t.begin(), t.end());
+            if (t[0] * 1.04 >= t[1]) break;
+        }
+    }
+    size_t best = 0;
+    for (size_t k = 1; k < made.size(); ++k) if (made[k].second < made[best].second) best = k;
+    for (size_t k = 0; k < made.size(); ++k) if (k != best) poppy_hip_pool_destroy(made[k].first);
+    if (n_made) *n_made = (int)made.size();
+    if (kept) *kept = (int)best;
+    return made[best].first;
 }
 
 int poppy_hip_pool_set_timing(poppy_hip_pool* p, int on) {

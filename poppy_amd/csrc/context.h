@@ -108,6 +108,7 @@ struct poppy_hip_ctx {
                       const uint8_t* c1 = nullptr; const uint8_t* c2 = nullptr; uint8_t* tr1 = nullptr; uint8_t* tr2 = nullptr; WarpExtras ex; bool valid = false; } last_warp;
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
+    std::atomic<bool> comm_aborted{false};                          // ncclCommAbort ran on it (and freed it): poppy_hip_comm_free only forgets the pointer
     double* d_comm_scratch = nullptr;                               // 8 doubles for the small reductions (comm.cpp), allocated on first use
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used

@@ -22,6 +22,7 @@ ForegroundFilter::~ForegroundFilter() {
     release2();
     if (logtab) (void)hipFree(logtab);
     if (h_easy) (void)hipHostFree(h_easy);
+    if (easy_ev) (void)hipEventDestroy(easy_ev);
 }
 
 void ForegroundFilter::release() {
@@ -90,22 +91,32 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     int use_cols = forced_cols >= 0 ? forced_cols : median_cols_hint;
     median_cols_hint = -1;
     if (median_cols_min_ksize() > 89) use_cols = 0;
+    bool ask_device = false;
     if (use_cols < 0) {
+        // the device counts the grey image's easy tiles now; the answer is read when the first large window comes up — behind the small windows' launches,
+        // so that the host does not stall the queue for it
         uint32_t* d_easy = med_pres + 2 * median_presence_words(w, h);
+        if (!easy_ev) chk(hipEventCreateWithFlags(&easy_ev, hipEventDisableTiming), "event create");
         chk(hipMemsetAsync(d_easy, 0, 4, s), "memset");
         launch_median_presence(grey, pres[pp], w, h, d_easy, s);
         chk(hipMemcpyAsync(h_easy, d_easy, 4, hipMemcpyDeviceToHost, s), "copy");
-        chk(hipStreamSynchronize(s), "sync");
-        const MedianColsGeom g = median_cols_geom(w, h);
-        use_cols = (unsigned long long)h_easy[0] * 10 >= (unsigned long long)g.tiles_x * g.tiles_y * 9;
-        pres_valid = true;                                    // (of the grey image: the first median's source)
+        if (easy_ev) chk(hipEventRecord(easy_ev, s), "event record");
+        ask_device = true;
+        pres_valid = median_cols_min_ksize() <= 9;            // (of the grey image: the first median's source)
     }
     launch_pad_cols(grey, pad[pc], w, h, s);                  // medianBlur(ksize 1) is a copy: the first real median reads the grey image
     for (int i = 0; i < 12; ++i) {
         uint8_t* med = meds + (size_t)i * P;
         const int ksize = i * 8 + 1;
         if (ksize <= 1) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy");
-        else if (use_cols && ksize >= median_cols_min_ksize()) {   // by column histograms: every launch also leaves the presence map of its result's tiles
+        if (ask_device && ksize >= median_cols_min_ksize()) {
+            chk(easy_ev ? hipEventSynchronize(easy_ev) : hipStreamSynchronize(s), "sync");
+            const MedianColsGeom g = median_cols_geom(w, h);
+            use_cols = (unsigned long long)h_easy[0] * 10 >= (unsigned long long)g.tiles_x * g.tiles_y * 9;
+            ask_device = false;
+        }
+        if (ksize <= 1) {}
+        else if (use_cols > 0 && ksize >= median_cols_min_ksize()) {   // by column histograms: every launch also leaves the presence map of its result's tiles
             if (!pres_valid) { launch_median_presence(inputs[i], pres[pp], w, h, nullptr, s); pres_valid = true; }
             launch_median_cols(pad[pc], med, i < 11 ? pad[pc ^ 1] : nullptr, w, h, ksize, pres[pp], pres[pp ^ 1], 0, s);
             pc ^= 1; pp ^= 1;

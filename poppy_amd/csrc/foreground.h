@@ -77,6 +77,7 @@ private:
     unsigned* hist = nullptr;
     uint32_t* med_pres = nullptr;        // two presence maps (kernels_median_cols.hip): the current median's source and result; then the counter of easy tiles
     uint32_t* h_easy = nullptr;          // pinned: that counter read back
+    hipEvent_t easy_ev = nullptr;        // ... when this event has passed
     bool prepared = false;
 };
 

@@ -104,7 +104,9 @@ __device__ __forceinline__ void fft_pass(cd* __restrict__ L, int tid) { cd v[8];
 // the taps, row by row; measured on the GPU over ~1e5 such values of photographs, textures and flat shapes at 1080p: at most 1.1e-14 x
 // max(1, the patch's largest magnitude), rms ~1.5e-15).  Rounded to float and clamped to [0, 1], a plane value v contributes the same
 // as the direct sum unless it lies within that distance of the midpoint between two floats, or of zero (the clamp's corner: the noise
-// around an exact zero at the border of a black region would survive it).  `band` is 1e-13 x max(1, the patch's largest magnitude).
+// around an exact zero at the border of a black region would survive it).  `band` is 1e-13 x max(1, the patch's largest magnitude): ten
+// times the measured worst case — an empirical margin (the transform's error follows the patch's and the kernel's norms), so "the two forms
+// agree in every bit" means: on everything tested, with that margin; POPPY_GABOR_BAND=1e30 re-forms every pixel for a check without it.
 // Not in doubt: v below -band or above 1 + band (clamped either way) and the planes of a window that holds only zeros (exact zeros in
 // the direct sums; the kernel knows such windows from ballots taken while it loads the patch and adds nothing for them).  A pixel
 // with a value in doubt — 1 value in ~1e4, most of them small: a float's neighbours are 2^-24 of its size apart — goes on a list, and
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(256) k_gabor_redo(const float* __restrict__ sr
 
 template <int KS>
 __global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ src, const cd* __restrict__ G, unsigned* __restrict__ list,
-                                                   float* __restrict__ dst, int W, int H, int CN, int tiles_x) {
+                                                   float* __restrict__ dst, int W, int H, int CN, int tiles_x, double band_unit) {
     constexpr int R = KS / 2, B = kFN - KS + 1, kEl = kFN * kFN / kFT;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];      // 64 x 65 complex doubles: just over the static 64 KB limit
     cd* const L = (cd*)lds_raw;
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(kFT, 4) k_gabor_fft(const float* __restrict__ 
 #pragma unroll
         for (int w = 0; w < kFT / 64; ++w) amax = fmaxf(amax, wavemax[w]);
     }
-    const double band = KS != 13 ? 1e-13 * (double)amax : 1e-13;
+    const double band = KS != 13 ? band_unit * (double)amax : band_unit;
     // inverse: rows, then columns; the last pass leaves the planes in registers: column `lane`, rows g + 8 i — output pixel (lane, g + 8 i) of
     // the tile's B x B block, a wave's lanes along x
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,6 +342,10 @@ bool gabor_fft_prepare() {                                     // the twiddle ta
 
 // POPPY_GABOR_NO_REDO (measurement aid): the transform alone, as until round 4 — a plane value in ~1e8 then lands on the other neighbouring float
 static bool gabor_redo_on() { static const bool on = getenv("POPPY_GABOR_NO_REDO") == nullptr; return on; }
+// The width of the doubt band in units of max(1, the patch's largest magnitude): 1e-13 = ten times the largest distance between the two forms
+// measured on ~1e5 plane values (1.1e-14).  The equality of the forms rests on that measurement, not on a proof: POPPY_GABOR_BAND widens the
+// band for checks (1e30: every pixel is re-formed as direct sums — a fuzz run under it and one without must agree in every bit).
+static double gabor_band_unit() { static const double v = getenv("POPPY_GABOR_BAND") ? atof(getenv("POPPY_GABOR_BAND")) : 1e-13; return v; }
 
 // list: 2 + w * h * channels words, device (this launch resets and fills it; k_gabor_redo reads it)
 void launch_gabor_fft31(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s) {
@@ -347,7 +353,7 @@ void launch_gabor_fft31(const float* src, const double* d_tables, const double* 
     const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
     if (!gabor_redo_on()) d_list = nullptr;
     if (d_list) (void)hipMemsetAsync(d_list, 0, 4, s);
-    hipLaunchKernelGGL(k_gabor_fft<31>, dim3(tiles_x * tiles_y, 1), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 1, tiles_x);
+    hipLaunchKernelGGL(k_gabor_fft<31>, dim3(tiles_x * tiles_y, 1), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 1, tiles_x, gabor_band_unit());
     if (d_list) hipLaunchKernelGGL(k_gabor_redo<31>, dim3(512), dim3(256), redo_lds_bytes(31), s, src, d_bank, d_list, dst, w, h, 1);
 }
 void launch_gabor_fft13_c3(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s) {
@@ -355,7 +361,7 @@ void launch_gabor_fft13_c3(const float* src, const double* d_tables, const doubl
     const int tiles_x = (w + B - 1) / B, tiles_y = (h + B - 1) / B;
     if (!gabor_redo_on()) d_list = nullptr;
     if (d_list) (void)hipMemsetAsync(d_list, 0, 4, s);
-    hipLaunchKernelGGL(k_gabor_fft<13>, dim3(tiles_x * tiles_y, 3), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 3, tiles_x);
+    hipLaunchKernelGGL(k_gabor_fft<13>, dim3(tiles_x * tiles_y, 3), dim3(kFT), kFftLds, s, src, (const cd*)d_tables, d_list, dst, w, h, 3, tiles_x, gabor_band_unit());
     if (d_list) hipLaunchKernelGGL(k_gabor_redo<13>, dim3(512), dim3(256), redo_lds_bytes(13), s, src, d_bank, d_list, dst, w, h, 3);
 }
 

@@ -94,33 +94,43 @@ hipError_t OrbDetector::prepare(int w, int h) {
 // room for n keypoints (positions, responses / angles, descriptors; device buffers and their pinned mirrors)
 hipError_t OrbDetector::grow_keypoints(int n) {
     if (n <= kp_cap) return hipSuccess;
+    // the new buffers first, the swap only when all of them exist: a failed allocation leaves the detector as it was (smaller, but consistent)
+    int *nd_kp = nullptr, *nh_kp = nullptr; float *nd_val = nullptr, *nh_val = nullptr; uint8_t* nd_desc = nullptr;
+    hipError_t e = hipMalloc((void**)&nd_kp, (size_t)n * 3 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&nd_val, (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&nd_desc, (size_t)n * 32);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&nh_kp, (size_t)n * 3 * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&nh_val, (size_t)n * sizeof(float));
+    if (e != hipSuccess) {
+        if (nd_kp) (void)hipFree(nd_kp);
+        if (nd_val) (void)hipFree(nd_val);
+        if (nd_desc) (void)hipFree(nd_desc);
+        if (nh_kp) (void)hipHostFree(nh_kp);
+        if (nh_val) (void)hipHostFree(nh_val);
+        return e;
+    }
     if (d_kp) (void)hipFree(d_kp);
     if (d_val) (void)hipFree(d_val);
     if (d_desc) (void)hipFree(d_desc);
     if (h_kp) (void)hipHostFree(h_kp);
     if (h_val) (void)hipHostFree(h_val);
-    d_kp = nullptr; d_val = nullptr; d_desc = nullptr; h_kp = nullptr; h_val = nullptr;
+    d_kp = nd_kp; d_val = nd_val; d_desc = nd_desc; h_kp = nh_kp; h_val = nh_val;
     kp_cap = n;
-    hipError_t e;
-    if ((e = hipMalloc((void**)&d_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&d_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&d_desc, (size_t)kp_cap * 32)) != hipSuccess) return e;
-    if ((e = hipHostMalloc((void**)&h_kp, (size_t)kp_cap * 3 * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipHostMalloc((void**)&h_val, (size_t)kp_cap * sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
 }
 
 // room for new_cap candidates per level (device lists + their pinned mirror); the level geometry stays
 hipError_t OrbDetector::grow_candidates(int new_cap) {
     if (new_cap <= cap) return hipSuccess;
+    int *nd = nullptr, *nh = nullptr;
+    const size_t bytes = (kCandHeader + (size_t)kOrbLevels * new_cap * 2) * sizeof(int);
+    hipError_t e = hipMalloc((void**)&nd, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&nh, bytes);
+    if (e != hipSuccess) { if (nd) (void)hipFree(nd); return e; }      // (the old lists stay: the detector is unchanged)
     if (d_counters) (void)hipFree(d_counters);
     if (h_cand) (void)hipHostFree(h_cand);
-    d_counters = d_cand = nullptr; h_cand = nullptr;
+    d_counters = nd; d_cand = d_counters + kCandHeader; h_cand = nh;
     cap = new_cap;
-    hipError_t e;
-    if ((e = hipMalloc((void**)&d_counters, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
-    d_cand = d_counters + kCandHeader;
-    if ((e = hipHostMalloc((void**)&h_cand, (kCandHeader + (size_t)kOrbLevels * cap * 2) * sizeof(int))) != hipSuccess) return e;
     last_total = 0;
     return hipSuccess;
 }

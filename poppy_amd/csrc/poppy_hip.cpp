@@ -367,6 +367,8 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
 // Multi-frame calls plan on a small pool of host threads: only the POINT chain is sequential in chained mode
 // (src/poppy.hpp:178-179,218: srcPoints1 <- morphedPoints), and that is a few hundred multiply-adds per frame; the
 // triangulation and matrix work of the frames is independent once each frame's input points are known.
+constexpr int kPlanThrew = -1000;          // rcs[] marker: the planner of that frame threw
+
 static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* mask, int n, bool chain, poppy_write_cb write, void* user) {
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
     if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
@@ -402,8 +404,11 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         for (;;) {
             const int j = next.fetch_add(1);
             if (j >= n) return;
-            rcs[j] = plan_frame(W, H, chain ? src1[j] : src1[0], c->pts2, shape[j], plans[j]);
-            if (!rcs[j] && bin_tw) build_tile_bins(plans[j], W, H, bin_tw, 1024 / bin_tw, c->bins_cap);
+            // a planner that throws (std::bad_alloc is the case that can happen) must still publish its frame: the calling thread spins on ready[j]
+            try {
+                rcs[j] = plan_frame(W, H, chain ? src1[j] : src1[0], c->pts2, shape[j], plans[j]);
+                if (!rcs[j] && bin_tw) build_tile_bins(plans[j], W, H, bin_tw, 1024 / bin_tw, c->bins_cap);
+            } catch (...) { rcs[j] = kPlanThrew; }
             ready[j].store(1, std::memory_order_release);
         }
     };
@@ -459,6 +464,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         const auto t_plan = clk::now();
         while (!ready[j].load(std::memory_order_acquire)) std::this_thread::yield();
         ms_plan += lap(t_plan);
+        if (rcs[j] == kPlanThrew) { rc = fail(c, POPPY_E_DEVICE, "frame planner failed (out of memory?)"); break; }
         if (rcs[j]) { rc = fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)"); break; }
         c->plan = std::move(plans[j]);
         if (chain) c->pts1 = src1[j];
