@@ -10,7 +10,14 @@ namespace poppy_hip {
 struct PyrLevel {        // geometry of one pyramid level and of the pyrDown that PRODUCES it
     int w, h;            // size of this level
     size_t off3, off1;   // element offsets of this level inside the 3-channel / 1-channel pyramid buffers
+    int pitch;           // pixels per row of this level in those buffers: w, or w rounded up to a multiple of 4 (level_pitch)
 };
+// Rows of the large levels begin on 16-byte boundaries whatever the width is: the kernels that carry most of a frame's bytes move 4 pixels
+// (12 bytes of u8, 48 of float) per access.  Widths that are multiples of 4 have that for free (pitch == w: nothing changes for them); other
+// widths get up to 3 pixels of padding per row in the frame slots' own buffers (warped images, pyramid levels) — never in what a caller hands
+// in or gets back.  The small levels (the fused and the tail kernels' domain) stay tight.
+constexpr size_t kPitchMinPixels = 150001;          // (= above kFuseMaxPixels)
+inline int level_pitch(int w, int h) { return ((w & 3) && (size_t)w * h >= kPitchMinPixels) ? (w + 3) & ~3 : w; }
 
 // --- once per pair ---------------------------------------------------------------------------
 // m2 = 1 - gray(gabor2)   (src/algo.cpp:250-252)
@@ -40,6 +47,7 @@ struct WarpExtras {
     const float* m2 = nullptr;
     float* mask = nullptr;
     double alpha = 0, beta = 0;
+    int out_pitch = 0;                          // pixels per row of tr1 / tr2 and of `mask` (0 = w; PyrLevel::pitch of level 0).  m2 and the sources are tight.
 };
 // t0 / t1 (optional) are attached to the dispatch: the kernel's own begin / end timestamps.
 void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
@@ -49,6 +57,7 @@ void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const ui
 // The same warp from per-triangle records (frame_plan.h: pack_warp_records), for frames whose matrices the host admitted
 // and geometries warp_fast_geometry() accepts (kernels_warp_fast.hip).  Bit-identical output, about half the instructions.
 bool warp_fast_geometry(int w, int h);
+bool warp_bin_geometry(int w, int h);       // what launch_warp_bin takes: any width from 8 up (rows of the outputs: WarpExtras::out_pitch, a multiple of 4)
 void launch_warp_fast(int32_t* triMap, const float* records, int n_records, const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
                       int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
@@ -71,22 +80,23 @@ void launch_warp_bin(const float* records, const void* tile_data, size_t tile_da
 // level 0 of L/R is the u8 warped image (converted on the fly), deeper levels are float.
 // mask_ab (level 0 only, frames whose geometry pyr_level0_vec_ok admits): srcM is the pair's m2 field and mask_ab points to this
 // frame's (alpha, beta) in device memory — the kernel computes lbmask = clamp(alpha + m2 * beta) on the values it loads.
+// sp / mp / dp: pixels per row of srcL / srcR, of srcM and of the destination level (0 = the level's width)
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr);
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr, int sp = 0, int mp = 0, int dp = 0);
 
 // one collapse step: B_i = pyrUp(B_{i+1}) + mix(G_i - pyrUp(G_{i+1}))   (src/blend.hpp:58-77)
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM,
                      const float* nL, const float* nR, const float* nB, float* outB,
-                     int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr);
+                     int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr, int gp = 0, int mp = 0, int np = 0);      // gp: gL / gR / outB, mp: gM, np: n*
 bool pyr_level0_vec_ok(int w, int h);
 // lbmask = clamp(alpha + m2 * beta) as an array (debug fetches of frames that did not materialise it)
 void launch_lbmask(const float* m2, const double* mask_ab, float* dst, size_t n, hipStream_t s);
 
 // wide-access forms (kernels_pyramid_vec.hip); return false when the level's geometry does not allow them
 bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr);
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab = nullptr, int sp = 0, int mp = 0, int dp = 0);
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr);
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab = nullptr, int gp = 0, int mp = 0, int np = 0);
 
 // Two levels per launch for levels that are launch-latency bound (kernels_pyramid_fused.hip): the workgroup that owns a
 // tile of the second level computes the part of the intermediate level it needs into LDS itself.
@@ -137,8 +147,9 @@ void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, fl
 // that the launch can sit in a captured graph while the value changes per frame.
 // `done` (optional): an event that completes with the launch's last kernel; for the tile kernel it rides on the dispatch
 // itself instead of being a packet of its own behind it.
+// src_pitch: pixels per row of src (0 = w; the outputs are tight).  A padded source takes the tile kernel.
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done = nullptr);
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done = nullptr, int src_pitch = 0);
 
 // The streaming form (kernels_unsharp_stream.hip: a wave per 60-pixel column strip, rows kept in registers); launch_unsharp uses it
 // for frames of 4 Mpx and more among the geometries it takes (w % 4 == 0, w >= 64, h >= 16) unless POPPY_UNSHARP_TILE is set;

@@ -185,7 +185,8 @@ __global__ void __launch_bounds__(256) k_warp(int32_t* __restrict__ triMap, cons
     if (x >= W) return;
     size_t p = (size_t)y * W + x;
     int idx = decode_id((uint32_t)triMap[p], ex.id_base) - 1;
-    if (ex.m2) ex.mask[p] = mask_value(ex.m2[p], ex.alpha, ex.beta);
+    const size_t po = (size_t)y * (ex.out_pitch > 0 ? ex.out_pitch : W) + x;      // the outputs' rows may be padded
+    if (ex.m2) ex.mask[po] = mask_value(ex.m2[p], ex.alpha, ex.beta);
     float mx1 = (float)x, my1 = (float)y, mx2 = mx1, my2 = my1;
     if (idx >= 0) {
         map_point(inv1 + (size_t)idx * 9, x, y, mx1, my1);
@@ -194,8 +195,8 @@ __global__ void __launch_bounds__(256) k_warp(int32_t* __restrict__ triMap, cons
     uint8_t o1[3], o2[3];
     sample3(c1, W, H, mx1, my1, o1);
     sample3(c2, W, H, mx2, my2, o2);
-    tr1[p * 3] = o1[0]; tr1[p * 3 + 1] = o1[1]; tr1[p * 3 + 2] = o1[2];
-    tr2[p * 3] = o2[0]; tr2[p * 3 + 1] = o2[1]; tr2[p * 3 + 2] = o2[2];
+    tr1[po * 3] = o1[0]; tr1[po * 3 + 1] = o1[1]; tr1[po * 3 + 2] = o1[2];
+    tr2[po * 3] = o2[0]; tr2[po * 3 + 1] = o2[1]; tr2[po * 3 + 2] = o2[2];
 }
 // --- 4 pixels per thread (W % 4 == 0) ---------------------------------------------------------------
 // One 16-byte load of the id map, the two inverse matrices fetched once per run of equal ids, each 2x2
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(256) k_warp4(int4* __restrict__ triMap4, const
 // profiler's kernel trace reports — rather than markers queued around it.
 void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const uint8_t* c1, const uint8_t* c2,
                  uint8_t* tr1, uint8_t* tr2, int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-    if ((w & 3) == 0 && w >= 8 && h >= 2)
+    if ((w & 3) == 0 && w >= 8 && h >= 2 && (ex.out_pitch == 0 || ex.out_pitch == w))
         hipExtLaunchKernelGGL(k_warp4, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, t0, t1, 0, (int4*)triMap, inv1, inv2,
                               c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, w, h, ex);
     else
@@ -324,7 +325,7 @@ void launch_warp(int32_t* triMap, const float* inv1, const float* inv2, const ui
 // so every output is the same expression tree as pyrdown_elem.  Strips that touch a border fall back to it.
 template <bool U8, int V>
 __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g, int y0, int xe, float* __restrict__ dst) {
-    const int cn = g.cn, dwe = g.dw * cn;
+    const int cn = g.cn, dwe = g.dp * cn;                      // (row stride of the destination buffer)
     const int px = xe / cn, c = xe - px * cn;
     const bool interior = px >= 1 && 2 * px + 2 <= g.sw - 1 && y0 >= 1 && 2 * (y0 + V - 1) + 2 <= g.sh - 1;
     if (!interior) {
@@ -334,7 +335,7 @@ __device__ __forceinline__ void pyrdown_strip(const void* src, const DownGeom& g
     }
     const bool hBody = (xe >= cn) && (xe < g.hBodyEnd);
     const bool vBody = xe < g.vBodyEnd;
-    const size_t rowlen = (size_t)g.sw * cn;
+    const size_t rowlen = (size_t)g.sp * cn;
     const size_t col = (size_t)(2 * px - 2) * cn + c;
     float r[2 * V + 3];
 #pragma unroll
@@ -378,10 +379,10 @@ static void launch_pyrdown_v(const void* srcL, const void* srcR, const float* sr
     hipLaunchKernelGGL((k_pyrdown<U8, V>), grid, dim3(256), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1);
 }
 void launch_pyrdown(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab) {
-    if (launch_pyrdown_vec(srcL, srcR, srcM, src_u8, dstL, dstR, dstM, sw, sh, s, mask_ab)) return;
+                    float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab, int sp, int mp, int dp) {
+    if (launch_pyrdown_vec(srcL, srcR, srcM, src_u8, dstL, dstR, dstM, sw, sh, s, mask_ab, sp, mp, dp)) return;
     if (mask_ab) abort();                      // the caller asks for the m2 form only where pyr_level0_vec_ok holds
-    DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+    DownGeom g3 = make_down_geom(sw, sh, 3, sp, dp), g1 = make_down_geom(sw, sh, 1, mp, dp);
     // taller strips share more row sums but leave fewer threads: only worth it when the level is large
     const size_t outputs = (size_t)g3.dw * g3.dh * 3;
     const int V = outputs >= (size_t)5000000 ? 4 : outputs >= (size_t)1000000 ? 2 : 1;
@@ -427,18 +428,20 @@ __device__ __forceinline__ UpQuad pyrup_quad(const float* __restrict__ p, int st
 template <bool U8>
 __global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                   const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                  float* __restrict__ outB, int w, int h, int nw, int nh) {
+                                                  float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp) {
     const int sxe = blockIdx.x * blockDim.x + threadIdx.x;
     const int sy = blockIdx.y;
     if (sxe >= nw * 3) return;
     const int sx = sxe / 3, c = sxe - sx * 3;
     const int x0 = 2 * sx, y0 = 2 * sy;
-    if (sx >= 1 && sx <= nw - 2 && sy >= 1 && sy <= nh - 2) {
-        const int ns = nw * 3;
+    // interior quads: the low-resolution 3 x 3 neighbourhood inside the coarser level AND all four outputs inside this one (an odd width's last
+    // quad has one column)
+    if (sx >= 1 && sx <= nw - 2 && sy >= 1 && sy <= nh - 2 && x0 + 1 < w && y0 + 1 < h) {
+        const int ns = cp.n * 3;
         const size_t lo = (size_t)sy * ns + sxe;
         const UpQuad uL = pyrup_quad(nL + lo, ns), uR = pyrup_quad(nR + lo, ns), uB = pyrup_quad(nB + lo, ns);
-        const size_t e00 = ((size_t)y0 * w + x0) * 3 + c, e10 = e00 + (size_t)w * 3;
-        const size_t m00 = (size_t)y0 * w + x0, m10 = m00 + w;
+        const size_t e00 = ((size_t)y0 * cp.g + x0) * 3 + c, e10 = e00 + (size_t)cp.g * 3;
+        const size_t m00 = (size_t)y0 * cp.m + x0, m10 = m00 + cp.m;
         outB[e00]     = uB.ee + mix_lr(ld<U8>(gL, e00) - uL.ee,     ld<U8>(gR, e00) - uR.ee,     gM[m00]);
         outB[e00 + 3] = uB.eo + mix_lr(ld<U8>(gL, e00 + 3) - uL.eo, ld<U8>(gR, e00 + 3) - uR.eo, gM[m00 + 1]);
         outB[e10]     = uB.oe + mix_lr(ld<U8>(gL, e10) - uL.oe,     ld<U8>(gR, e10) - uR.oe,     gM[m10]);
@@ -450,17 +453,18 @@ __global__ void __launch_bounds__(256) k_collapse(const void* __restrict__ gL, c
             for (int dx = 0; dx < 2; ++dx) {
                 const int x = x0 + dx, y = y0 + dy;
                 if (x < w && y < h)
-                    outB[((size_t)y * w + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c);
+                    outB[((size_t)y * cp.g + x) * 3 + c] = collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c, cp);
             }
     }
 }
 void launch_collapse(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                     float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab) {
-    if (launch_collapse_vec(gL, gR, g_u8, gM, nL, nR, nB, outB, w, h, nw, nh, s, mask_ab)) return;
+                     float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab, int gp, int mp, int np) {
+    if (launch_collapse_vec(gL, gR, g_u8, gM, nL, nR, nB, outB, w, h, nw, nh, s, mask_ab, gp, mp, np)) return;
     if (mask_ab) abort();
+    const CollapsePitch cp = make_collapse_pitch(w, nw, gp, mp, np);
     dim3 grid((nw * 3 + 255) / 256, nh);
-    if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
-    else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh);
+    if (g_u8) hipLaunchKernelGGL(k_collapse<true>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp);
+    else      hipLaunchKernelGGL(k_collapse<false>, grid, dim3(256), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp);
 }
 
 __global__ void k_lbmask(const float* __restrict__ m2, const double* __restrict__ ab, float* __restrict__ dst, size_t n) {
@@ -610,7 +614,8 @@ __device__ __forceinline__ float median_of_cols(const Col3& a, const Col3& b, co
 }
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min) {
+                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int SP) {
+    // SP: pixels per row of src (the blended level 0: PyrLevel::pitch); the frame goes out tight
     const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
     __shared__ __attribute__((aligned(16))) float S[kUSy * kUSs];
     __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
@@ -621,18 +626,18 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     const int tile_y = blk / tiles_x, tile_x = blk - tile_y * tiles_x;
     const int tx0 = tile_x * kUTx, ty0 = tile_y * kUTy;
     // 1. stage: S(r, u(col, c)) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + col))
-    const bool interior = (W & 3) == 0 && tx0 >= 8 && tx0 + 38 <= W && ty0 >= 5 && ty0 + kUTy + 5 <= H;
+    const bool interior = (SP & 3) == 0 && tx0 >= 8 && tx0 + 38 <= W && ty0 >= 5 && ty0 + kUTy + 5 <= H;
     if (interior) {
-        const float* base = src + ((size_t)(ty0 - 5) * W + (tx0 - 5)) * 3 - 1;      // 16-byte aligned: W % 4 == 0, tx0 % 32 == 0
+        const float* base = src + ((size_t)(ty0 - 5) * SP + (tx0 - 5)) * 3 - 1;     // 16-byte aligned: SP % 4 == 0, tx0 % 32 == 0
         for (int i = tid; i < kUSy * 32; i += 256) {
             const int r = i >> 5, v = i & 31;
-            *(f4*)(S + r * kUSs + 4 * v) = *(const f4*)(base + (size_t)r * W * 3 + 4 * v);
+            *(f4*)(S + r * kUSs + 4 * v) = *(const f4*)(base + (size_t)r * SP * 3 + 4 * v);
         }
     } else {
         for (int i = tid; i < kUSy * (kUTx + 10); i += 256) {
             const int r = i / (kUTx + 10), c = i - r * (kUTx + 10);
             const int yy = reflect101(ty0 - 5 + r, H), xx = reflect101(tx0 - 5 + c, W);
-            const float* p = src + ((size_t)yy * W + xx) * 3;
+            const float* p = src + ((size_t)yy * SP + xx) * 3;
             float* d = S + r * kUSs + 1 + c * 3;
             d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
         }
@@ -749,7 +754,8 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
 }
 
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
-                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done) {
+                    int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done, int src_pitch) {
+    if (src_pitch <= 0) src_pitch = w;
     if (w > 1 && h > 1) {
         // norm(d) >= threshold with norm = correctly rounded sqrt of a double: equivalent to |d|^2 >= x*, where x* is the
         // smallest double whose square root rounds to >= threshold (found here with the host's IEEE sqrt).
@@ -760,9 +766,9 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
         static const bool tile_only = getenv("POPPY_UNSHARP_TILE") != nullptr;
-        if (!tile_only && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done); return; }
+        if (!tile_only && src_pitch == w && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done); return; }
         dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
-        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x);
+        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, src_pitch);
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);

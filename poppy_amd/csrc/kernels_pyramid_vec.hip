@@ -44,20 +44,20 @@ __device__ __forceinline__ void pyrdown_border_body(int block, const void* __res
     const int pix = i / 7, k = i - pix * 7;
     int x, y;
     if (!border_pixel(pix, g3.dw, g3.dh, x0, x1, y0, y1, x, y)) return;
-    if (k < 3)      dstL[((size_t)y * g3.dw + x) * 3 + k] = pyrdown_elem_wide<U8, 3>(srcL, g3, y, x * 3 + k);
-    else if (k < 6) dstR[((size_t)y * g3.dw + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8, 3>(srcR, g3, y, x * 3 + (k - 3));
-    else            dstM[(size_t)y * g1.dw + x] = pyrdown_elem_wide<false, 1>(srcM, g1, y, x, fn);
+    if (k < 3)      dstL[((size_t)y * g3.dp + x) * 3 + k] = pyrdown_elem_wide<U8, 3>(srcL, g3, y, x * 3 + k);
+    else if (k < 6) dstR[((size_t)y * g3.dp + x) * 3 + (k - 3)] = pyrdown_elem_wide<U8, 3>(srcR, g3, y, x * 3 + (k - 3));
+    else            dstM[(size_t)y * g1.dp + x] = pyrdown_elem_wide<false, 1>(srcM, g1, y, x, fn);
 }
 
 template <bool U8, typename F>
 __device__ __forceinline__ void collapse_border_body(int block, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                      const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                     float* __restrict__ outB, int w, int h, int nw, int nh, int x0, int x1, int y0, int y1, F fn) {
+                                                     float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp, int x0, int x1, int y0, int y1, F fn) {
     const int i = block * 256 + threadIdx.y * 64 + threadIdx.x;
     const int pix = i / 3, c = i - pix * 3;
     int x, y;
     if (!border_pixel(pix, w, h, x0, x1, y0, y1, x, y)) return;
-    outB[((size_t)y * w + x) * 3 + c] = collapse_elem_wide<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c, fn);
+    outB[((size_t)y * cp.g + x) * 3 + c] = collapse_elem_wide<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, x * 3 + c, cp, fn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,20 +116,20 @@ __device__ __forceinline__ void pyrdown3_body2(int bx, int by, const void* __res
     const int y = (by * 4 + threadIdx.y) * 2;
     if (y >= g.dh) return;
     if (!(t >= 2 && t <= 2 * b.t1 + 1)) return;                        // border outputs: k_pyrdown_border
-    const size_t srow = (size_t)g.sw * 3;
+    const size_t srow = (size_t)g.sp * 3;
     const bool in0 = y >= 1 && y <= b.y1, in1 = y + 1 <= b.y1;
     if (in0 && in1) {
         float r[7][6];
 #pragma unroll
         for (int k = 0; k < 7; ++k) pyrdown3_row2<U8>(src, srow, 2 * y - 2 + k, t, g, r[k]);
-        pyrdown3_store2(dst, g.dw * 3, y, t, g, r[0], r[1], r[2], r[3], r[4]);
-        pyrdown3_store2(dst, g.dw * 3, y + 1, t, g, r[2], r[3], r[4], r[5], r[6]);
+        pyrdown3_store2(dst, g.dp * 3, y, t, g, r[0], r[1], r[2], r[3], r[4]);
+        pyrdown3_store2(dst, g.dp * 3, y + 1, t, g, r[2], r[3], r[4], r[5], r[6]);
     } else if (in0 || in1) {
         const int yy = in0 ? y : y + 1;
         float r[5][6];
 #pragma unroll
         for (int k = 0; k < 5; ++k) pyrdown3_row2<U8>(src, srow, 2 * yy - 2 + k, t, g, r[k]);
-        pyrdown3_store2(dst, g.dw * 3, yy, t, g, r[0], r[1], r[2], r[3], r[4]);
+        pyrdown3_store2(dst, g.dp * 3, yy, t, g, r[0], r[1], r[2], r[3], r[4]);
     }
 }
 
@@ -139,13 +139,13 @@ template <typename F>
 __device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __restrict__ src, float* __restrict__ dst, const DownGeom& g, VecBounds b, F fn) {
     const int t = bx * 64 + threadIdx.x;
     const int y = by * 4 + threadIdx.y;
-    const int nt = g.dw >> 2;
+    const int nt = (g.dw + 3) >> 2;
     if (t >= nt || y >= g.dh) return;
     if (!(t >= 1 && t <= b.t1 && y >= 1 && y <= b.y1)) return;        // border outputs: k_pyrdown_border
     float r[5][4];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const float4* p = (const float4*)(src + (size_t)(2 * y - 2 + k) * g.sw + (8 * t - 4));
+        const float4* p = (const float4*)(src + (size_t)(2 * y - 2 + k) * g.sp + (8 * t - 4));
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void pyrdown1_body(int bx, int by, const float* __res
         o[e] = (xe < g.vBodyEnd) ? ((r[1][e] + r[3][e] + r[2][e]) * 4.f + (r[0][e] + r[4][e] + (r[2][e] + r[2][e]))) * s
                                  : (r[2][e] * 6.f + (r[1][e] + r[3][e]) * 4.f + r[0][e] + r[4][e]) * s;
     }
-    *(float4*)(dst + (size_t)y * g.dw + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
+    *(float4*)(dst + (size_t)y * g.dp + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // One launch per level: blocks [0, 3*nbi) are the interior tiles of L, R and the mask, the rest enumerate the border
@@ -209,16 +209,23 @@ __global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ 
     else               pyrdown_level_body<U8>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
 }
 
-static bool pyrdown_vec_bounds(int sw, int sh, VecBounds& b) {
-    const DownGeom g3 = make_down_geom(sw, sh, 3);
-    if ((g3.dw & 3) != 0 || (sw & 3) != 0 || g3.dw < 32 || g3.dh < 8) return false;
+// sp / mp / dp: pixels per row of the source images, the source mask and the destination level (0: the level's own width).  The 16-byte accesses
+// need rows that begin on 16-byte boundaries: pitches that are multiples of 4 — the widths themselves may be anything.
+static bool pyrdown_vec_bounds(int sw, int sh, VecBounds& b, int sp = 0, int mp = 0, int dp = 0) {
+    const DownGeom g3 = make_down_geom(sw, sh, 3, sp, dp), g1 = make_down_geom(sw, sh, 1, mp, dp);
+    if ((g3.dp & 3) != 0 || (g3.sp & 3) != 0 || (g1.sp & 3) != 0 || g3.dw < 32 || g3.dh < 8) return false;
     // interior threads: 24t + 27 < 3 sw  (this also covers the 1-channel window 8t + 11 < sw) and 2y + 2 <= sh - 1
     b.t1 = std::min(g3.dw / 4 - 1, (3 * sw - 28) / 24);
     b.t1 = std::min(b.t1, (sw - 12) / 8);
     b.y1 = std::min(g3.dh - 1, (sh - 3) / 2);
     return b.t1 >= 1 && b.y1 >= 1;
 }
-static bool collapse_vec_ok(int w, int h, int nw, int nh) { (void)h; return (w & 3) == 0 && nw * 2 == w && nw >= 16 && nh >= 8; }
+// (gp / mp: pixels per row of this level's images and of its mask; the coarser level's rows are read 12 bytes at a time: any pitch)
+static bool collapse_vec_ok(int w, int h, int nw, int nh, int gp = 0, int mp = 0) {
+    (void)h;
+    const CollapsePitch cp = make_collapse_pitch(w, nw, gp, mp, 0);
+    return (cp.g & 3) == 0 && (cp.m & 3) == 0 && (nw * 2 == w || nw * 2 == w + 1) && cp.g >= 2 * nw && nw >= 16 && nh >= 8;
+}
 
 // both level-0 kernels of a w x h frame take the wide forms (the ones that can read the mask through m2)
 bool pyr_level0_vec_ok(int w, int h) {
@@ -227,10 +234,10 @@ bool pyr_level0_vec_ok(int w, int h) {
 }
 
 bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, bool src_u8,
-                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab) {
-    const DownGeom g3 = make_down_geom(sw, sh, 3), g1 = make_down_geom(sw, sh, 1);
+                        float* dstL, float* dstR, float* dstM, int sw, int sh, hipStream_t s, const double* mask_ab, int sp, int mp, int dp) {
+    const DownGeom g3 = make_down_geom(sw, sh, 3, sp, dp), g1 = make_down_geom(sw, sh, 1, mp, dp);
     VecBounds b;
-    if (!pyrdown_vec_bounds(sw, sh, b)) return false;
+    if (!pyrdown_vec_bounds(sw, sh, b, sp, mp, dp)) return false;
     const int gx = (g3.dw / 4 + 63) / 64, gy = (g3.dh + 3) / 4;
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
@@ -297,17 +304,17 @@ __device__ __forceinline__ void load_g12(const void* g, size_t elem_off, float v
 template <bool U8, typename F>
 __device__ __forceinline__ void collapse_body(int bx, int by, const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                               const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                              float* __restrict__ outB, int w, int h, int nw, int nh, F fn) {
+                                              float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp, F fn) {
     const int t = bx * 64 + threadIdx.x;
     const int sy = by * 4 + threadIdx.y;
     if (t >= (nw >> 1) || sy >= nh) return;
     if (!(t >= 1 && 2 * t + 2 <= nw - 1 && sy >= 1 && sy <= nh - 2)) return;     // border outputs: k_collapse_border
-    const size_t nrow = (size_t)nw * 3, orow = (size_t)w * 3;
+    const size_t nrow = (size_t)cp.n * 3, orow = (size_t)cp.g * 3;
     float res[2][12];
     float m[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const float4 q = *(const float4*)(gM + (size_t)(2 * sy + r) * w + 4 * t);
+        const float4 q = *(const float4*)(gM + (size_t)(2 * sy + r) * cp.m + 4 * t);
         m[r][0] = fn(q.x); m[r][1] = fn(q.y); m[r][2] = fn(q.z); m[r][3] = fn(q.w);
     }
     // The three upsampled images one after the other in a loop that is NOT unrolled: unrolled, the scheduler hoists all 36 three-dword
@@ -348,36 +355,37 @@ __device__ __forceinline__ void collapse_body(int bx, int by, const void* __rest
 template <bool U8, typename F>
 __device__ __forceinline__ void collapse_level_body(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                     const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                    float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
+                                                    float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp, int gx, int gy, int nborder,
                                                     int x0, int x1, int y0, int y1, F fn) {
     int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     if (blk >= nborder) {
         blk -= nborder;
         const int by = blk / gx, bx = blk - by * gx;
-        collapse_body<U8>(bx, by, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, fn);
+        collapse_body<U8>(bx, by, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, fn);
     } else {
-        collapse_border_body<U8>(blk, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, x0, x1, y0, y1, fn);
+        collapse_border_body<U8>(blk, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, x0, x1, y0, y1, fn);
     }
 }
 template <bool U8>
 __global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                         const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
-                                                        float* __restrict__ outB, int w, int h, int nw, int nh, int gx, int gy, int nborder,
+                                                        float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp, int gx, int gy, int nborder,
                                                         int x0, int x1, int y0, int y1, const double* __restrict__ mask_ab) {
-    if (U8 && mask_ab) collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
-    else               collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
+    if (U8 && mask_ab) collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
+    else               collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
 }
 
 bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float* gM, const float* nL, const float* nR, const float* nB,
-                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab) {
-    if (!collapse_vec_ok(w, h, nw, nh)) return false;
+                         float* outB, int w, int h, int nw, int nh, hipStream_t s, const double* mask_ab, int gp, int mp, int np) {
+    if (!collapse_vec_ok(w, h, nw, nh, gp, mp)) return false;
+    const CollapsePitch cp = make_collapse_pitch(w, nw, gp, mp, np);
     const int t1 = (nw - 3) / 2;                      // last interior thread: 2t + 2 <= nw - 1
     const int gx = (nw / 2 + 63) / 64, gy = (nh + 3) / 4;
     const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
     const int nb = border_count(w, h, x0, x1, y0, y1);
     const int nborder = (nb * 3 + 255) / 256, blocks = gx * gy + nborder;
-    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
-    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
+    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
     return true;
 }
 

@@ -190,8 +190,11 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
     const int row = tid / kTileTx, xg = tid % kTileTx;           // this thread's pixels: (tx0 + 4 xg .. + 3, ty0 + row)
     const int x0 = tx * kTileW + xg * 4, y = ty * kTileH + row;
     const bool active = x0 < W && y < H;
-    const uint32_t g = (uint32_t)y * (uint32_t)(W >> 2) + (uint32_t)(x0 >> 2);
-    const uint32_t pitch = (uint32_t)W * 3u, npx = (uint32_t)W * (uint32_t)H;
+    // the outputs' rows are op pixels long (a multiple of 4: W itself, or W rounded up — then the row's last group also holds up to three
+    // pixels of padding, computed like any other and never read); the sources and m2 are tight
+    const uint32_t op = ex.out_pitch > 0 ? (uint32_t)ex.out_pitch : (uint32_t)W;
+    const uint32_t g = (uint32_t)y * (op >> 2) + (uint32_t)(x0 >> 2);
+    const uint32_t pitch = (uint32_t)W * 3u, npx = op * (uint32_t)H;
     const __amdgpu_buffer_rsrc_t rdata = make_rsrc(tile_data, data_bytes);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(c1, pitch * (uint32_t)H + 16u), rs2 = make_rsrc(c2, pitch * (uint32_t)H + 16u);
     const __amdgpu_buffer_rsrc_t ro1 = make_rsrc(tr1, npx * 3u), ro2 = make_rsrc(tr2, npx * 3u);
@@ -205,7 +208,8 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
         staged = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                      rdata, (uint32_t)n_tiles * kTileIdBytes + (uint32_t)tile * kTileSlotBytes + (uint32_t)tid * 16u, 0, 0));
     float4 m2v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active && ex.m2) m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, npx * 4u), g * 16u, 0, 0));
+    if (active && ex.m2)
+        m2v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ex.m2, (uint32_t)W * (uint32_t)H * 4u), ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 4u, 0, 0));
     if (stages) s_rec[tid] = staged;
     __syncthreads();
     if (active && ex.m2) {                                       // the lbmask rider
@@ -250,9 +254,13 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
         if (e == 0) return (const float*)rec;
         if (e < (unsigned)kSlots) return (const float*)(tile_data + (size_t)n_tiles * kTileIdBytes + (size_t)tile * kTileSlotBytes + (size_t)e * kEntryBytes);
         return (const float*)(tile_data + (size_t)over_base + (size_t)(tile_off[tile] + (int)e - 1) * kEntryBytes);
-    });
+    }, (int)op);
 }
 
+
+bool warp_bin_geometry(int w, int h) {
+    return w >= 8 && h >= 2 && w <= 16384 && h <= 16384 && (long long)((w + 3) & ~3) * h * 3 + 16 < (1ll << 31);
+}
 
 int warp_bin_tile_width(int w, int h) {
     static const int forced = getenv("POPPY_TILE_W") ? atoi(getenv("POPPY_TILE_W")) : 0;

@@ -218,10 +218,12 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     size_t off3 = 0, off1 = 0;
     int w = W, h = H;
     for (int i = 0; i <= L; ++i) {
-        c->levels[i] = PyrLevel{w, h, off3, off1};
-        off3 += (size_t)w * h * 3; off1 += (size_t)w * h;
+        const int pitch = level_pitch(w, h);                      // rows of the large levels begin on 16-byte boundaries (kernels.h)
+        c->levels[i] = PyrLevel{w, h, off3, off1, pitch};
+        off3 += (size_t)pitch * h * 3; off1 += (size_t)pitch * h;
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
+    const size_t P0 = (size_t)c->levels[0].pitch * H;             // pixels of a padded level-0 image (= P for widths that are multiples of 4)
     c->first_tail = L;
     static const size_t tail_px = getenv("POPPY_TAIL_PX") ? (size_t)atoi(getenv("POPPY_TAIL_PX")) : 600;
     for (int i = 1; i <= L; ++i)
@@ -245,7 +247,7 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     c->m2 = (float*)(c->c2 + pair_align(P * 3 + 16));
     HIPCHK(c, hipMalloc((void**)&c->gabor2, P * 12));
     for (FrameSlot& f : c->slots) {
-        HIPCHK(c, hipMalloc((void**)&f.tr1, P * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P * 3 + 16));
+        HIPCHK(c, hipMalloc((void**)&f.tr1, P0 * 3 + 16)); HIPCHK(c, hipMalloc((void**)&f.tr2, P0 * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.out, P * 3 + 16));
         HIPCHK(c, hipMalloc((void**)&f.triMap, P * 4));
         f.map_tag = 0;
@@ -360,7 +362,7 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
     if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
     int rc = plan_frame(c->W, c->H, c->pts1, c->pts2, shape, c->plan);
     if (rc) return fail(c, POPPY_E_RANGE, "point outside the image rectangle (Subdiv2D::insert would throw)");
-    if (warp_fast_geometry(c->W, c->H)) { const int tw = warp_bin_tile_width(c->W, c->H); build_tile_bins(c->plan, c->W, c->H, tw, 1024 / tw, c->bins_cap); }
+    if (warp_bin_geometry(c->W, c->H)) { const int tw = warp_bin_tile_width(c->W, c->H); build_tile_bins(c->plan, c->W, c->H, tw, 1024 / tw, c->bins_cap); }
     return submit_frame(c, mask, chain);
 }
 
@@ -399,7 +401,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     const int alive = std::max(1, g_live_contexts.load());
     const int share = std::max(4, ((int)std::thread::hardware_concurrency() - 1) / alive);
     const int nthreads = std::max(1, std::min({n, 16, share, (int)std::thread::hardware_concurrency() - 1}));
-    const int bin_tw = warp_fast_geometry(W, H) ? warp_bin_tile_width(W, H) : 0;
+    const int bin_tw = warp_bin_geometry(W, H) ? warp_bin_tile_width(W, H) : 0;
     auto worker = [&]() {
         for (;;) {
             const int j = next.fetch_add(1);
@@ -521,7 +523,7 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
     static const bool fuse = getenv("POPPY_HIP_NOFUSE") == nullptr;
     for (int i = 0; i < ft;) {
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
-        if (fuse && i >= 1 && i + 2 <= ft && pyrdown2_eligible(a.w, a.h)) {           // two small levels in one launch
+        if (fuse && i >= 1 && i + 2 <= ft && a.pitch == a.w && pyrdown2_eligible(a.w, a.h)) {           // two small levels in one launch (their rows are tight)
             const PyrLevel& d = c->levels[i + 2];
             launch_pyrdown2(f.pyrL + a.off3, f.pyrR + a.off3, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1,
                             f.pyrL + d.off3, f.pyrR + d.off3, f.pyrM + d.off1, a.w, a.h, s);
@@ -532,7 +534,7 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         const void* sr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
         const bool lazy = i == 0 && c->lazy_mask;      // level 0 reads the mask through m2 (kernels.h: launch_pyrdown)
         launch_pyrdown(sl, sr, lazy ? c->m2 : f.pyrM + a.off1, i == 0, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1, a.w, a.h, s,
-                       lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr);
+                       lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr, a.pitch, lazy ? a.w : a.pitch, b.pitch);
         ++i;
     }
     if (tm) tm->mark("pyrdown");
@@ -543,7 +545,7 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
     for (int j = ft; j > 0;) {                     // blended level j is known; produce level j-2 or j-1
         if (fuse && j - 2 >= 1) {
             const PyrLevel &a = c->levels[j - 2], &m = c->levels[j - 1], &n = c->levels[j];
-            if (collapse2_eligible(a.w, a.h, m.w, m.h, n.w, n.h)) {
+            if (a.pitch == a.w && m.pitch == m.w && collapse2_eligible(a.w, a.h, m.w, m.h, n.w, n.h)) {
                 launch_collapse2(f.pyrL + a.off3, f.pyrR + a.off3, f.pyrM + a.off1, f.pyrL + m.off3, f.pyrR + m.off3, f.pyrM + m.off1,
                                  f.pyrL + n.off3, f.pyrR + n.off3, f.pyrB + n.off3, f.pyrB + a.off3, a.w, a.h, m.w, m.h, n.w, n.h, s);
                 j -= 2;
@@ -556,11 +558,11 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
         const void* gr = i == 0 ? (const void*)f.tr2 : (const void*)(f.pyrR + a.off3);
         const bool lazy = i == 0 && c->lazy_mask;
         launch_collapse(gl, gr, i == 0, lazy ? c->m2 : f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrB + b.off3, f.pyrB + a.off3,
-                        a.w, a.h, b.w, b.h, s, lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr);
+                        a.w, a.h, b.w, b.h, s, lazy ? (const double*)(f.d_blob + kBlobMaskAB) : nullptr, a.pitch, lazy ? a.w : a.pitch, b.pitch);
         --j;
     }
     if (tm) tm->mark("collapse");
-    launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s, done);
+    launch_unsharp(f.pyrB, f.tmp, f.diff, f.out, debug ? f.unsharpF : nullptr, W, H, amount, (const float*)f.d_blob, (float)0.3, s, done, c->levels[0].pitch);
     if (tm) tm->mark("unsharp");
 }
 
@@ -634,9 +636,11 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     }
     // the fast warp kernel takes the frame when every matrix passes the host's range check (always, short of degenerate input)
     static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
-    const bool fast_warp = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), c->plan.tri_xy.data()) &&
-                           warp_fast_geometry(W, H) && !exact_warp_only;
-    const bool bin_warp = fast_warp && bins;                 // raster fused into the warp kernel: no id map at all
+    const bool records_ok = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), c->plan.tri_xy.data()) && !exact_warp_only;
+    // raster fused into the warp kernel: no id map at all.  Any width whose level-0 rows begin on 16-byte boundaries: multiples of 4, and every width from
+    // 150 001 pixels up (level_pitch); small images of other widths keep the id-map path
+    const bool bin_warp = records_ok && bins && warp_bin_geometry(W, H) && (c->levels[0].pitch & 3) == 0;
+    const bool fast_warp = bin_warp || (records_ok && warp_fast_geometry(W, H));
     c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;
     ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
     const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
@@ -721,6 +725,7 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     ex.id_base = id_base;
     // lbmask (level 0 of pyrM) rides along with the warp only where the blend kernels cannot read it through m2
     ex.m2 = c->lazy_mask ? nullptr : c->m2; ex.mask = f.pyrM; ex.alpha = 1.0 - mask; ex.beta = -mask;
+    ex.out_pitch = c->levels[0].pitch;
     if (c->timing == 2) {       // the dispatch's own begin / end timestamps: no marker packets in the stream
         // A stamped dispatch still costs the frame loop ~5 us (it completes through a signal the host can read: 2.6 % of a
         // chained 1080p frame when every launch is stamped), so one launch in kWarpStampStride carries the stamps; the
@@ -978,21 +983,22 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     if (!c->W) return fail(c, POPPY_E_STATE, "no pair loaded");
     const size_t P = (size_t)c->W * c->H;
     const void* src = nullptr; size_t need = 0;
+    size_t px_bytes = 0;                          // set for the buffers whose rows may be padded (level 0 of the slot's own images): bytes per pixel
     std::string n(name);
     if (n != "m2" && n != "gabor2" && c->last_slot < 0) return fail(c, POPPY_E_STATE, "no frame rendered yet");
     const FrameSlot& f = c->slots[c->last_slot < 0 ? 0 : c->last_slot];          // intermediates of the last frame
     if (n == "triMap") { src = f.triMap; need = P * 4; }
-    else if (n == "trImg1") { src = f.tr1; need = P * 3; }
-    else if (n == "trImg2") { src = f.tr2; need = P * 3; }
+    else if (n == "trImg1") { src = f.tr1; need = P * 3; px_bytes = 3; }
+    else if (n == "trImg2") { src = f.tr2; need = P * 3; px_bytes = 3; }
     else if (n == "lbmask") {
         if (c->lazy_mask) {                    // never materialised by the frame: made here from m2 and the frame's (alpha, beta)
             if (hipStreamSynchronize(f.last_stream ? f.last_stream : c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "sync failed");
             launch_lbmask(c->m2, (const double*)(f.d_blob + kBlobMaskAB), f.pyrM, P, c->stream);
             if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, POPPY_E_DEVICE, "lbmask kernel failed");
         }
-        src = f.pyrM; need = P * 4;
+        src = f.pyrM; need = P * 4; px_bytes = 4;
     }
-    else if (n == "lapBlend") { src = f.pyrB; need = P * 12; }
+    else if (n == "lapBlend") { src = f.pyrB; need = P * 12; px_bytes = 12; }
     else if (n == "unsharp") {
         if (!c->debug || !f.unsharpF) return fail(c, POPPY_E_STATE, "enable debug before rendering the frame");
         src = f.unsharpF; need = P * 12;
@@ -1002,7 +1008,9 @@ int poppy_hip_debug_fetch(poppy_hip_ctx* c, const char* name, void* host, size_t
     else return fail(c, POPPY_E_ARG, "unknown debug buffer");
     if (bytes != need) return fail(c, POPPY_E_ARG, "debug buffer size mismatch");
     { int rc = drain_frames(c); if (rc) return rc; }
-    HIPCHK(c, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
+    if (px_bytes && c->levels[0].pitch != c->W)
+        HIPCHK(c, hipMemcpy2D(host, (size_t)c->W * px_bytes, src, (size_t)c->levels[0].pitch * px_bytes, (size_t)c->W * px_bytes, c->H, hipMemcpyDeviceToHost));
+    else HIPCHK(c, hipMemcpy(host, src, need, hipMemcpyDeviceToHost));
     return POPPY_OK;
 }
 

@@ -69,14 +69,16 @@ template <bool U8> __device__ __forceinline__ float ld(const void* p, size_t i) 
 
 struct DownGeom {            // host-computed constants of one pyrDown (source sw x sh, cn channels)
     int sw, sh, dw, dh, cn;
+    int sp, dp;              // pixels per row of the source / destination BUFFER (>= sw / dw: kernels.h PyrLevel::pitch)
     int w0;                  // width0 in pixels: columns reachable without the right border table
     int hBodyEnd;            // element index where the SIMD-body association of the H pass stops
     int vBodyEnd;            // same for the V pass: (dw*cn/4)*4
 };
 
-__host__ __device__ inline DownGeom make_down_geom(int sw, int sh, int cn) {
+__host__ __device__ inline DownGeom make_down_geom(int sw, int sh, int cn, int sp = 0, int dp = 0) {
     DownGeom g;
     g.sw = sw; g.sh = sh; g.cn = cn; g.dw = (sw + 1) / 2; g.dh = (sh + 1) / 2;
+    g.sp = sp > 0 ? sp : sw; g.dp = dp > 0 ? dp : g.dw;
     int w0 = (sw - 3) / 2 + 1;                 // C division truncates toward zero, as in the reference
     g.w0 = w0 < g.dw ? w0 : g.dw;
     int width = g.w0 * cn - cn;                // elements offered to the SIMD body (starts after pixel 0)
@@ -99,7 +101,7 @@ __device__ __forceinline__ float pyrdown_elem(const void* src, const DownGeom& g
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         int sy = reflect101(2 * y + k - 2, g.sh);
-        size_t base = (size_t)sy * g.sw * cn;
+        size_t base = (size_t)sy * g.sp * cn;
         float t0 = ld<U8>(src, base + col[0]), t1 = ld<U8>(src, base + col[1]), t2 = ld<U8>(src, base + col[2]);
         float t3 = ld<U8>(src, base + col[3]), t4 = ld<U8>(src, base + col[4]);
         r[k] = hBody ? t2 * 6.f + ((t1 + t3) * 4.f + (t0 + t4))
@@ -128,9 +130,10 @@ __device__ __forceinline__ float pyrup_h(const float* __restrict__ row, int sw, 
     return odd ? (s0 + sp) * 4.f : sm + s0 * 6.f + sp;
 }
 
-__device__ __forceinline__ float pyrup_elem(const float* __restrict__ src, int sw, int sh, int cn, int dy, int dxe) {
+// (sp: pixels per row of the source buffer, 0 = sw)
+__device__ __forceinline__ float pyrup_elem(const float* __restrict__ src, int sw, int sh, int cn, int dy, int dxe, int sp = 0) {
     const int sy = dy >> 1;
-    const size_t stride = (size_t)sw * cn;
+    const size_t stride = (size_t)(sp > 0 ? sp : sw) * cn;
     const float s = 1.f / 64;
     if (dy & 1) {
         int syp = reflect101((sy + 1) * 2, sh * 2) >> 1;
@@ -151,15 +154,28 @@ __device__ __forceinline__ float mix_lr(float l, float r, float m) {
     return a + b;
 }
 
+// pixels per row of the buffers of one collapse step: the Gaussian level's images (and the output), its mask, the coarser level
+struct CollapsePitch { int g, m, n; };
+__host__ __device__ inline CollapsePitch make_collapse_pitch(int w, int nw, int gp = 0, int mp = 0, int np = 0) {
+    CollapsePitch p;
+    p.g = gp > 0 ? gp : w; p.m = mp > 0 ? mp : w; p.n = np > 0 ? np : nw;
+    return p;
+}
+
+template <bool U8>
+__device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
+                                               const float* nB, int w, int h, int nw, int nh, int y, int xe, CollapsePitch cp) {
+    const size_t i = (size_t)y * cp.g * 3 + xe;
+    const float m = gM[(size_t)y * cp.m + xe / 3];
+    float lapL = ld<U8>(gL, i) - pyrup_elem(nL, nw, nh, 3, y, xe, cp.n);
+    float lapR = ld<U8>(gR, i) - pyrup_elem(nR, nw, nh, 3, y, xe, cp.n);
+    float res = mix_lr(lapL, lapR, m);
+    return pyrup_elem(nB, nw, nh, 3, y, xe, cp.n) + res;
+}
 template <bool U8>
 __device__ __forceinline__ float collapse_elem(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
                                                const float* nB, int w, int h, int nw, int nh, int y, int xe) {
-    const size_t i = (size_t)y * w * 3 + xe;
-    const float m = gM[(size_t)y * w + xe / 3];
-    float lapL = ld<U8>(gL, i) - pyrup_elem(nL, nw, nh, 3, y, xe);
-    float lapR = ld<U8>(gR, i) - pyrup_elem(nR, nw, nh, 3, y, xe);
-    float res = mix_lr(lapL, lapR, m);
-    return pyrup_elem(nB, nw, nh, 3, y, xe) + res;
+    return collapse_elem<U8>(gL, gR, gM, nL, nR, nB, w, h, nw, nh, y, xe, make_collapse_pitch(w, nw));
 }
 
 // ---- branch-free variants for levels of at least 3 x 3 pixels ------------------------------------------------
@@ -179,7 +195,7 @@ __device__ __forceinline__ float pyrdown_elem_wide(const void* src, const DownGe
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         col[k] = reflect101_once(2 * px + k - 2, g.sw) * cn + c;
-        rowo[k] = (size_t)reflect101_once(2 * y + k - 2, g.sh) * g.sw * cn;
+        rowo[k] = (size_t)reflect101_once(2 * y + k - 2, g.sh) * g.sp * cn;
     }
     float t[5][5];
 #pragma unroll
@@ -208,9 +224,9 @@ __device__ __forceinline__ float pyrup_h_wide(const float* __restrict__ row, int
     return odd ? od : ev;
 }
 
-__device__ __forceinline__ float pyrup_elem_wide(const float* __restrict__ src, int sw, int sh, int dy, int dxe) {
+__device__ __forceinline__ float pyrup_elem_wide(const float* __restrict__ src, int sw, int sh, int dy, int dxe, int sp = 0) {
     const int sy = dy >> 1;
-    const size_t stride = (size_t)sw * 3;
+    const size_t stride = (size_t)(sp > 0 ? sp : sw) * 3;
     const int sym = sy >= 1 ? sy - 1 : 1, syp = sy + 1 <= sh - 1 ? sy + 1 : sh - 1;      // sh >= 2
     const float r0 = pyrup_h_wide(src + sym * stride, sw, dxe), r1 = pyrup_h_wide(src + sy * stride, sw, dxe);
     const float r2 = pyrup_h_wide(src + syp * stride, sw, dxe);
@@ -220,11 +236,11 @@ __device__ __forceinline__ float pyrup_elem_wide(const float* __restrict__ src, 
 
 template <bool U8, typename F = MaskPlain>
 __device__ __forceinline__ float collapse_elem_wide(const void* gL, const void* gR, const float* gM, const float* nL, const float* nR,
-                                                    const float* nB, int w, int h, int nw, int nh, int y, int xe, F fn = F()) {
-    const size_t i = (size_t)y * w * 3 + xe;
-    const float m = fn(gM[(size_t)y * w + xe / 3]);
+                                                    const float* nB, int w, int h, int nw, int nh, int y, int xe, CollapsePitch cp, F fn = F()) {
+    const size_t i = (size_t)y * cp.g * 3 + xe;
+    const float m = fn(gM[(size_t)y * cp.m + xe / 3]);
     const float gl = ld<U8>(gL, i), gr = ld<U8>(gR, i);
-    const float uL = pyrup_elem_wide(nL, nw, nh, y, xe), uR = pyrup_elem_wide(nR, nw, nh, y, xe), uB = pyrup_elem_wide(nB, nw, nh, y, xe);
+    const float uL = pyrup_elem_wide(nL, nw, nh, y, xe, cp.n), uR = pyrup_elem_wide(nR, nw, nh, y, xe, cp.n), uB = pyrup_elem_wide(nB, nw, nh, y, xe, cp.n);
     return uB + mix_lr(gl - uL, gr - uR, m);
 }
 

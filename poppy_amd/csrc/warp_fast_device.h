@@ -95,7 +95,8 @@ template <typename RecOf>
 __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amdgpu_buffer_rsrc_t rs1, __amdgpu_buffer_rsrc_t rs2,
                                                        __amdgpu_buffer_rsrc_t ro1, __amdgpu_buffer_rsrc_t ro2, uint32_t pitch, uint32_t g,
                                                        const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
-                                                       uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, int x0, int y, RecOf rec_of) {
+                                                       uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, int x0, int y, RecOf rec_of,
+                                                       int out_pitch = 0) {
     u3v ra[2][4], rb[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amd
             if (!((edges >> e) & 1u)) continue;
             const int k = e & 3, im = e >> 2;
             const uint32_t v = slow_pixel(rec_of(k), im, im ? c2 : c1, W, H, x0 + k, y);
-            uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y * W + x0 + k) * 3;
+            uint8_t* dst = (uint8_t*)(im ? tr2 : tr1) + ((size_t)y * (out_pitch > 0 ? out_pitch : W) + x0 + k) * 3;
             dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
     }
