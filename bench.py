@@ -303,6 +303,50 @@ def content_sensitivity(capi, ctx, w, h):
     return out
 
 
+def odd_width(capi, dev_index):
+    """Widths that are not multiples of 4 (the reference's CLI pads to the union size of its inputs, src/poppy.cpp:186-239: any width; 5 of its 26 sample images
+    are 639 or 749 wide): pair set-up from host images and the chained frame, each beside the next multiple of 4 — 1918 / 1920 x 1080 on the synthetic pair,
+    749 / 752 x 480 and 639 / 640 x 480 on the reference's own demo pairs (tests/golden/demo_pairs.npz; the wider canvas = the image padded with its edge).
+    Rows of the frame slots' large levels are padded to 16 bytes (kernels.h: level_pitch), so every width takes the fused warp kernel and the wide
+    pyramid kernels (`frames_by_kernel`)."""
+    from poppy_amd import synth
+    def widened(img, w):          # the same content on a canvas w pixels wide (edge replicated): the multiple-of-4 neighbour of an odd-width demo image
+        return np.ascontiguousarray(np.pad(img, ((0, 0), (0, w - img.shape[1]), (0, 0)), mode="edge"))
+    cars, numbers = synth.demo_pair("cars"), synth.demo_pair("numbers")
+    cases = [("1918x1080_synthetic", lambda: synth.gen_pair(1918, 1080, seed=1234)), ("1920x1080_synthetic", lambda: synth.gen_pair(1920, 1080, seed=1234)),
+             ("749x480_cars", lambda: cars), ("752x480_cars", lambda: (widened(cars[0], 752), widened(cars[1], 752))),
+             ("639x480_numbers", lambda: numbers), ("640x480_numbers", lambda: (widened(numbers[0], 640), widened(numbers[1], 640)))]
+    shapes = np.array([capi.lib().poppy_frame_ratio(j, FRAMES, -1.0) for j in range(FRAMES)])
+    out = {}
+    for name, make in cases:
+        ctx = capi.Context(dev_index, number_of_frames=FRAMES)
+        try:
+            a, b = make()
+            ctx.pair_begin(a, b)
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter(); ctx.pair_begin(a, b); t.append((time.perf_counter() - t0) * 1e3)
+            p1, _ = ctx.pair_points()
+            k0 = ctx.warp_counts()
+            ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.reset(); ctx.render_many(shapes, chain=True)
+            ctx.sync()
+            us = (time.perf_counter() - t0) / (reps * FRAMES) * 1e6
+            k1 = ctx.warp_counts()
+            out[name] = {"pair_setup_ms_from_host_images": round(sorted(t)[len(t) // 2], 3), "point_pairs": int(len(p1)), "chained_frame_us": round(us, 1),
+                         "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), (int(y - x) for x, y in zip(k0, k1))))}
+        except Exception as e:
+            out[name] = {"error": str(e)}
+        ctx.close()
+    for odd, even in (("1918x1080_synthetic", "1920x1080_synthetic"), ("749x480_cars", "752x480_cars"), ("639x480_numbers", "640x480_numbers")):
+        if "chained_frame_us" in out.get(odd, {}) and "chained_frame_us" in out.get(even, {}):
+            out[odd]["chained_frame_vs_multiple_of_4"] = round(out[odd]["chained_frame_us"] / out[even]["chained_frame_us"], 3)
+    return out
+
+
 def run_cfg3_4k(capi, torch, dev, steps, check=True):
     """BASELINE.json configs[2]: 3840x2160 pair, 120 phase-mode frames (t_j = j / 120), set-up and writer hand-off inside."""
     w, h, n = 3840, 2160, 120
@@ -665,6 +709,10 @@ def bench_single(args, torch, capi, dev, local):
     except Exception as e:
         out["content_sensitivity"] = {"error": str(e)}
     ctx.close()
+    try:
+        out["odd_width"] = odd_width(capi, local)
+    except Exception as e:
+        out["odd_width"] = {"error": str(e)}
     try:
         out["ceilings"] = measure_ceilings(torch, dev, W, H)
         cap = out["ceilings"]["pinned_d2h_frames"]["frames_per_s_cap"]

@@ -25,6 +25,6 @@ wait
 g++ $CXXFLAGS $INC -c "$HERE/gen_golden.cpp" -o "$OUT/obj/gen_golden.o"
 g++ -o "$OUT/gen_golden" "$OUT/obj/"*.o \
   -L"$OCVB/lib" -L"$OCVB/3rdparty/lib" \
-  -lopencv_video -lopencv_photo -lopencv_calib3d -lopencv_features2d -lopencv_flann -lopencv_imgcodecs -lopencv_imgproc -lopencv_core \
+  -lopencv_highgui -lopencv_video -lopencv_photo -lopencv_calib3d -lopencv_features2d -lopencv_flann -lopencv_imgcodecs -lopencv_imgproc -lopencv_core \
   -llibpng -llibjpeg-turbo -lzlib -lpthread -ldl
 echo "built $OUT/gen_golden"

@@ -48,13 +48,8 @@ void symmetryTest(const std::vector<std::vector<cv::DMatch>>& matches1, const st
 #include <dirent.h>
 #include <sys/stat.h>
 
-// The survey-stage OpenCV build has no highgui; Poppy's util.cpp references these three
-// GUI entry points from show_image()/wait_key(), which are never reached (show_gui=false).
-namespace cv {
-void namedWindow(const String&, int) {}
-void imshow(const String&, InputArray) {}
-int waitKey(int) { return -1; }
-}
+// (Poppy's util.cpp references cv::namedWindow / imshow / waitKey from show_image() / wait_key(), never reached with show_gui = false: the
+// symbols come from the vendored highgui module, built without a window back end — build_ocv.sh.  Until round 4 three no-op stand-ins stood here.)
 
 using namespace cv;
 using namespace poppy;

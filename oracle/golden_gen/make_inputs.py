@@ -82,6 +82,10 @@ ASTAGE = {
     "a_320x180_photo": (320, 180, 3, -1.0, 64, 0, (0.5,), "photo"),
     "a_256x192_textured": (256, 192, 3, -1.0, 64, 0, (), "textured"),
     "a_1920x1080_photo60": (1920, 1080, 60, -1.0, 64, 0, (), "photo"),    # BASELINE.json configs[1] on the photographs: frames pinned by sha256
+    # round 5: two of the reference's own demo pairs whose widths are no multiples of 4 (make_demos.sh:15,31; tests/golden/demo_pairs.npz, synth.demo_pair):
+    # the whole of poppy::morph at the sizes that took the general kernels until then
+    "a_639x480_numbers": (639, 480, 4, -1.0, 64, 0, (0.5,), "numbers"),
+    "a_749x480_cars": (749, 480, 4, -1.0, 64, 0, (0.5,), "cars"),
     # (A featureless second image does NOT reach the linear-blend fallback of src/poppy.hpp:125-134: with empty point lists
     #  Matcher::find -> morph_distance -> cv::convexHull throws "total >= 0 && (depth == CV_32F || depth == CV_32S)" first —
     #  tried with the generator.  The fallback expression itself is pinned by x_dissolve_* below.)
@@ -170,6 +174,9 @@ def astage_inputs(name):
         a, b = synth.photo_pair(w, h)
     if variant == "textured":
         a, b = synth.textured_bgr(w, h, 7), synth.textured_bgr(w, h, 8)
+    if variant in ("numbers", "cars"):
+        a, b = synth.demo_pair(variant)
+        assert a.shape == (h, w, 3) and b.shape == (h, w, 3)
     if variant == "flat2":                          # a featureless second image: ORB finds nothing, the point lists come back empty
         b = np.full_like(a, 77)                     # (the reference throws on it, see ASTAGE; kept for the library's own error test)
     cfg = [nframes, phase, levels] + ([align] if (align or len(t) > 6) else []) + extra

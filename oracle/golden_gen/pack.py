@@ -33,7 +33,8 @@ def load_raw(path):
 
 
 # long sequences: frames are pinned by their sha256 only (first and last kept in full for debugging)
-HASH_ONLY_FRAMES = {"a_512x512_chain30": ("frame0", "frame29"), "a_1920x1080_chain60": (), "a_3840x2160_phase": (), "a_1920x1080_photo60": ()}
+HASH_ONLY_FRAMES = {"a_512x512_chain30": ("frame0", "frame29"), "a_1920x1080_chain60": (), "a_3840x2160_phase": (), "a_1920x1080_photo60": (),
+                    "a_639x480_numbers": ("frame0",), "a_749x480_cars": ("frame0",)}
 
 
 def keep_full(name, arr, case=""):

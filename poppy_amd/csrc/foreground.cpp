@@ -3,6 +3,7 @@
 // Everything stays in HBM between the steps; the only host work is the schedule of learning rates.
 #include "foreground.h"
 #include "kernels_prefilter.h"
+#include "kernels.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -206,7 +207,7 @@ int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int fo
 int ForegroundFilter::run(const uint8_t* bgr, size_t stride, int w, int h, hipStream_t s, uint8_t* dst, const ForegroundDebugOut* dbg) {
     if (!bgr || !dst || w <= 0 || h <= 0 || stride < (size_t)w * 3) { err = "bad arguments"; return -1; }
     if (ensure(w, h)) return -2;
-    FG_CHK(hipMemcpy2DAsync(d_bgr, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, s));
+    FG_CHK(copy_rows_async(d_bgr, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, s));
     median_cols_hint = median_cols_hint_from_host(bgr, stride, w, h);
     const uint8_t* r = run_device(d_bgr, (size_t)w * 3, w, h, s, dbg);
     if (!r) return -2;

@@ -19,6 +19,13 @@ struct PyrLevel {        // geometry of one pyramid level and of the pyrDown tha
 constexpr size_t kPitchMinPixels = 150001;          // (= above kFuseMaxPixels)
 inline int level_pitch(int w, int h) { return ((w & 3) && (size_t)w * h >= kPitchMinPixels) ? (w + 3) & ~3 : w; }
 
+// hipMemcpy2DAsync, except that rows which are tight on both sides go as ONE linear copy: a 2-D copy whose row length is no multiple of 4 bytes
+// takes a slow path of the runtime (639 x 480 x 3: 4 ms against 0.03; 1918 x 1080 x 3: 9 ms)
+inline hipError_t copy_rows_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s) {
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * height, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
+}
+
 // --- once per pair ---------------------------------------------------------------------------
 // m2 = 1 - gray(gabor2)   (src/algo.cpp:250-252)
 void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s);

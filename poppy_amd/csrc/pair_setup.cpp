@@ -66,7 +66,7 @@ static int align_stage(poppy_hip_ctx* c, const uint8_t* img, size_t stride, int 
         HIPCHK(c, hipMalloc((void**)&c->d_align, bytes));
         c->d_align_bytes = bytes;
     }
-    HIPCHK(c, hipMemcpy2DAsync(c->d_align, (size_t)W * 3, img, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy_rows_async(c->d_align, (size_t)W * 3, img, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
     return POPPY_OK;
 }
 
@@ -79,7 +79,7 @@ int poppy_hip_warp_affine(poppy_hip_ctx* c, const uint8_t* src, size_t ss, int W
     HIPCHK(c, hipMalloc((void**)&d_out, (size_t)W * H * 3));
     hipError_t e = hipMalloc((void**)&d_tab, (size_t)2 * (W + H) * sizeof(int));
     bool ok = e == hipSuccess && warp_affine_device(c->d_align, d_out, W, H, M, d_tab, c->stream);
-    if (ok) ok = hipMemcpy2DAsync(dst, ds, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+    if (ok) ok = copy_rows_async(dst, ds, d_out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                  hipStreamSynchronize(c->stream) == hipSuccess;
     (void)hipFree(d_out); if (d_tab) (void)hipFree(d_tab);
     return ok ? POPPY_OK : fail(c, POPPY_E_DEVICE, "warp_affine failed");
@@ -95,7 +95,7 @@ static int align_host_entry(poppy_hip_ctx* c, int which, uint8_t* img, size_t st
     rc = which < 0 ? c->aligner.run(c->d_align, W, H, a, b, c->stream, dist) : c->aligner.step(which, c->d_align, W, H, a, b, c->stream, dist);
     if (rc) return fail(c, rc == -1 ? POPPY_E_ARG : POPPY_E_DEVICE, c->aligner.err.c_str());
     memcpy(p2, b.data(), (size_t)n * 8);
-    HIPCHK(c, hipMemcpy2DAsync(img, stride, c->d_align, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy_rows_async(img, stride, c->d_align, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return POPPY_OK;
 }
@@ -393,7 +393,7 @@ int poppy_hip_pair_corrected2(poppy_hip_ctx* c, uint8_t* dst, size_t ds) {
     if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no resident pair");
     if (ds < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "stride too small");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy2DAsync(dst, ds, c->c2, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy_rows_async(dst, ds, c->c2, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return POPPY_OK;
 }
@@ -437,7 +437,7 @@ int poppy_hip_gabor_field(poppy_hip_ctx* c, const uint8_t* bgr, size_t stride, i
     HIPCHK(c, hipSetDevice(c->device));
     ForegroundFilter& fg = c->foreground;
     if (fg.prepare(W, H)) { c->err = "foreground: " + fg.err; return POPPY_E_DEVICE; }
-    HIPCHK(c, hipMemcpy2DAsync(fg.bgr_staging(), (size_t)W * 3, bgr, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy_rows_async(fg.bgr_staging(), (size_t)W * 3, bgr, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
     const float* gab = fg.gabor_field(fg.bgr_staging(), W, H, c->stream);
     if (!gab) { c->err = "gabor_field: " + fg.err; return POPPY_E_DEVICE; }
     HIPCHK(c, hipMemcpyAsync(out, gab, (size_t)W * H * 12, hipMemcpyDeviceToHost, c->stream));
@@ -471,14 +471,14 @@ int poppy_hip_blur_margin(poppy_hip_ctx* c, const uint8_t* src, size_t stride, i
     const double margin = (W + H) / 100.0;
     double dx = std::fabs((double)(W - UW)) / 2.0, dy = std::fabs((double)(H - UH)) / 2.0;
     const int rx = (int)dx, ry = (int)dy;
-    if (e == hipSuccess) e = hipMemcpy2DAsync(canvas + ((size_t)ry * UW + rx) * 3, (size_t)UW * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = copy_rows_async(canvas + ((size_t)ry * UW + rx) * 3, (size_t)UW * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, canvas, UB, hipMemcpyDeviceToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }
     dx = (dx == 0 ? 1.3 : dx + margin);
     dy = (dy == 0 ? 1.3 : dy + margin);
     const int rects[4][4] = {{0, 0, (int)dx, UH}, {(int)(UW - dx), 0, (int)dx, UH}, {0, 0, UW, (int)dy}, {0, (int)(UH - dy), UW, (int)dy}};
     for (const auto& r : rects) launch_strip_blur(canvas, out, UW, tmp, d_taps, n, r[0], r[1], r[2], r[3], c->stream);   // left, right, top, bottom: later strips win
-    e = hipMemcpy2DAsync(dst, dst_stride, out, (size_t)UW * 3, (size_t)UW * 3, UH, hipMemcpyDeviceToHost, c->stream);
+    e = copy_rows_async(dst, dst_stride, out, (size_t)UW * 3, (size_t)UW * 3, UH, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) { c->err = std::string("blur_margin: ") + hipGetErrorString(e); return POPPY_E_DEVICE; }

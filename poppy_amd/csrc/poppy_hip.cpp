@@ -767,7 +767,8 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
 }
 
 int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H) {
-    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)W * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
+    // (tight rows go as one linear copy: kernels.h copy_rows_async; only images that really have padded rows — ROIs — pay the 2-D copy's slow path at odd widths)
+    HIPCHK(c, copy_rows_async(dst, (size_t)W * 3, src, stride, (size_t)W * 3, H, hipMemcpyHostToDevice, c->stream));
     return POPPY_OK;
 }
 
@@ -821,7 +822,7 @@ int poppy_hip_render(poppy_hip_ctx* c, double shape, double mask, int chain, uin
         if (dst_stride < (size_t)c->W * 3) return fail(c, POPPY_E_ARG, "dst_stride too small");
         FrameSlot& f = c->slots[c->last_slot];
         hipStream_t fs = f.last_stream ? f.last_stream : c->stream;               // in order behind the frame itself
-        HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, f.out, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, fs));
+        HIPCHK(c, copy_rows_async(dst, dst_stride, f.out, (size_t)c->W * 3, (size_t)c->W * 3, c->H, hipMemcpyDeviceToHost, fs));
         HIPCHK(c, hipStreamSynchronize(fs));
     }
     return POPPY_OK;
@@ -972,7 +973,7 @@ int poppy_hip_dissolve(poppy_hip_ctx* c, const uint8_t* img1, size_t s1, const u
     // Mat blend = img2*phase + img1*(1.0-phase)  ->  addWeighted(img2, phase, img1, 1-phase, 0)
     launch_dissolve(c->c2, c->c1, c->slots[0].out, (size_t)W * H * 3, (float)phase, (float)(1.0 - phase), c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->slots[0].out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy_rows_async(dst, dst_stride, c->slots[0].out, (size_t)W * 3, (size_t)W * 3, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pair_ready = false;
     return POPPY_OK;

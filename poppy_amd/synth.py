@@ -152,6 +152,14 @@ def photo_pair(w, h):
     return upscale_bgr(z["a"], w, h), upscale_bgr(z["b"], w, h)
 
 
+def demo_pair(name):
+    """One of the reference's own demo pairs of a width that is no multiple of 4 (committed as pixels: tests/golden/demo_pairs.npz, tools/make_demo_fixture.py):
+    "numbers" = images/1st.png + 2nd.png (639 x 480), "cars" = images/kindpng1s.png + kindpng2s.png (749 x 480)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "demo_pairs.npz"))
+    return np.ascontiguousarray(z[name + "_a"]), np.ascontiguousarray(z[name + "_b"])
+
+
 def fnv1a64(buf):
     """FNV-1a over the raw bytes of an array (used by the golden manifests)."""
     data = np.ascontiguousarray(buf).view(np.uint8).ravel()

@@ -5,6 +5,7 @@ of 4 inside the frame slots (kernels.h: level_pitch), so that the fused raster +
 import numpy as np
 import pytest
 
+import golden_util as G
 import oracle_lib as O
 from poppy_amd import capi, synth
 
@@ -78,3 +79,32 @@ def test_chained_sequence_vs_oracle(w, h):
             cur, pts = want, mp
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("case", ["a_639x480_numbers", "a_749x480_cars"])
+def test_reference_demo_pairs_whole_morph(case):
+    """The whole of poppy::morph on two of the reference's own demo pairs whose widths are no multiples of 4 (make_demos.sh:15 `cars`, 749 x 480; :31 `numbers`,
+    639 x 480; pixels committed as tests/golden/demo_pairs.npz) against runs of the REAL reference on the same pixels: nfeatures, both details, the prepared
+    point pairs, the printed morph distance, every chained frame (frame 0 in full, the others by sha256) and a phase-mode frame."""
+    inp = G.astage_inputs(case)
+    n = int(inp["cfg"][0])
+    c = capi.Context(0, number_of_frames=n)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"])
+    assert rc == 0 and len(frames) == n
+    nf, det = c.pair_begin_info()
+    ref = G.full(case, "detail")
+    assert nf == int(ref[3]) and det == (ref[0], ref[1])
+    assert dist == float(G.full(case, "printedMorphDist")[0])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
+    assert c.last_warp_kind() == 2
+    G.check(case, "frame0", frames[0])
+    bad = [j for j, f in enumerate(frames) if G.sha(f) != G.entries(case)[f"frame{j}"]["sha256"]]
+    assert not bad, f"frames {bad} differ from the reference"
+    c.close()
+    c1 = capi.Context(0, number_of_frames=1)                            # a phase-mode frame of the same pair
+    rc, fr, _ = c1.morph(inp["img1"], inp["img2"], phase=float(inp["cfg"][4]))
+    assert rc == 0 and len(fr) == 1
+    assert G.sha(fr[0]) == G.entries(case)["phase0_frame"]["sha256"]
+    c1.close()

@@ -12,6 +12,10 @@ below are inputs and expected outputs of those tests (data, not code).
   pyrDown                          OCV/imgproc/test/test_filter.cpp:2318-2324 (issue_12961: zeros stay zeros)
   cvRound (double and float)       OCV/core/test/test_arithm.cpp:1679-1690 (Core_round.CvRound: halves to even)
   large-kernel filter2D            OCV/imgproc/test/test_filter.cpp:2147-2221 (dftFilter2d_regression_10683: literal 24 x 24 in / out, tol 2)
+                                   OCV/imgproc/test/test_filter.cpp:2223-2282 (dftFilter2d_regression_13179: a 13 x 13 getGaborKernel on a 16 x 16 ROI, literal in / out, tol 2)
+  float GaussianBlur               OCV/imgproc/test/test_filter.cpp:2358-2367 (regression_11303: a blurred constant image stays the constant, 2115 x 211 — as a property
+                                   of the oracle's own two float Gaussians; the reference call's sigma 8.64 kernel is not on the path)
+  medianBlur                       OCV/imgproc/test/test_filter.cpp:2284-2294 (hires_regression_13409: the median of a region = the region of the median, images over 1024)
 Not usable: Multiply.FloatingPointRounding (test_arithm.cpp:1649-1657) pins cv::multiply(Mat, Scalar) in double; the path has no such call
 (its scaled accumulate is MatExpr `flow * s`, a convertTo with a float scale: oracle/prefilter.cpp accumulate_scaled_u8).
 """
@@ -115,37 +119,40 @@ def test_cv_round_known_answers():
         assert L.orc_round_f(x) == want, x          # all nine values are exact in float: the float overload agrees
 
 
+_SRC_10683 = np.array([
+    0, 40, 0, 0, 255, 0, 0, 78, 131, 0, 196, 0, 255, 0, 0, 0, 0, 255, 70, 0, 255, 0, 0, 0,
+    0, 0, 255, 204, 0, 0, 255, 93, 255, 0, 0, 255, 12, 0, 0, 0, 255, 121, 0, 255, 0, 0, 0, 255,
+    0, 178, 0, 25, 67, 0, 165, 0, 255, 0, 0, 181, 151, 175, 0, 0, 32, 0, 0, 255, 165, 93, 0, 255,
+    255, 255, 0, 0, 255, 126, 0, 0, 0, 0, 133, 29, 9, 0, 220, 255, 0, 142, 255, 255, 255, 0, 255, 0,
+    255, 32, 255, 0, 13, 237, 0, 0, 0, 0, 0, 19, 90, 0, 0, 85, 122, 62, 95, 29, 255, 20, 0, 0,
+    0, 0, 166, 41, 0, 48, 70, 0, 68, 0, 255, 0, 139, 7, 63, 144, 0, 204, 0, 0, 0, 98, 114, 255,
+    105, 0, 0, 0, 0, 255, 91, 0, 73, 0, 255, 0, 0, 0, 255, 198, 21, 0, 0, 0, 255, 43, 153, 128,
+    0, 98, 26, 0, 101, 0, 0, 0, 255, 0, 0, 0, 255, 77, 56, 0, 241, 0, 169, 132, 0, 255, 186, 255,
+    255, 87, 0, 1, 0, 0, 10, 39, 120, 0, 23, 69, 207, 0, 0, 0, 0, 84, 0, 0, 0, 0, 255, 0,
+    255, 0, 0, 136, 255, 77, 247, 0, 67, 0, 15, 255, 0, 143, 0, 243, 255, 0, 0, 238, 255, 0, 255, 8,
+    42, 0, 0, 255, 29, 0, 0, 0, 255, 255, 255, 75, 0, 0, 0, 255, 0, 0, 255, 38, 197, 0, 255, 87,
+    0, 123, 17, 0, 234, 0, 0, 149, 0, 0, 255, 16, 0, 0, 0, 255, 0, 255, 0, 38, 0, 114, 255, 76,
+    0, 0, 8, 0, 255, 0, 0, 0, 220, 0, 11, 255, 0, 0, 55, 98, 0, 0, 0, 255, 0, 175, 255, 110,
+    235, 0, 175, 0, 255, 227, 38, 206, 0, 0, 255, 246, 0, 0, 123, 183, 255, 0, 0, 255, 0, 156, 0, 54,
+    0, 255, 0, 202, 0, 0, 0, 0, 157, 0, 255, 63, 0, 0, 0, 0, 0, 255, 132, 0, 255, 0, 0, 0,
+    0, 0, 0, 255, 0, 0, 128, 126, 0, 243, 46, 7, 0, 211, 108, 166, 0, 0, 162, 227, 0, 204, 0, 51,
+    255, 216, 0, 0, 43, 0, 255, 40, 188, 188, 255, 0, 0, 255, 34, 0, 0, 168, 0, 0, 0, 35, 0, 0,
+    0, 80, 131, 255, 0, 255, 10, 0, 0, 0, 180, 255, 209, 255, 173, 34, 0, 66, 0, 49, 0, 255, 83, 0,
+    0, 204, 0, 91, 0, 0, 0, 205, 84, 0, 0, 0, 92, 255, 91, 0, 126, 0, 185, 145, 0, 0, 9, 0,
+    255, 0, 0, 255, 255, 0, 0, 255, 0, 0, 216, 0, 187, 221, 0, 0, 141, 0, 0, 209, 0, 0, 255, 0,
+    255, 0, 0, 154, 150, 0, 0, 0, 148, 0, 201, 255, 0, 255, 16, 0, 0, 160, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 255, 0, 255, 0, 255, 0, 255, 198, 255, 147, 131, 0, 255, 202, 0, 0, 0, 0, 255, 0,
+    0, 0, 0, 164, 181, 0, 0, 0, 69, 255, 31, 0, 255, 195, 0, 0, 255, 164, 109, 0, 0, 202, 0, 206,
+    0, 0, 61, 235, 33, 255, 77, 0, 0, 0, 0, 85, 0, 228, 0, 0, 0, 0, 255, 0, 0, 5, 255, 255], np.float32).reshape(24, 24)      # the literal 24 x 24 image of regressions 10683 and 13179
+
+
 def test_dft_filter2d_regression_10683():
     """Imgproc_Filter2D.dftFilter2d_regression_10683 (OCV/imgproc/test/test_filter.cpp:2147-2221): a 24 x 24 8-bit image filtered with a
     12 x 12 box kernel through filter2D's DFT path, literal input and expected output, tolerance 2.  filter2D with a kernel this large is
     the correlation the Gabor banks take (OCV/imgproc/src/filter.dispatch.cpp:1291-1292 -> crossCorr); the oracle's form of it is
     gabor_filter_direct (double sums, one rounding; anchor ks / 2, BORDER_REFLECT_101).  Sixteen copies of the box kernel stand in for the
     sixteen orientations: on an image scaled to [0, 1] the bank's clamp does nothing and the mean of sixteen equal planes is the plane."""
-    src = np.array([
-        0, 40, 0, 0, 255, 0, 0, 78, 131, 0, 196, 0, 255, 0, 0, 0, 0, 255, 70, 0, 255, 0, 0, 0,
-        0, 0, 255, 204, 0, 0, 255, 93, 255, 0, 0, 255, 12, 0, 0, 0, 255, 121, 0, 255, 0, 0, 0, 255,
-        0, 178, 0, 25, 67, 0, 165, 0, 255, 0, 0, 181, 151, 175, 0, 0, 32, 0, 0, 255, 165, 93, 0, 255,
-        255, 255, 0, 0, 255, 126, 0, 0, 0, 0, 133, 29, 9, 0, 220, 255, 0, 142, 255, 255, 255, 0, 255, 0,
-        255, 32, 255, 0, 13, 237, 0, 0, 0, 0, 0, 19, 90, 0, 0, 85, 122, 62, 95, 29, 255, 20, 0, 0,
-        0, 0, 166, 41, 0, 48, 70, 0, 68, 0, 255, 0, 139, 7, 63, 144, 0, 204, 0, 0, 0, 98, 114, 255,
-        105, 0, 0, 0, 0, 255, 91, 0, 73, 0, 255, 0, 0, 0, 255, 198, 21, 0, 0, 0, 255, 43, 153, 128,
-        0, 98, 26, 0, 101, 0, 0, 0, 255, 0, 0, 0, 255, 77, 56, 0, 241, 0, 169, 132, 0, 255, 186, 255,
-        255, 87, 0, 1, 0, 0, 10, 39, 120, 0, 23, 69, 207, 0, 0, 0, 0, 84, 0, 0, 0, 0, 255, 0,
-        255, 0, 0, 136, 255, 77, 247, 0, 67, 0, 15, 255, 0, 143, 0, 243, 255, 0, 0, 238, 255, 0, 255, 8,
-        42, 0, 0, 255, 29, 0, 0, 0, 255, 255, 255, 75, 0, 0, 0, 255, 0, 0, 255, 38, 197, 0, 255, 87,
-        0, 123, 17, 0, 234, 0, 0, 149, 0, 0, 255, 16, 0, 0, 0, 255, 0, 255, 0, 38, 0, 114, 255, 76,
-        0, 0, 8, 0, 255, 0, 0, 0, 220, 0, 11, 255, 0, 0, 55, 98, 0, 0, 0, 255, 0, 175, 255, 110,
-        235, 0, 175, 0, 255, 227, 38, 206, 0, 0, 255, 246, 0, 0, 123, 183, 255, 0, 0, 255, 0, 156, 0, 54,
-        0, 255, 0, 202, 0, 0, 0, 0, 157, 0, 255, 63, 0, 0, 0, 0, 0, 255, 132, 0, 255, 0, 0, 0,
-        0, 0, 0, 255, 0, 0, 128, 126, 0, 243, 46, 7, 0, 211, 108, 166, 0, 0, 162, 227, 0, 204, 0, 51,
-        255, 216, 0, 0, 43, 0, 255, 40, 188, 188, 255, 0, 0, 255, 34, 0, 0, 168, 0, 0, 0, 35, 0, 0,
-        0, 80, 131, 255, 0, 255, 10, 0, 0, 0, 180, 255, 209, 255, 173, 34, 0, 66, 0, 49, 0, 255, 83, 0,
-        0, 204, 0, 91, 0, 0, 0, 205, 84, 0, 0, 0, 92, 255, 91, 0, 126, 0, 185, 145, 0, 0, 9, 0,
-        255, 0, 0, 255, 255, 0, 0, 255, 0, 0, 216, 0, 187, 221, 0, 0, 141, 0, 0, 209, 0, 0, 255, 0,
-        255, 0, 0, 154, 150, 0, 0, 0, 148, 0, 201, 255, 0, 255, 16, 0, 0, 160, 0, 0, 0, 0, 0, 0,
-        0, 0, 0, 0, 255, 0, 255, 0, 255, 0, 255, 198, 255, 147, 131, 0, 255, 202, 0, 0, 0, 0, 255, 0,
-        0, 0, 0, 164, 181, 0, 0, 0, 69, 255, 31, 0, 255, 195, 0, 0, 255, 164, 109, 0, 0, 202, 0, 206,
-        0, 0, 61, 235, 33, 255, 77, 0, 0, 0, 0, 85, 0, 228, 0, 0, 0, 0, 255, 0, 0, 5, 255, 255], np.float32).reshape(24, 24)
+    src = _SRC_10683
     expected = np.array([
         83, 83, 77, 80, 76, 76, 76, 75, 71, 67, 72, 71, 73, 70, 80, 83, 86, 84, 89, 88, 88, 96, 99, 98,
         83, 83, 77, 80, 76, 76, 76, 75, 71, 67, 72, 71, 73, 70, 80, 83, 86, 84, 89, 88, 88, 96, 99, 98,
@@ -176,3 +183,66 @@ def test_dft_filter2d_regression_10683():
     plane = O.gabor_filter_direct(src / np.float32(255.0), ks, bank)
     got = np.rint(plane.astype(np.float64) * 255.0).astype(np.int32)
     assert np.abs(got - expected).max() <= 2, np.abs(got - expected).max()
+
+
+def test_dft_filter2d_regression_13179():
+    """Imgproc_Filter2D.dftFilter2d_regression_13179 (OCV/imgproc/test/test_filter.cpp:2223-2282): the 16 x 16 top-left ROI of a literal 24 x 24 8-bit image
+    filtered with getGaborKernel(Size(13, 13), 8, 0, 3, 0.25) through filter2D's DFT path (the ROI is not isolated: its right and bottom borders are the
+    parent image's pixels, its left and top ones the reflection), literal expected output, tolerance 2.  As in regression_10683 above the oracle's form is
+    gabor_filter_direct with sixteen copies of the kernel on the image scaled to [0, 1] (the bank's clamp = the 8-bit saturation).  The kernel comes from
+    getGaborKernel's formula (OCV/imgproc/src/gabor.cpp:50-95) restated here in double, AND from the oracle's own bank generator (orientation 0 of
+    gabor_bank(13, 8, 3, 0.25, pi / 2) — the function the hot path's banks come from): the two must agree to float precision."""
+    src = _SRC_10683
+    expected = np.array([
+        0, 255, 0, 0, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 0, 0,
+        0, 255, 0, 0, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 0, 0,
+        0, 255, 0, 0, 255, 0, 0, 255, 70, 0, 255, 255, 0, 255, 0, 0,
+        0, 234, 138, 0, 255, 0, 0, 255, 8, 0, 255, 255, 0, 255, 0, 0,
+        0, 0, 255, 0, 255, 228, 0, 255, 255, 0, 255, 255, 0, 255, 0, 5,
+        0, 0, 255, 0, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 0, 0,
+        0, 253, 0, 0, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 0, 0,
+        0, 255, 0, 0, 255, 0, 0, 255, 0, 0, 255, 93, 0, 255, 0, 255,
+        0, 255, 0, 0, 255, 0, 182, 255, 0, 0, 255, 0, 0, 255, 0, 0,
+        0, 0, 253, 0, 228, 0, 255, 255, 0, 0, 255, 0, 0, 0, 0, 75,
+        0, 0, 255, 0, 0, 0, 255, 255, 0, 255, 206, 0, 1, 162, 0, 255,
+        0, 0, 255, 0, 0, 0, 255, 255, 0, 255, 255, 0, 0, 255, 0, 255,
+        0, 0, 255, 0, 0, 0, 255, 255, 0, 255, 255, 0, 255, 255, 0, 255,
+        0, 0, 255, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 168, 0, 255,
+        0, 0, 255, 255, 0, 0, 255, 26, 0, 255, 255, 0, 255, 255, 0, 255,
+        0, 0, 255, 255, 0, 0, 255, 0, 0, 255, 255, 0, 255, 255, 0, 255], np.int32).reshape(16, 16)
+    ks, sigma, theta, lambd, gamma, psi = 13, 8.0, 0.0, 3.0, 0.25, np.pi * 0.5
+    r = ks // 2
+    yy, xx = np.mgrid[-r:r + 1, -r:r + 1].astype(np.float64)
+    xr = xx * np.cos(theta) + yy * np.sin(theta); yr = -xx * np.sin(theta) + yy * np.cos(theta)
+    v = np.exp(-0.5 / sigma ** 2 * xr ** 2 - 0.5 / (sigma / gamma) ** 2 * yr ** 2) * np.cos(2 * np.pi / lambd * xr + psi)
+    kernel = np.ascontiguousarray(v[::-1, ::-1])                       # kernel(ymax - y, xmax - x) = v(x, y)
+    own = O.gabor_bank(ks, sigma, lambd, gamma, psi)[0]
+    assert np.abs(own.astype(np.float64) - kernel).max() < 1e-6
+    for k32 in (kernel.astype(np.float32), own):
+        bank = np.ascontiguousarray(np.broadcast_to(k32, (16, ks, ks)))
+        plane = O.gabor_filter_direct(src / np.float32(255.0), ks, bank)
+        got = np.rint(plane.astype(np.float64) * 255.0).astype(np.int32)[:16, :16]
+        assert np.abs(got - expected).max() <= 2, np.abs(got - expected).max()
+
+
+def test_gaussian_blur_regression_11303_property():
+    """Imgproc_GaussianBlur.regression_11303 (OCV/imgproc/test/test_filter.cpp:2358-2367): a float GaussianBlur of a constant 2115 x 211 image must return the
+    constant (norm L2 <= 1e-3) — normalised taps and reflected borders.  The reference call's kernel (sigma 8.64, 71 taps) is not on the path; the property is
+    asserted for the oracle's own float Gaussians: the 9-tap sigma-1 blur inside unsharp_mask (src/util.cpp:113-148) and the 17-tap sigma-2 one of
+    Extractor::keypoints' unsharp (src/extractor.cpp:57), at the regression's geometry."""
+    img = np.ones((211, 2115, 3), np.float32)
+    _, blur, _ = O.unsharp(img, 1.0, 0.3)
+    assert float(np.sqrt(((blur.astype(np.float64) - 1.0) ** 2).sum())) <= 1e-3
+    us = O.orb_unsharp_gray(np.full((211, 2115), 255, np.uint8))      # constant image: blurred == itself, the difference is 0, the output the input
+    assert float(np.sqrt(((us.astype(np.float64) - 1.0) ** 2).sum())) <= 1e-3
+
+
+def test_median_blur_hires_regression_13409():
+    """Imgproc_MedianBlur.hires_regression_13409 (OCV/imgproc/test/test_filter.cpp:2284-2294): on an image with sides over 1024 (the reference tiles such images)
+    medianBlur of a region equals the region of medianBlur away from the region's own border, ksize 9 — the first window of Extractor::foreground's chain
+    (src/extractor.cpp:149).  The oracle's median has no tiles; the test pins that it is a pure sliding-window function."""
+    rng = np.random.default_rng(13409)
+    src = rng.integers(0, 256, (1100, 1300), dtype=np.uint8)
+    whole = O.median_blur_u8(src, 9)
+    part = O.median_blur_u8(np.ascontiguousarray(src[150:950, 200:1100]), 9)
+    assert np.array_equal(whole[154:946, 204:1096], part[4:-4, 4:-4])
