@@ -126,7 +126,14 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
                            "bound_us": round(bound_us, 2), "frac_of_launch": round(bound_us / (per_launch_ms * 1e3), 3) if per_launch_ms > 0 else None,
                            "note": "vector issue cycles of the kernel's main path by the measured per-instruction costs of gfx950 (profiles/r03_notes.md section 1: "
                                    "2 cycles full rate, 4 half rate incl. every packed / perm / dot / cvt / min-max, 8 quarter) x waves / 1024 SIMDs / %.1f GHz: the time the "
-                                   "arithmetic alone needs; the binding resource beside the HBM fraction" % clk}
+                                   "arithmetic alone needs; the binding resource beside the HBM fraction" % clk,
+                           # the kernel's arithmetic run ALONE on register data (tools/micro/warp_alu.hip, profiles/r04_warp_alu.txt) and what deleting pieces of
+                           # TODAY'S kernel does to its time in the chained loop (tools/experiments/abl_build.sh + abl_run.sh, profiles/r05_warp_ablation.txt)
+                           "alu_floor_us": {"1920x1080": 7.7, "3840x2160": 30.5}.get(f"{w}x{h}"),
+                           "ablation_4k_us": {"as_shipped": 45.8, "no_division": 46.8, "constant_weights": 46.3, "no_blend": 43.9, "no_footprint_loads": 41.4, "all_four": 30.2,
+                                              "reading": "no single deletion moves the kernel by more than 10 % (the division: +2 %), all four together by a third: it is not bound by "
+                                                         "instruction issue — the arithmetic-only 30.5 us is not its floor — but by its workgroups' turnover (ids + record slots -> barrier -> "
+                                                         "taps -> gathers -> stores: 30 us of it remain with no arithmetic and no gather at all); DESIGN.md section 4"}}
     try:        # the frame's other full-resolution kernels, from the same committed trace: duration, algorithmic bytes (DESIGN.md's kernel table), fraction of 8 TB/s
         allf = json.load(open(os.path.join(ROOT, "profiles", "r04_warp_facts.json"))).get(f"{w}x{h}", {})
         others = {v["kernel"]: {k2: v[k2] for k2 in ("what", "algo_bytes_per_px", "trace_avg_us", "achieved_GBps", "frac_of_8_TBps")}

@@ -64,6 +64,16 @@ __device__ __forceinline__ Interval fill_row(const RasterTriDev& r, int y, int W
     return iv;
 }
 
+// floor(a / b) for a >= 0, b > 0 whose quotient is below 2^15 (the callers' coordinates are clipped to the image: < 2^14): a float
+// reciprocal with a correction step each way — a relative error of a few 2^-24 moves a quotient below 2^15 by less than one —
+// instead of the ~30 instructions of an integer division
+__device__ __forceinline__ int div_small_quotient(unsigned a, unsigned b) {
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const int r = (int)(a - (unsigned)q * b);                    // (wraps to the true remainder when q is off by one)
+    q += (r >= (int)b) - (r < 0);
+    return q;
+}
+
 // pixels of one outline segment on row y: the steps k of the 8-connected Bresenham walk (drawing.cpp:159-245 with
 // leftToRight) whose minor offset m_k = max(0, ceil((2 minor k - major) / (2 major))) puts them on this row
 __device__ __forceinline__ Interval outline_row(int4 seg, int y) {
@@ -75,12 +85,12 @@ __device__ __forceinline__ Interval outline_row(int4 seg, int y) {
         if (d < 0 || d > major) return iv;
         int m = 0;
         const int num = 2 * minor * d - major;
-        if (num > 0) m = (num + 2 * major - 1) / (2 * major);
+        if (num > 0) m = div_small_quotient((unsigned)(num + 2 * major - 1), (unsigned)(2 * major));
         iv.lo = iv.hi = x0 + m;
     } else {                                                     // shallow: row d holds the run of steps with m_k == d
         if (d < 0 || d > minor) return iv;
-        const int k_lo = d == 0 ? 0 : (int)((unsigned)(major * (2 * d - 1)) / (unsigned)(2 * minor)) + 1;
-        const int k_hi = d == minor ? major : (int)((unsigned)(major * (2 * d + 1)) / (unsigned)(2 * minor));
+        const int k_lo = d == 0 ? 0 : div_small_quotient((unsigned)(major * (2 * d - 1)), (unsigned)(2 * minor)) + 1;
+        const int k_hi = d == minor ? major : div_small_quotient((unsigned)(major * (2 * d + 1)), (unsigned)(2 * minor));
         iv.lo = x0 + k_lo; iv.hi = x0 + k_hi;
     }
     return iv;
@@ -122,7 +132,7 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
                                                      const uint16_t* __restrict__ tile_tris, uint8_t* __restrict__ tile_data,
                                                      int W, int tiles_x, int n_tiles) {
     constexpr int kTileH = 1024 / kTileW, kPass = 256 / kTileH, kWords = kTileW / 64, kTileTx = kTileW / 4;
-    __shared__ __attribute__((aligned(16))) uint64_t s_mask[kPass * kTileH * kWords];     // [entry of the pass][row][word]
+    __shared__ __attribute__((aligned(16))) uint64_t s_mask[4 * kPass * kTileH * kWords];     // [interval: fill, three outline segments][entry of the pass][row][word]
     const int tid = threadIdx.x, tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tx0 = tx * kTileW, ty0 = ty * kTileH;
@@ -142,7 +152,12 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
             const int e = i / 5, part = i - e * 5;
             *(float4*)(overflow + (size_t)(off0 + e) * kEntryBytes + part * 16) = rec[(size_t)(tile_tris[off0 + e] + 1) * 5 + part];
         }
-    const int ji = tid / kTileH, jr = tid % kTileH;              // raster job: (entry ji of the pass, tile row jr)
+    // raster jobs: (entry ji of the pass, tile row jr) x the four intervals of a triangle's row — the fill span and the three outline segments.  A wave
+    // takes ONE of the four intervals for 64 jobs at a time (wave 0 the fills, waves 1-3 a segment each), so that the four short instruction streams
+    // run side by side on the four SIMDs instead of one after the other in the one wave the usual 3-8 entries of a tile fill (the kernel's time is the
+    // latency of a tile's chain of dependent steps, not its instruction count: 79 % of a wave's life was spent waiting); every wave writes the masks of
+    // its own interval, the resolve step ORs the four.
+    const int wv = tid >> 6, ln = tid & 63;
     const int row = tid / kTileTx, xg = tid % kTileTx;           // resolve job: pixels (4 xg .. 4 xg + 3, row) of the tile
     const int mdword = row * kWords * 2 + ((xg * 4) >> 5), shift = (xg * 4) & 31;
     const uint32_t* s_mask32 = (const uint32_t*)s_mask;
@@ -150,15 +165,14 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
     for (int base = 0; base < nb; base += kPass) {
         const int n_here = min(kPass, nb - base);
         if (base) __syncthreads();                               // the previous pass's masks have been read
-        if (ji < n_here) {
+        for (int j = ln; j < n_here * kTileH; j += 64) {
+            const int ji = j / kTileH, jr = j - ji * kTileH;
             const int t = tile_tris[off0 + base + ji];
-            const RasterTriDev r = tris[t];
             const int yy = ty0 + jr;
             uint64_t m0 = 0, m1 = 0;
-            add_interval<kTileW>(fill_row(r, yy, W), tx0, m0, m1);
-#pragma unroll
-            for (int e = 0; e < 3; ++e) add_interval<kTileW>(outline_row(outline[t * 3 + e], yy), tx0, m0, m1);
-            uint64_t* dst = s_mask + (ji * kTileH + jr) * kWords;
+            if (wv == 0) add_interval<kTileW>(fill_row(tris[t], yy, W), tx0, m0, m1);
+            else add_interval<kTileW>(outline_row(outline[t * 3 + wv - 1], yy), tx0, m0, m1);
+            uint64_t* dst = s_mask + ((wv * kPass + ji) * kTileH + jr) * kWords;
             dst[0] = m0;
             if (kWords > 1) dst[kWords - 1] = m1;
         }
@@ -166,7 +180,9 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
         // painter's order, a later entry overwrites: an entry's four coverage bits become the byte selector of one v_perm between
         // the old bytes and the entry's number
         for (int i = 0; i < n_here; ++i) {
-            const uint32_t bits = (s_mask32[i * kTileH * kWords * 2 + mdword] >> shift) & 15u;
+            constexpr int kPlane = kPass * kTileH * kWords * 2;                          // dwords of one interval's masks
+            const int at = i * kTileH * kWords * 2 + mdword;
+            const uint32_t bits = ((s_mask32[at] | s_mask32[at + kPlane] | s_mask32[at + 2 * kPlane] | s_mask32[at + 3 * kPlane]) >> shift) & 15u;
             const uint32_t spread = __umul24(bits, 0x204081u) & 0x01010101u;          // bit k of `bits` -> bit 0 of byte k
             ids = __builtin_amdgcn_perm((uint32_t)(base + i + 1) * 0x01010101u, ids, (spread << 2) | 0x03020100u);
         }

@@ -6,6 +6,14 @@
 #include "warp_device.h"
 #include <hip/hip_ext.h>
 
+// POPPY_WARP_ABL (timing builds only — tools/experiments/abl_build.sh; the product is built without it and the results of such a build are wrong by
+// construction): bit 0 = the IEEE division chains become one multiply, bit 1 = constant bilinear weights, bit 2 = no blend arithmetic (the first
+// footprint word passes through), bit 3 = no footprint loads (registers filled from the tap offsets).  What each deletion does to the kernel's time says
+// whether it is bound by instruction issue (profiles/r05_notes.md).
+#ifndef POPPY_WARP_ABL
+#define POPPY_WARP_ABL 0
+#endif
+
 namespace poppy_hip {
 namespace {
 
@@ -48,13 +56,20 @@ __device__ __forceinline__ FastTap make_fast_tap(int sx, int sy, int W, int H) {
     t.inside = (unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1);
     const uint32_t P = __umul24(fx, 65535u) + 32u;                 // (32 - fx) | fx << 16
     const uint32_t M2 = 0x08000800u - __umul24(fy, 0x00400040u);   // 64 (32 - fy) in both halves
+#if POPPY_WARP_ABL & 2
+    t.wt = 0x40004000u; t.wb = 0x40004000u; (void)P; (void)M2;
+#else
     asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(t.wt) : "v"(P), "v"(M2));
     t.wb = __umul24(P, (uint32_t)(fy << 6));                       // 2 w10 | 2 w11 << 16 (no half exceeds 63488)
+#endif
     t.off = t.inside ? (uint32_t)(__umul24(iy, W) + ix) * 3u : 0u;
     return t;
 }
 
 __device__ __forceinline__ uint32_t blend_fast(const FastTap& t, u2v a, u2v b) {
+#if POPPY_WARP_ABL & 4
+    return (a.x ^ b.y) + t.wt;
+#endif
     uint32_t acc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -103,8 +118,12 @@ __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amd
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
             const uint32_t o4 = t[im][k].off & ~3u;
+#if POPPY_WARP_ABL & 8
+            ra[im][k] = u3v{o4, o4 + 1u, o4 + 2u}; rb[im][k] = u3v{o4 ^ pitch, o4 + 5u, o4 + 7u};
+#else
             ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
             rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
+#endif
         }
     }
     uint32_t p[2][4];
@@ -154,6 +173,10 @@ __device__ __forceinline__ void warp_taps(float4 A, float4 B, float4 C, float4 D
     // (the empty asm statements pin the lock-step order: left alone, the scheduler runs one chain after the other)
 #define POPPY_PAIR_HERE(a, b) asm volatile("" : "+v"(a), "+v"(b))
     f2 qa = n1 * ra, qb = n2 * rb;
+#if POPPY_WARP_ABL & 1
+    const f2 q1 = qa, q2 = qb;
+    (void)d1; (void)d2;
+#else
     POPPY_PAIR_HERE(qa, qb);
     f2 sa = __builtin_elementwise_fma(-d1, qa, n1), sb = __builtin_elementwise_fma(-d2, qb, n2);
     POPPY_PAIR_HERE(sa, sb);
@@ -162,6 +185,7 @@ __device__ __forceinline__ void warp_taps(float4 A, float4 B, float4 C, float4 D
     sa = __builtin_elementwise_fma(-d1, qa, n1); sb = __builtin_elementwise_fma(-d2, qb, n2);
     POPPY_PAIR_HERE(sa, sb);
     const f2 q1 = __builtin_elementwise_fma(sa, ra, qa), q2 = __builtin_elementwise_fma(sb, rb, qb);
+#endif
 #undef POPPY_PAIR_HERE
     int sx, sy;
     to_fixed(q1, sx, sy);
