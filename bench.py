@@ -755,6 +755,15 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     ts = sharding.phase_share(rank, world, total)
     link = sharding.PairLink(torch, dist, capi, ctx, rank, world, W, H, cdev, use_library=not rehearsal)
     t_setup = [0.0]; t_bcast = [0.0]; t_frames = [0.0]
+    comm_info = ctx.comm_info() if link.library else None
+    if comm_info is not None and comm_info[3] >= 0:          # the communicator the library exchanges the pair through IS this job: ncclCommCount == N on every rank
+        assert comm_info[3] == world and comm_info[1] == world, ("ncclCommCount != --gpus", comm_info, world)
+    # every rank's share of the job's frames (the partition is a pure function of (rank, world, total): checked here across the ranks)
+    shares = torch.zeros(world, dtype=torch.int32, device=cdev)
+    shares[rank] = len(ts)
+    dist.all_reduce(shares)
+    frame_shares = [int(x) for x in shares.cpu().tolist()]
+    assert sum(frame_shares) == total, (frame_shares, total)
 
     shard_setup = link.library and args.shard_setup and not args.no_shard_setup
 
@@ -875,6 +884,12 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
                        "rank0_frames_ms": round(t_frames[0] / k * 1e3, 3),
                        "note": "host-side wall time on rank 0 per step; the set-up and the broadcast are the serial part of the job: N GPUs cannot beat "
                                "(set-up + frames) / (set-up + broadcast + frames / N) over the --gpus 1 line's scaling_baseline_480"},
+            "frame_shares": frame_shares,
+            "communicator": ({"rank_world_given": list(comm_info[:2]), "nccl_rank_count": list(comm_info[2:]), "count_equals_gpus": comm_info[3] == world} if comm_info is not None
+                             else {"note": "torch.distributed transport (no library communicator in this run)"}),
+            # what THIS run's own rank-0 terms predict for the job against one GPU doing everything: (set-up + N x this rank's frames) / (set-up + broadcast + this rank's frames);
+            # read beside value / scaling_baseline_480.fps of the --gpus 1 line (the measured speed-up) and that line's predicted_speedup
+            "predicted_speedup_from_this_runs_terms": round((t_setup[0] + world * t_frames[0]) / max(t_setup[0] + t_bcast[0] + t_frames[0], 1e-9), 2),
             "cfg4_note": "value = configs[3] (one %d-frame morph sharded by frame range); speed-up = value / scaling_baseline_480.fps of the --gpus 1 line" % total,
             "cfg5_pairs": {"workload": f"BASELINE.json configs[4]: {ppg * world} independent {W}x{H} pairs x {FRAMES} chained frames, {ppg} pairs per GPU on "
                                        f"{args.contexts} contexts each, set-up from the raw images and the writer hand-off included, no communication",

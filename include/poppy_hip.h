@@ -299,6 +299,9 @@ int poppy_hip_render_many(poppy_hip_ctx* ctx, const double* shape_ratio, const d
 int poppy_hip_comm_id(uint8_t* id128);
 int poppy_hip_comm_init(poppy_hip_ctx* ctx, int rank, int world, const uint8_t* id128);
 int poppy_hip_comm_free(poppy_hip_ctx* ctx);
+/* rank / world as handed to poppy_hip_comm_init, and what the RCCL communicator itself reports (ncclCommUserRank / ncclCommCount; -1 without one):
+ * a launcher's check that the job it started is the job the library communicates in (bench.py --gpus N asserts count == N).  Any pointer may be NULL. */
+int poppy_hip_comm_info(poppy_hip_ctx* ctx, int* rank, int* world, int* nccl_rank, int* nccl_count);
 int poppy_hip_pair_broadcast(poppy_hip_ctx* ctx, int root, int width, int height);
 /* The pair set-up ITSELF spread over the communicator's ranks — a collective that replaces poppy_hip_pair_begin_device + poppy_hip_pair_broadcast
  * (the serial part of a sharded morph): rank `root` holds the raw pair (device pointers; the other ranks pass NULL) and filters / detects image 1,

@@ -31,7 +31,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_comm_info", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_sharded_setups", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -90,6 +90,7 @@ def lib():
         L.poppy_hip_orb_detect.argtypes = [vp, vp, sz, i, i, i, vp, i, vp]
         L.poppy_hip_foreground.argtypes = [vp, vp, sz, i, i, vp, vp]
         L.poppy_hip_median_blur.argtypes = [vp, vp, i, i, i, i, vp]
+        L.poppy_hip_comm_info.argtypes = [vp, vp, vp, vp, vp]
         L.poppy_hip_pair_begin.argtypes = [vp, vp, sz, vp, sz, i, i]
         L.poppy_hip_pair_begin_info.argtypes = [vp, vp, vp]
         L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
@@ -574,6 +575,12 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(id128)
         self._chk(lib().poppy_hip_comm_init(self.h, rank, world, buf), "comm_init")
 
+    def comm_info(self):
+        """(rank, world) as given to comm_init and (rank, count) as the RCCL communicator reports them (-1 without one)."""
+        v = [C.c_int(-1) for _ in range(4)]
+        self._chk(lib().poppy_hip_comm_info(self.h, *[C.byref(x) for x in v]), "comm_info")
+        return tuple(x.value for x in v)
+
     def comm_free(self):
         lib().poppy_hip_comm_free(self.h)
 
@@ -734,18 +741,27 @@ class Context:
         self._chk(lib().poppy_hip_pair_points(self.h, _p(p1), _p(p2), max_points, C.byref(n)), "pair_points")
         return p1[:n.value].copy(), p2[:n.value].copy()
 
-    def morph(self, bgr1, bgr2, phase=-1.0, distance=False, collect=True):
+    def morph(self, bgr1, bgr2, phase=-1.0, distance=False, collect=True, row_pad=(0, 0)):
         """poppy::morph end to end: returns (status, frames, printed morph distance or None).  status is POPPY_OK (0) or
-        POPPY_E_NOMATCH (-5, fallback frames written); anything else raises."""
+        POPPY_E_NOMATCH (-5, fallback frames written); anything else raises.  row_pad = (bytes, bytes): the two images are handed over with that many
+        extra bytes per row (cv::Mat ROIs, src/poppy.cpp:234-239: step > cols * 3), the padding filled with a pattern no pixel may come from."""
         a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
         h, w = a.shape[:2]
+        strides = [w * 3 + int(row_pad[0]), w * 3 + int(row_pad[1])]
+        if row_pad != (0, 0):
+            padded = []
+            for img, st in zip((a, b), strides):
+                buf = np.full((h, st), 0xA5, np.uint8)
+                buf[:, :w * 3] = img.reshape(h, w * 3)
+                padded.append(buf)
+            a, b = padded
         frames = []
 
         def cb(user, ptr, ww, hh, stride):
             frames.append(np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy())
         fn = WRITE_CB(cb) if collect else None
         d = C.c_double(float("nan"))
-        rc = lib().poppy_hip_morph(self.h, _p(a), w * 3, _p(b), w * 3, w, h, phase, int(distance),
+        rc = lib().poppy_hip_morph(self.h, _p(a), strides[0], _p(b), strides[1], w, h, phase, int(distance),
                                    C.cast(fn, C.c_void_p) if fn else None, None, C.byref(d))
         if rc not in (0, -5):
             self._chk(rc, "morph")

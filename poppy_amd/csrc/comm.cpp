@@ -31,6 +31,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;      // optional: what the communicator itself says its size is (poppy_hip_comm_info)
+    int (*CommUserRank)(void*, int*) = nullptr;
     int (*CommAbort)(void*) = nullptr;            // optional: unblocks the other device threads of poppy_hip_morph_sharded when one of them failed
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -56,6 +58,8 @@ Rccl* rccl() {
         r.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
         r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
         r.CommAbort = (int (*)(void*))dlsym(r.handle, "ncclCommAbort");
+        r.CommCount = (int (*)(void*, int*))dlsym(r.handle, "ncclCommCount");
+        r.CommUserRank = (int (*)(void*, int*))dlsym(r.handle, "ncclCommUserRank");
         r.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
@@ -99,6 +103,22 @@ int poppy_hip_comm_init(poppy_hip_ctx* c, int rank, int world, const uint8_t* id
         (void)r->CommDestroy(comm); c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
         return fail(c, POPPY_E_DEVICE, "allocation of the reduction scratch");
     }
+    return POPPY_OK;
+}
+
+// what the context believes (rank, world) and what its RCCL communicator reports (ncclCommUserRank, ncclCommCount; -1: no communicator / symbol missing)
+int poppy_hip_comm_info(poppy_hip_ctx* c, int* rank, int* world, int* nccl_rank, int* nccl_count) {
+    if (!c) return POPPY_E_ARG;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm_world;
+    int nr = -1, nc = -1;
+    Rccl* r = rccl();
+    if (c->comm && r->handle) {
+        if (r->CommUserRank && r->CommUserRank(c->comm, &nr) != 0) nr = -1;
+        if (r->CommCount && r->CommCount(c->comm, &nc) != 0) nc = -1;
+    }
+    if (nccl_rank) *nccl_rank = nr;
+    if (nccl_count) *nccl_count = nc;
     return POPPY_OK;
 }
 

@@ -420,3 +420,22 @@ def test_bench_sharded_path_on_a_world_of_one():
     assert f["same_point_lists_on_every_rank"] is True and f["used"] in ("sharded", "rank 0 + broadcast")
     assert f["sharded_protocol_runs_on_rank0"] >= 4          # 1 + 3 timed runs of the protocol itself
     assert d["cfg5_pairs"]["value"] > 0
+
+
+@pytest.mark.parametrize("case,pads", [("a_256x256_phase", (13, 13)), ("a_256x256_chain", (13, 40)), ("a_639x480_numbers", (13, 1))])
+def test_main_entry_takes_images_with_padded_rows(case, pads):
+    """poppy_hip_morph on images whose row stride is not 3 * width — the reference hands poppy::morph ROI cv::Mats of the union canvas (src/poppy.cpp:234-239:
+    step > cols * 3) — with a different padding per image, the padding bytes filled with a pattern: points, distance and every frame against the reference's
+    fixture of the same pair handed over tight (an odd-width pair among them: the upload then takes the 2-D copy)."""
+    inp = G.astage_inputs(case)
+    n = int(inp["cfg"][0]); phase = float(inp["cfg"][1])
+    c = _ctx(number_of_frames=n)
+    rc, frames, dist = c.morph(inp["img1"], inp["img2"], phase=phase, row_pad=pads)
+    assert rc == 0 and len(frames) == (n if phase < 0 else 1)
+    if "printedMorphDist" in G.entries(case):
+        assert dist == float(G.full(case, "printedMorphDist")[0])
+    p1, p2 = c.pair_points()
+    G.check(case, "prepared1", p1); G.check(case, "prepared2", p2)
+    for j, f in enumerate(frames):
+        assert G.sha(f) == G.entries(case)[f"frame{j}"]["sha256"], f"frame {j}"
+    c.close()
