@@ -187,7 +187,7 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
 }
 
 int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int form, hipStream_t s, uint8_t* dst) {
-    if (!src || !dst || w <= 0 || h <= 0 || ksize < 3 || ksize > 89 || !(ksize & 1) || form < 0 || form > 4) { err = "bad arguments"; return -1; }
+    if (!src || !dst || w <= 0 || h <= 0 || ksize < 3 || ksize > 89 || !(ksize & 1) || form < 0 || form > 5) { err = "bad arguments"; return -1; }
     if (ensure(w, h)) return -2;
     const size_t P = (size_t)w * h;
     FG_CHK(hipMemcpyAsync(grey, src, P, hipMemcpyHostToDevice, s));
@@ -196,7 +196,7 @@ int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int fo
     if (form == 1) launch_median_padded(padded, meds, nullptr, w, h, ksize, s);
     else {
         if (form != 3) launch_median_presence(grey, med_pres, w, h, nullptr, s);
-        launch_median_cols(padded, meds, nullptr, w, h, ksize, form != 3 ? med_pres : nullptr, med_pres + median_presence_words(w, h), form == 3 ? 1 : form == 4 ? 2 : 0, s);
+        launch_median_cols(padded, meds, nullptr, w, h, ksize, form != 3 ? med_pres : nullptr, med_pres + median_presence_words(w, h), form == 3 || form == 5 ? 1 : form == 4 ? 2 : 0, s);
     }
     FG_CHK(hipGetLastError());
     FG_CHK(hipMemcpyAsync(dst, meds, P, hipMemcpyDeviceToHost, s));

@@ -39,7 +39,7 @@ def _mixed(w, h, seed):
     return img
 
 
-FORMS = (1, 2, 3, 4)
+FORMS = (1, 2, 3, 4, 5)
 
 
 @pytest.mark.parametrize("ksize", [3, 9, 17, 25, 33, 41, 49, 57, 65, 73, 81, 89])
@@ -67,12 +67,12 @@ def test_exactly_64_and_65_values_per_tile(ctx):
     """the rank form takes a tile whose footprint holds at most 64 different values: both sides of that limit, and one value only"""
     import oracle_lib as O
     rng = np.random.default_rng(64)
-    for values in (1, 2, 63, 64, 65, 66, 127, 128, 129, 200):
+    for values in (1, 2, 63, 64, 65, 66, 127, 128, 129, 130, 200, 255, 256):
         vals = np.sort(rng.choice(256, values, replace=False)).astype(np.uint8)
         img = vals[rng.integers(0, values, (150, 300))]
         for ksize in (9, 41, 89):
             want = O.median_blur_u8(img, ksize)
-            for form in (2, 3, 4):
+            for form in (2, 3, 4, 5):
                 assert np.array_equal(ctx.median_blur(img, ksize, form), want), f"{values} values, ksize {ksize}, form {form}"
 
 
