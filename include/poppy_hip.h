@@ -203,9 +203,10 @@ int poppy_hip_foreground(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride, 
 /* One link of that chain on its own: cv::medianBlur(src, dst, ksize) on a tight 8-bit single-channel host image, odd 3 <= ksize <= 89
  * (src/extractor.cpp:149; OCV/imgproc/src/median_blur.simd.hpp:84-346).  form selects the kernel (diagnostics, tests): 0 = what the chain
  * takes for this ksize, 1 = a lane per image column (k_median_u8), 2 = column histograms over the ranks of the values each tile's
- * footprint holds (k_median_cols: one count per lane up to 64 values, two up to 128, two passes beyond), 3 = k_median_cols without the
- * presence maps (every tile in two passes over all 256 values), 4 = as 2 without the one-count form, 5 = as 2 with every tile in two
- * passes.  All forms return the same bytes.                                                                                          */
+ * footprint holds (k_median_cols: one count per lane up to 64 values, two up to 129, windows of 128 ranks beyond), 3 = k_median_cols
+ * without the presence maps (every tile by windows over all 256 values), 4 = as 2 without the one-count form, 5 = as 2 with every tile
+ * by windows, 6 / 7 = as 5 with the first window at the top / bottom of the ranks (the windows beside it do the work).  All forms return
+ * the same bytes.                                                                                                                     */
 int poppy_hip_median_blur(poppy_hip_ctx* ctx, const uint8_t* src, int width, int height, int ksize, int form, uint8_t* dst);
 
 /* Pair set-up from the two ORB input images g1/g2 (what Extractor::keypoints feeds the detector,

@@ -528,7 +528,7 @@ class Context:
 
     def median_blur(self, img, ksize, form=0):
         """cv::medianBlur on a single-channel u8 image; form: 0 chain default, 1 lane per column, 2 column histograms over the ranks of each tile's values,
-        3 the same without presence maps (two passes over 256 values), 4 no one-count tiles, 5 every tile in two passes (include/poppy_hip.h)."""
+        3 the same without presence maps, 4 no one-count tiles, 5 every tile by windows of ranks, 6 / 7 first window at the top / bottom (include/poppy_hip.h)."""
         a = np.ascontiguousarray(img, np.uint8)
         h, w = a.shape
         out = np.zeros((h, w), np.uint8)

@@ -92,6 +92,8 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     int use_cols = forced_cols >= 0 ? forced_cols : median_cols_hint;
     median_cols_hint = -1;
     if (median_cols_min_ksize() > 89) use_cols = 0;
+    // images with many values per tile (photographs): the lane-per-column kernel's time grows with the window, the column histograms' does not — they take over later
+    const int cols_from_hard = forced_cols == 0 || median_cols_min_ksize() > 89 ? 999 : median_cols_min_ksize_hard();
     bool ask_device = false;
     if (use_cols < 0) {
         // the device counts the grey image's easy tiles now; the answer is read when the first large window comes up — behind the small windows' launches,
@@ -117,7 +119,7 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
             ask_device = false;
         }
         if (ksize <= 1) {}
-        else if (use_cols > 0 && ksize >= median_cols_min_ksize()) {   // by column histograms: every launch also leaves the presence map of its result's tiles
+        else if (ksize >= (use_cols > 0 ? median_cols_min_ksize() : cols_from_hard)) {   // by column histograms: every launch also leaves the presence map of its result's tiles
             if (!pres_valid) { launch_median_presence(inputs[i], pres[pp], w, h, nullptr, s); pres_valid = true; }
             launch_median_cols(pad[pc], med, i < 11 ? pad[pc ^ 1] : nullptr, w, h, ksize, pres[pp], pres[pp ^ 1], 0, s);
             pc ^= 1; pp ^= 1;
@@ -187,7 +189,7 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
 }
 
 int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int form, hipStream_t s, uint8_t* dst) {
-    if (!src || !dst || w <= 0 || h <= 0 || ksize < 3 || ksize > 89 || !(ksize & 1) || form < 0 || form > 5) { err = "bad arguments"; return -1; }
+    if (!src || !dst || w <= 0 || h <= 0 || ksize < 3 || ksize > 89 || !(ksize & 1) || form < 0 || form > 7) { err = "bad arguments"; return -1; }
     if (ensure(w, h)) return -2;
     const size_t P = (size_t)w * h;
     FG_CHK(hipMemcpyAsync(grey, src, P, hipMemcpyHostToDevice, s));
@@ -196,7 +198,7 @@ int ForegroundFilter::median(const uint8_t* src, int w, int h, int ksize, int fo
     if (form == 1) launch_median_padded(padded, meds, nullptr, w, h, ksize, s);
     else {
         if (form != 3) launch_median_presence(grey, med_pres, w, h, nullptr, s);
-        launch_median_cols(padded, meds, nullptr, w, h, ksize, form != 3 ? med_pres : nullptr, med_pres + median_presence_words(w, h), form == 3 || form == 5 ? 1 : form == 4 ? 2 : 0, s);
+        launch_median_cols(padded, meds, nullptr, w, h, ksize, form != 3 ? med_pres : nullptr, med_pres + median_presence_words(w, h), form == 3 || form == 5 ? 1 : form == 4 ? 2 : form == 6 ? 5 : form == 7 ? 9 : 0, s);
     }
     FG_CHK(hipGetLastError());
     FG_CHK(hipMemcpyAsync(dst, meds, P, hipMemcpyDeviceToHost, s));

@@ -20,10 +20,13 @@
 //   * A chain restarts every row at its first pixel from the counts it had there one row up: the change of that window — 2r+1 values in,
 //     2r+1 out — is collected by the chain's own lanes as plain counts in a small LDS table (two atomics per column that changed, runs of
 //     equal columns combined) and its running sum over the lanes is the cumulative change.
-//   * More than 128 different values in a tile's footprint (noise, the first stages of photographs): the tile is filtered TWICE with 128
-//     counts — ranks clamped at 128 (exact wherever the median's rank is below 128), then ranks 128 .. shifted down (exact wherever it is
-//     not) — instead of a third form with four counts per lane: the tables stay at 132 bytes per column, a workgroup at 34 KB of LDS and
-//     64 registers, and four workgroups share a compute unit (8 waves per SIMD; the launches of a pair's two images overlap).
+//   * More than 129 different values in a tile's footprint (noise, photographs): the 128 counts cover a WINDOW of ranks, base .. base + 127 —
+//     values ranked below the window count at its first rank, values above it have no count — and the pass's answer is the median's rank
+//     clamped into the window: exact strictly inside it.  The window is laid around the median of a sample of the tile's own pixels (a
+//     median filter's output varies little over 128 x 24 pixels); pixels that come out at the window's edge are noted in two bitmaps and
+//     filtered again with the window below / above — a second or third pass of the same code that most tiles never need.  So the tables
+//     stay at 132 bytes per column, a workgroup at 35 KB of LDS and 64 registers, and four workgroups share a compute unit (8 waves per
+//     SIMD: the launches of a pair's two images overlap).
 #include "kernels_prefilter.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -48,18 +51,20 @@ constexpr int kOffDelta = kOffTab + kMcCols * kTabStride;            // per chai
 constexpr int kOffRowIn = kOffDelta + kMcWaves * kTabStride;         // the row step's entering / leaving rank of every column
 constexpr int kOffRowOut = kOffRowIn + (kMcCols + 3) / 4;
 constexpr int kOffRank = kOffRowOut + (kMcCols + 3) / 4;             // value -> rank (256 bytes), rank -> value (128 bytes) of the current pass
-constexpr int kOffInv = kOffRank + 64;
-constexpr int kOffPres = kOffInv + 32;                               // the footprint's presence bits, the output tile's
+constexpr int kOffInv = kOffRank + 64;                               // (129 entries: the answer 128 = the last rank, when the window reaches it)
+constexpr int kOffPres = kOffInv + 33;                               // the footprint's presence bits, the output tile's
 constexpr int kOffPresOut = kOffPres + 8;
 constexpr int kOffOutRow = kOffPresOut + 8;                          // the tile's current output row (ranks), translated and stored by the waves that step no columns
-constexpr int kOffLater = kOffOutRow + kMcWaves * kMcRun / 4;        // two passes: per row 128 bits — the pixels whose rank the first pass could not give
-constexpr int kMcMaxRows = 256;
-constexpr int kMcLdsWords = kOffLater + kMcMaxRows * 4;
+constexpr int kOffMisc = kOffOutRow + kMcWaves * kMcRun / 4;         // [0] bit 0 / 1: some pixel's median lies below / above the first window; [1] the first window's base
+constexpr int kMcMaxRows = 128;
+constexpr int kOffBelow = kOffMisc + 4;                              // per row 128 bits: the pixels whose median lies below the first window; above it
+constexpr int kOffAbove = kOffBelow + kMcMaxRows * 4;
+constexpr int kMcLdsWords = kOffAbove + kMcMaxRows * 4;
 static_assert(kMcCols <= 256, "the column threads are waves 0..3; waves 4..7 store the rows");
 static_assert(kMcLdsWords * 4 <= 39 * 1024, "four workgroups per compute unit");
 
 enum { kRank64 = 1, kRank128 = 2 };                                  // counts per lane x 64
-enum { kPassOnly = 0, kPassLow = 1, kPassHigh = 2 };                 // the one pass of a tile of <= 128 values; the two passes of a tile with more
+enum { kPassOnly = 0, kPassFirst = 1, kPassBelow = 2, kPassAbove = 3 };   // the one pass of a tile of <= 128 values; a tile with more: the first window, the ones beside it
 
 constexpr uint32_t kBias4 = 0x80808080u;
 
@@ -101,10 +106,11 @@ __device__ __forceinline__ void table_step(uint32_t* __restrict__ tab, int ia, i
     }
 }
 
-// One pass over the tile.  kForm: counts per lane; pass: which pixels it writes (kPassLow also notes the others in the `later` bits).
+// One pass over the tile.  kForm: counts per lane; pass: which pixels it writes (kPassFirst notes the others in the bitmaps); lo_exact / hi_exact:
+// the answers 0 / 128 are the median's rank too (the window begins at rank 0 / reaches the last rank).
 template <int kForm>
 __device__ __forceinline__ void median_cols_pass(uint32_t* __restrict__ lds, const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst,
-                                                 uint8_t* __restrict__ padded_out, int W, int H, int ksize, int rows, int pass, int& prev_m, int dbg) {
+                                                 uint8_t* __restrict__ padded_out, int W, int H, int ksize, int rows, int pass, bool lo_exact, bool hi_exact, int& prev_m, int dbg) {
     uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
     const uint16_t* const lds16 = reinterpret_cast<const uint16_t*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -204,10 +210,14 @@ __device__ __forceinline__ void median_cols_pass(uint32_t* __restrict__ lds, con
         __syncthreads();                                              // every chain has read the columns of row y; the output row is complete
         if (tid >= 256 && tid - 256 < Cw) {
             const int k = tid - 256, x = X0 + k, rk = lds8[kOffOutRow * 4 + k];
-            uint32_t* const later = lds + kOffLater + (y - Y0) * 4 + (k >> 5);
+            const int word = (y - Y0) * 4 + (k >> 5);
+            const uint32_t bit = 1u << (k & 31);
             bool mine = x < W;
-            if (pass == kPassLow && rk >= 128) { if (mine) atomicOr(later, 1u << (k & 31)); mine = false; }      // all 128 counts <= half: the second pass knows
-            if (pass == kPassHigh) mine = mine && ((*later >> (k & 31)) & 1u);
+            if (pass == kPassFirst) {                                 // an answer at the window's edge is only a bound: the pixel waits for the window beside it
+                if (rk == 0 && !lo_exact) { if (mine) { atomicOr(&lds[kOffBelow + word], bit); atomicOr(&lds[kOffMisc], 1u); } mine = false; }
+                else if (rk >= 128 && !hi_exact) { if (mine) { atomicOr(&lds[kOffAbove + word], bit); atomicOr(&lds[kOffMisc], 2u); } mine = false; }
+            } else if (pass == kPassBelow) mine = mine && (lds[kOffBelow + word] & bit);
+            else if (pass == kPassAbove) mine = mine && (lds[kOffAbove + word] & bit);
             if (mine) {
                 const int m = inv8[rk];
                 dst[(size_t)y * W + x] = (uint8_t)m;
@@ -262,7 +272,8 @@ __device__ __forceinline__ void median_cols_pass(uint32_t* __restrict__ lds, con
     }
 }
 
-// force: 0 = by the footprint's values, 1 = every tile in two passes (as if it held more than 128 values), 2 = no tile with one rank per lane
+// force: bits 0-1: 0 = by the footprint's values, 1 = every tile by windows (as if it held more than 129 values), 2 = no tile with one count per lane;
+// tests of the windows beside the first: bit 2 = the first window at the top of the ranks, bit 3 = at their bottom (instead of around the sample's median)
 __global__ void __launch_bounds__(kMcWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_median_cols(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, uint8_t* __restrict__ padded_out, int W, int H, int ksize, int rows,
               const uint32_t* __restrict__ pres_in, uint32_t* __restrict__ pres_out, int force, int dbg) {
@@ -289,7 +300,7 @@ k_median_cols(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, uint8
     int distinct = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) distinct += __popc(lds[kOffPres + k]);
-    const bool two_passes = force == 1 || distinct > 128;
+    const bool windows = (force & 3) == 1 || distinct > 129;
     int rk = 0;                                                       // this thread's value: its rank among the values present
     bool present = false;
     if (tid < 256) {
@@ -298,33 +309,61 @@ k_median_cols(const uint8_t* __restrict__ srcp, uint8_t* __restrict__ dst, uint8
         rk += __popc(mine & ((1u << (tid & 31)) - 1u));
         present = (mine >> (tid & 31)) & 1u;
     }
+    // value -> rank within the window that begins at rank `base` (0 .. 128), and back (a rank has one value)
+    auto window_tables = [&](int base) {
+        if (tid < 256) {
+            lds8[kOffRank * 4 + tid] = (uint8_t)min(max(rk - base, 0), 128);
+            if (present && rk >= base && rk <= base + 128) lds8[kOffInv * 4 + rk - base] = (uint8_t)tid;
+        }
+    };
     int prev_m = -1;                                                  // (storing threads) the value stored last: its presence bit is set
-    if (!two_passes) {
-        if (tid < 256) {
-            lds8[kOffRank * 4 + tid] = (uint8_t)min(rk, 127);
-            if (present) lds8[kOffInv * 4 + rk] = (uint8_t)tid;
-        }
+    if (!windows) {
+        window_tables(0);
         __syncthreads();
-        if (distinct <= 64 && force != 2) median_cols_pass<kRank64>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassOnly, prev_m, dbg);
-        else median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassOnly, prev_m, dbg);
+        if (distinct <= 64 && (force & 3) != 2) median_cols_pass<kRank64>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassOnly, true, true, prev_m, dbg);
+        else median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassOnly, true, true, prev_m, dbg);
     } else {
-        // With cumulative counts C[0 .. D-1] the median's rank is m = #{j : C[j] <= half}.  First pass: ranks clamped at 128, the 128 counts are C[0 .. 127]
-        // exactly (rank 128 has no count), so the pass's answer is min(m, 128): right where it is below 128; the other pixels are noted in `later`.
-        // Second pass: ranks 128 .. D-1 shifted down to 0 .., everything below counted at rank 0: the counts are C[128 .. 255], the answer max(m - 128, 0).
-        for (int k = tid; k < kMcMaxRows * 4; k += kMcWaves * 64) lds[kOffLater + k] = 0;
-        if (tid < 256) {
-            lds8[kOffRank * 4 + tid] = (uint8_t)min(rk, 128);
-            if (present && rk < 128) lds8[kOffInv * 4 + rk] = (uint8_t)tid;
+        // With cumulative counts C[0 .. D-1] the median's rank is m = #{j : C[j] <= half}.  A window at `base` holds the counts C[base .. base + 127]
+        // (lower ranks count at `base`, higher ranks nowhere), so its answer is clamp(m - base, 0, 128): m itself for answers 1 .. 127, for 0 if
+        // base = 0, for 128 if base + 128 is the last rank.  First window: around the median rank of 512 of the tile's own pixels.
+        const int top = max(distinct - 129, 0);                       // the highest base: its window reaches the last rank
+        uint16_t* const sample = reinterpret_cast<uint16_t*>(lds + kOffBelow);       // 256 counts by rank (the bitmaps' place, cleared below)
+        if (tid < 256) lds8[kOffRank * 4 + tid] = (uint8_t)rk;
+        if (tid < 128) lds[kOffBelow + tid] = 0;
+        __syncthreads();
+        {
+            const int sx = min(X0 + (tid & 127), W - 1), sy = min(Y0 + ((tid >> 7) * rows >> 2) + (rows >> 3), H - 1);
+            const int sr = lds8[kOffRank * 4 + srcp[(size_t)sy * (W + 2 * kMedPad) + kMedPad + sx]];
+            atomicAdd(&lds[kOffBelow + (sr >> 1)], 1u << (16 * (sr & 1)));
         }
         __syncthreads();
-        median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassLow, prev_m, dbg);
-        __syncthreads();
-        if (tid < 256) {
-            lds8[kOffRank * 4 + tid] = (uint8_t)max(rk - 128, 0);
-            if (present && rk >= 128) lds8[kOffInv * 4 + rk - 128] = (uint8_t)tid;
+        if (tid < 64) {
+            const int four = sample[4 * tid] + sample[4 * tid + 1] + sample[4 * tid + 2] + sample[4 * tid + 3];
+            const int upto = wave_prefix_sum(four);
+            const int ms = 4 * __popcll(__ballot(upto <= kMcWaves * 32)) + 2;        // about the sample's median rank
+            const int guess = (force & 4) ? 255 : (force & 8) ? 0 : ms - 64;
+            if (tid == 0) { lds[kOffMisc] = 0; lds[kOffMisc + 1] = min(max(guess, 0), top); }
         }
         __syncthreads();
-        median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassHigh, prev_m, dbg);
+        const int base = lds[kOffMisc + 1];
+        for (int k = tid; k < 2 * kMcMaxRows * 4; k += kMcWaves * 64) lds[kOffBelow + k] = 0;
+        window_tables(base);
+        __syncthreads();
+        median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassFirst, base == 0, base == top, prev_m, dbg);
+        __syncthreads();
+        const uint32_t again = lds[kOffMisc];
+        if (again & 1u) {                                             // medians of rank <= base: the window at 0 holds them all (base <= 127)
+            __syncthreads();
+            window_tables(0);
+            __syncthreads();
+            median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassBelow, true, true, prev_m, dbg);
+        }
+        if (again & 2u) {                                             // medians of rank >= base + 128 > top: the top window holds them all (top <= 127)
+            __syncthreads();
+            window_tables(top);
+            __syncthreads();
+            median_cols_pass<kRank128>(lds, srcp, dst, padded_out, W, H, ksize, rows, kPassAbove, true, true, prev_m, dbg);
+        }
     }
     if (pres_out) {
         __syncthreads();

@@ -39,8 +39,9 @@ size_t median_presence_words(int w, int h);
 void launch_median_presence(const uint8_t* src_tight, uint32_t* pres, int w, int h, uint32_t* easy_or_null, hipStream_t s);
 int median_cols_hint_from_host(const uint8_t* bgr, size_t stride, int w, int h);      // the same decision from a sparse sample of a host image (1 / 0)
 void launch_median_cols(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, const uint32_t* pres_in, uint32_t* pres_out,
-                        int force, hipStream_t s);             // force: 0 = by content, 1 = every tile in two passes, 2 = no tile with one count per lane
-int median_cols_min_ksize();            // windows from this size on take the column-histogram form (POPPY_MED_COLS_MIN overrides)
+                        int force, hipStream_t s);             // force: 0 = by content, 1 = every tile by windows of ranks, 2 = no tile with one count per lane; + 4 / 8: see k_median_cols
+int median_cols_min_ksize();            // windows from this size on take the column-histogram form (POPPY_MED_COLS_MIN overrides) on images of few values per tile
+int median_cols_min_ksize_hard();       // ... on every other image (POPPY_MED_COLS_MIN_HARD overrides)
 
 // GaussianBlur(src, dst, 23x23, sigma 1) on 8 bit (the fixed-point path); tmp = w*h uint16
 void launch_gauss23_u8(const uint8_t* src, uint16_t* tmp, uint8_t* dst, int w, int h, hipStream_t s);

@@ -437,6 +437,12 @@ int median_cols_min_ksize() {
     static const int v = getenv("POPPY_MED_COLS_MIN") ? atoi(getenv("POPPY_MED_COLS_MIN")) : 25;      // (below: k_median_u8 is as fast or faster on every content)
     return v;
 }
+int median_cols_min_ksize_hard() {
+    // never by default: on photographs a launch takes as long as its slowest tile (one whose medians need a second or third window of ranks), 200 - 250 us at
+    // 1080p beside 115 - 190 for the lane-per-column kernel; set-up with 57: photographs 4.43 against 4.27 ms, noise 4.9 - 5.0 against 5.3 (profiles/r05_notes.md)
+    static const int v = getenv("POPPY_MED_COLS_MIN_HARD") ? atoi(getenv("POPPY_MED_COLS_MIN_HARD")) : 999;
+    return v;
+}
 bool prepare_median_u8() { return true; }
 
 // ---- GaussianBlur 23x23, sigma 1, 8 bit: taps 1 14 62 102 62 14 1 (the other 16 taps are 0 in 8.8 fixed point) ------------

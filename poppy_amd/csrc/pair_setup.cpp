@@ -190,12 +190,18 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     c->pair_ready = false;
     c->c2_raw_valid = false;
     const size_t P = (size_t)W * H;
+    static const bool gabor2_first = getenv("POPPY_GABOR2_FIRST") != nullptr;
+    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
+    // Host images: the second image is uploaded by its own chain's thread on that chain's stream, so the first image's chain — stream-ordered behind its
+    // own upload — has the GPU to itself for the length of a copy instead of both waiting for both (POPPY_SETUP_UPLOAD_BOTH=1: the order before round 5)
+    static const bool upload_both = getenv("POPPY_SETUP_UPLOAD_BOTH") != nullptr;
+    const bool staged = !on_device && !upload_both && !gabor2_first && !serial_chains;
     if (on_device) {
         HIPCHK(c, hipMemcpyAsync(c->c1, bgr1, P * 3, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->c2, bgr2, P * 3, hipMemcpyDeviceToDevice, c->stream));
     } else {
         rc = upload_image(c, c->c1, bgr1, s1, W, H); if (rc) return rc;
-        rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc;
+        if (!staged) { rc = upload_image(c, c->c2, bgr2, s2, W, H); if (rc) return rc; }
     }
     // POPPY_SETUP_TIMING: host wall time of the set-up's stages on stderr (chains = foreground + detail + ORB input (+ gabor2) of both
     // images side by side; detect = the two ORB detections; match = the host matcher; finish = m2 + the pair state)
@@ -208,7 +214,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     const uint8_t* g_dev[2] = {nullptr, nullptr};
     double d[2] = {0, 0};
     if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                         // the uploads above
+    if (!staged) HIPCHK(c, hipStreamSynchronize(c->stream));            // the uploads above
     ms_upload = since(t_begin);
     // The two images go through the chain independently (Extractor::foreground -> dft_detail2 -> the ORB input of
     // Extractor::keypoints; image 2 also through gabor_filter(corrected2 / 255), src/poppy.hpp:119-122): one host thread and
@@ -220,7 +226,6 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes to the plan-upload stream — idle during a
     // set-up — and starts when the second image's medians are through, beside the strings of small dependent launches that follow them (at
     // the very start it ran beside the first medians, one wave per histogram set, and tripled their time; POPPY_GABOR2_FIRST: that order)
-    static const bool gabor2_first = getenv("POPPY_GABOR2_FIRST") != nullptr;
     auto gabor2_on_side_stream = [&]() -> bool {
         const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream);
         if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return false; }
@@ -245,7 +250,6 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         void now() { if (!done) { done = true; d.add(); } }
         ~Publish() { now(); }
     };
-    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
     if (!on_device) {                                                    // which median kernel each image's chain takes: from a sample of the host pixels
         c->foreground.median_cols_hint = median_cols_hint_from_host(bgr1, s1, W, H);
         c->foreground_b.median_cols_hint = median_cols_hint_from_host(bgr2, s2, W, H);
@@ -255,6 +259,9 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
         ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
         hipStream_t st = i ? c->aux_stream : c->stream;
+        if (i == 1 && staged && copy_rows_async(c->c2, (size_t)W * 3, bgr2, s2, (size_t)W * 3, H, hipMemcpyHostToDevice, st) != hipSuccess) {
+            errs[i] = "pair_begin: upload of the second image failed"; rcs[i] = POPPY_E_DEVICE; return;
+        }
         const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
         if (!gf) { errs[i] = "foreground: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         if (i == 1 && fg.medians_done) {                          // gabor2 starts when the second image's medians are through (queued now, long before)

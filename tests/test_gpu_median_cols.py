@@ -39,13 +39,23 @@ def _mixed(w, h, seed):
     return img
 
 
-FORMS = (1, 2, 3, 4, 5)
+def _wide(w, h, seed):
+    """every tile holds all 256 values AND medians from one end of them to the other (a steep ramp under noise): no window of 128 ranks holds a
+    tile's medians, the windows below and above the first are needed"""
+    rng = np.random.default_rng(seed)
+    ramp = (np.arange(w) % 90) * 255 // 89
+    img = np.clip(ramp[None, :] + rng.integers(-40, 41, (h, w)), 0, 255).astype(np.uint8)
+    img[::7, ::5] = rng.integers(0, 256, img[::7, ::5].shape, dtype=np.uint8)
+    return img
+
+
+FORMS = (1, 2, 3, 4, 5, 6, 7)
 
 
 @pytest.mark.parametrize("ksize", [3, 9, 17, 25, 33, 41, 49, 57, 65, 73, 81, 89])
 def test_every_window_of_the_chain_on_three_kinds_of_content(ctx, ksize):
     import oracle_lib as O
-    for img in (_noise(333, 129, ksize), _few(333, 129, ksize, 7), _mixed(333, 129, ksize)):
+    for img in (_noise(333, 129, ksize), _few(333, 129, ksize, 7), _mixed(333, 129, ksize), _wide(333, 129, ksize)):
         want = O.median_blur_u8(img, ksize)
         for form in FORMS:
             got = ctx.median_blur(img, ksize, form)
@@ -56,7 +66,7 @@ def test_every_window_of_the_chain_on_three_kinds_of_content(ctx, ksize):
 def test_ragged_sizes(ctx, w, h):
     import oracle_lib as O
     for ksize in (5, 33, 89):
-        for img in (_noise(w, h, w + h), _few(w, h, w * h, 3), _mixed(w, h, w)):
+        for img in (_noise(w, h, w + h), _few(w, h, w * h, 3), _mixed(w, h, w), _wide(w, h, h)):
             want = O.median_blur_u8(img, ksize)
             for form in FORMS:
                 got = ctx.median_blur(img, ksize, form)
@@ -72,7 +82,7 @@ def test_exactly_64_and_65_values_per_tile(ctx):
         img = vals[rng.integers(0, values, (150, 300))]
         for ksize in (9, 41, 89):
             want = O.median_blur_u8(img, ksize)
-            for form in (2, 3, 4, 5):
+            for form in (2, 3, 4, 5, 6, 7):
                 assert np.array_equal(ctx.median_blur(img, ksize, form), want), f"{values} values, ksize {ksize}, form {form}"
 
 
