@@ -40,6 +40,7 @@ public:
     // would take for this ksize
     int median(const uint8_t* src, int w, int h, int ksize, int form, hipStream_t s, uint8_t* dst);         // w*h*3 bytes once ensure() ran
     int prepare(int w, int h) { return ensure(w, h); }
+    int prepare2(int w, int h) { return ensure2(w, h); }      // the buffers of part 2 (a caller that uses the object from two threads allocates first)
     std::string err;
 
     hipEvent_t medians_done = nullptr;   // when set, run_device records it on its stream behind the last median (the pair set-up starts gabor2 there)

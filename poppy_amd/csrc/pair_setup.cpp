@@ -234,7 +234,12 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     };
     if (!align_first && gabor2_first && !gabor2_on_side_stream()) return POPPY_E_DEVICE;
     if (!c->setup_ev) HIPCHK(c, hipEventCreateWithFlags(&c->setup_ev, hipEventDisableTiming));
-    c->foreground_b.medians_done = (!align_first && !gabor2_first) ? c->setup_ev : nullptr;
+    // POPPY_GABOR2_AT: where gabor2 starts — 0 behind the second image's medians, 1 / 2 behind the FIRST image's ORB input / FAST kernels (queued by that
+    // image's thread): the first image's chain is through earlier than the second's, gabor2 then fills the GPU beside the second chain's tail of small launches
+    static const int gabor2_at = getenv("POPPY_GABOR2_AT") ? atoi(getenv("POPPY_GABOR2_AT")) : 2;      // (1080p 3.03 -> 2.96 ms, 4K 8.5 -> 8.1: tools/experiments/gabor2_at_ab.sh)
+    const int gabor2_late = (!align_first && !gabor2_first && !serial_chains) ? gabor2_at : 0;
+    if (gabor2_late && (c->foreground_b.prepare(W, H) || c->foreground_b.prepare2(W, H))) return fail(c, POPPY_E_DEVICE, "foreground buffers");
+    c->foreground_b.medians_done = (!align_first && !gabor2_first && !gabor2_late) ? c->setup_ev : nullptr;
     // Each image's thread goes on to the detector's second half by itself as soon as BOTH details are known (nfeatures, src/extractor.cpp:40-45):
     // the other image's detail is ready long before its own candidates are, so nobody waits for a whole chain.  `details` counts the images
     // whose detail is published (or whose chain failed before it).
@@ -274,12 +279,20 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
+        auto gabor2_behind_this_chain = [&]() {
+            if (hipEventRecord(c->setup_ev, st) != hipSuccess || hipStreamWaitEvent(c->copy_stream, c->setup_ev, 0) != hipSuccess || !gabor2_on_side_stream()) {
+                errs[i] = c->err.empty() ? "gabor2: stream wait failed" : c->err; rcs[i] = POPPY_E_DEVICE; return false;
+            }
+            return true;
+        };
+        if (i == 0 && gabor2_late == 1 && !gabor2_behind_this_chain()) return;
         hipError_t e = ratio >= 0.f ? hipMemcpyAsync(g[i].data(), gi, P, hipMemcpyDeviceToHost, st) : hipSuccess;
         if (e != hipSuccess) { errs[i] = std::string("pair_begin: ") + hipGetErrorString(e); rcs[i] = POPPY_E_DEVICE; return; }
         // the detector's first half needs no nfeatures (which takes BOTH images' detail, src/extractor.cpp:40-45): it follows the chain at once,
         // so the image that is through first does not wait for the other with the GPU half idle
         OrbDetector& orb = i ? c->orb_b : c->orb;
         if (orb.detect_begin(gi, W, W, H, st, true) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; return; }
+        if (i == 0 && gabor2_late == 2 && !gabor2_behind_this_chain()) return;
         if (serial_chains) return;                                // (one chain after the other: the second half follows below)
         details.wait_for(2);
         if (rcs[i ^ 1]) return;                                   // the other chain failed (its error is reported)
