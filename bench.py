@@ -67,29 +67,29 @@ def synth_pair(w, h, k):
 
 
 def measured_traffic(kernel, w, h):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r04_warp_pmc.json) — only when those passes were
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r05_warp_pmc.json) — only when those passes were
     taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
     import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_warp_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_pmc.json")))
         hsh = hashlib.sha256()
         for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
             hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
         if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
-            return None, "profiles/r04_warp_pmc.json was taken from other kernel sources: not quoted"
+            return None, "profiles/r05_warp_pmc.json was taken from other kernel sources: not quoted"
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
-            return None, "no counter pass for this kernel / size in profiles/r04_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r04_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r04_y_pmc.md)"
+            return None, "no counter pass for this kernel / size in profiles/r05_warp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/r05_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r05_z_pmc.md)"
     except (OSError, ValueError, KeyError):
-        return None, "profiles/r04_warp_pmc.json missing"
+        return None, "profiles/r05_warp_pmc.json missing"
 
 
 def profile_facts(kernel, w, h):
-    """What the committed profiles say about `kernel` at this size (profiles/r04_warp_facts.json, written by tools/warp_facts.py from the
+    """What the committed profiles say about `kernel` at this size (profiles/r05_warp_facts.json, written by tools/warp_facts.py from the
     round's rocprofv3 kernel trace and from the kernel's ISA): the trace's average duration and the kernel's vector-issue bound."""
     try:
-        f = json.load(open(os.path.join(ROOT, "profiles", "r04_warp_facts.json")))
+        f = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_facts.json")))
         return f.get(f"{w}x{h}", {}).get(kernel)
     except (OSError, ValueError):
         return None
@@ -135,7 +135,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
                                                          "instruction issue — the arithmetic-only 30.5 us is not its floor — but by its workgroups' turnover (ids + record slots -> barrier -> "
                                                          "taps -> gathers -> stores: 30 us of it remain with no arithmetic and no gather at all); DESIGN.md section 4"}}
     try:        # the frame's other full-resolution kernels, from the same committed trace: duration, algorithmic bytes (DESIGN.md's kernel table), fraction of 8 TB/s
-        allf = json.load(open(os.path.join(ROOT, "profiles", "r04_warp_facts.json"))).get(f"{w}x{h}", {})
+        allf = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_facts.json"))).get(f"{w}x{h}", {})
         others = {v["kernel"]: {k2: v[k2] for k2 in ("what", "algo_bytes_per_px", "trace_avg_us", "achieved_GBps", "frac_of_8_TBps")}
                   for k, v in allf.items() if k != "k_warp_bin" and "kernel" in v}
         if others:

@@ -19,7 +19,7 @@ P=profiles/${tag}_pmc.md
   for sz in "1920 1080" "3840 2160"; do set -- $sz
     echo "## $1x$2"; echo
     python tools/pmc_traffic.py gpurun_out/${tag}_fetch_$1/f_results.db gpurun_out/${tag}_write_$1/w_results.db --px $1*$2 | grep -v "$F"; echo
-    grep "$1x$2 k_warp_bin" /tmp/pmc_json.out | sed 's/^/`/; s/ grid / (grid /; s/: read /): read (x2) /; s/$/; the images alone are 12 B\/px (c1 3 + c2 3 in, tr1 3 + tr2 3 out), the rest are the id bytes (1 B/px) and the record slots of the tiles.  No id map, no blend mask./'; echo
+    grep "$1x$2 k_warp_bin" /tmp/pmc_json.out | sed 's/^/`/; s/ grid / (grid /; s/: read /): read (x2) /; s/$/; the images alone are 12 B\/px (c1 3 + c2 3 in, tr1 3 + tr2 3 out), the rest are the id bytes (1 B\/px) and the record slots of the tiles.  No id map, no blend mask./'; echo
   done; } > $P
 cp gpurun_out/${tag}_bench.json profiles/${tag}_bench.json
 python tools/warp_facts.py ${tag}
