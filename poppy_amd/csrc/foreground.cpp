@@ -24,6 +24,7 @@ ForegroundFilter::~ForegroundFilter() {
     if (logtab) (void)hipFree(logtab);
     if (h_easy) (void)hipHostFree(h_easy);
     if (easy_ev) (void)hipEventDestroy(easy_ev);
+    if (detail_ev) (void)hipEventDestroy(detail_ev);
 }
 
 void ForegroundFilter::release() {

@@ -32,6 +32,8 @@ public:
     const uint8_t* run_device(const uint8_t* d_bgr, size_t stride, int w, int h, hipStream_t s, const ForegroundDebugOut* dbg);
     // --- part 2 (foreground2.cpp): everything between goodFeatures and the ORB input, gabor2, dft_detail2 ---------------
     int detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out);
+    int detail_begin(const uint8_t* d_gf, int w, int h, hipStream_t s);      // the same in two halves: everything queued, no host round trip ...
+    int detail_end(double* out);                                             // ... and the value, once the stream has passed it
     const uint8_t* orb_input(const uint8_t* d_gf, int w, int h, int which, hipStream_t s, float* h_us = nullptr, float* h_gb = nullptr);
     const float* gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s);
     uint8_t* bgr_staging() { return d_bgr; }
@@ -79,6 +81,8 @@ private:
     uint32_t* med_pres = nullptr;        // two presence maps (kernels_median_cols.hip): the current median's source and result; then the counter of easy tiles
     uint32_t* h_easy = nullptr;          // pinned: that counter read back
     hipEvent_t easy_ev = nullptr;        // ... when this event has passed
+    hipEvent_t detail_ev = nullptr;      // dft_detail2's sum of squares has landed in h_easy + 2
+    double detail_px = 0;
     bool prepared = false;
 };
 

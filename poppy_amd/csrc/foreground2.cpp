@@ -188,35 +188,37 @@ void ForegroundFilter::release2() {
 }
 
 // dft_detail2(goodFeatures): RMS of the first `cols` bytes of every row of the normalised, centred log spectrum
-int ForegroundFilter::detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out) {
+// dft_detail2 in two halves: detail_begin queues everything on the stream (no host round trip: the normalisation's scale and shift are formed on the
+// device, the sum of squares lands in pinned memory behind an event) so that the caller can queue the ORB input's kernels behind it at once;
+// detail_end waits for the event and finishes the value.
+int ForegroundFilter::detail_begin(const uint8_t* d_gf, int w, int h, hipStream_t s) {
     if (ensure(w, h) || ensure2(w, h)) return -2;
     const int N = dftN, M = dftM, Nc = N & -2, Mc = M & -2;
-    launch_pad_complex(d_gf, (float2*)spec, w, h, N, M, s);
+    launch_pad_complex(d_gf, (float2*)spec, w, h, N, M, minmax, powsum, s);
     DftPlanDev pr, pc;
     pr.n = dft_n[0]; pr.nf = dft_nf[0]; pr.itab = d_itab[0]; pr.wave = (const float2*)d_wave[0];
     pc.n = dft_n[1]; pc.nf = dft_nf[1]; pc.itab = d_itab[1]; pc.wave = (const float2*)d_wave[1];
     for (int k = 0; k < 16; ++k) { pr.factors[k] = dft_factors[0][k]; pc.factors[k] = dft_factors[1][k]; }
     launch_dft2d_exact((const float2*)spec, (float2*)spec_tmp, (float2*)spec_out, N, M, pr, pc, s);
-    const unsigned init[2] = {0xffffffffu, 0u};
-    F2_CHK(hipMemcpyAsync(minmax, init, 8, hipMemcpyHostToDevice, s));
     launch_spectrum_log((const float2*)spec_out, mag, logtab, minmax, N, M, Nc, Mc, s);
-    unsigned mm[2];
-    F2_CHK(hipMemcpyAsync(mm, minmax, 8, hipMemcpyDeviceToHost, s));
-    F2_CHK(hipStreamSynchronize(s));
-    auto ord2f = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; };
-    const double smin = ord2f(mm[0]), smax = ord2f(mm[1]);
-    // cv::normalize(.., 0, 1, NORM_MINMAX) into CV_32F (OCV/core/src/norm.cpp:1384-1397): the scale is rounded to float
-    // first and the shift is built from that rounded scale, then convertTo(CV_32F, scale, shift)
-    double scale = (1.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0);
-    scale = (float)scale;
-    const double shift = (float)0.0 - (float)(smin * scale);
-    F2_CHK(hipMemsetAsync(powsum, 0, 8, s));
-    launch_spectrum_bytes(mag, (float)scale, (float)shift, Nc, Mc, powsum, s);
-    unsigned long long ps = 0;
-    F2_CHK(hipMemcpyAsync(&ps, powsum, 8, hipMemcpyDeviceToHost, s));
-    F2_CHK(hipStreamSynchronize(s));
-    *out = std::sqrt((double)ps / (double)(Nc * Mc));
+    launch_spectrum_bytes(mag, minmax, Nc, Mc, powsum, s);
+    if (!detail_ev) F2_CHK(hipEventCreateWithFlags(&detail_ev, hipEventDisableTiming));
+    F2_CHK(hipMemcpyAsync(h_easy + 2, powsum, 8, hipMemcpyDeviceToHost, s));      // (pinned: 16 bytes, the first word belongs to the medians' count)
+    F2_CHK(hipEventRecord(detail_ev, s));
+    detail_px = (double)Nc * (double)Mc;
     return 0;
+}
+int ForegroundFilter::detail_end(double* out) {
+    if (!detail_ev) { err = "detail_end without detail_begin"; return -1; }
+    F2_CHK(hipEventSynchronize(detail_ev));
+    unsigned long long ps;
+    memcpy(&ps, h_easy + 2, 8);
+    *out = std::sqrt((double)ps / detail_px);
+    return 0;
+}
+int ForegroundFilter::detail(const uint8_t* d_gf, int w, int h, hipStream_t s, double* out) {
+    const int rc = detail_begin(d_gf, w, h, s);
+    return rc ? rc : detail_end(out);
 }
 
 // the ORB input image of Extractor::keypoints for one goodFeatures image (device in, device out); which = 0 / 1 selects the output buffer

@@ -90,8 +90,8 @@ void launch_orb_input(const float* gb, const float* us, const float* radial, uin
 // cv::dft's complex float transform (exact operation order, dft_exact.h builds the tables); 2-D forward: rows then columns
 struct DftPlanDev { int n, nf; int factors[16]; const int* itab; const float2* wave; };
 void launch_dft2d_exact(const float2* src, float2* tmp, float2* dst, int n, int m, const DftPlanDev& rows, const DftPlanDev& cols, hipStream_t s);
-void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s);
+void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, unsigned* minmax, unsigned long long* powsum, hipStream_t s);   // also resets the two reductions
 void launch_spectrum_log(const float2* spec, float* mag, const float* d_logtab, unsigned* minmax, int n, int m, int nc, int mc, hipStream_t s);
-void launch_spectrum_bytes(const float* mag, float scale, float shift, int nc, int mc, unsigned long long* powsum, hipStream_t s);
+void launch_spectrum_bytes(const float* mag, const unsigned* minmax, int nc, int mc, unsigned long long* powsum, hipStream_t s);
 
 }  // namespace poppy_hip

@@ -164,8 +164,11 @@ __device__ __forceinline__ float cv_log32f_dev(float x, const float* __restrict_
 }
 __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
-__global__ void __launch_bounds__(256) k_pad_complex(const uint8_t* __restrict__ src, float2* __restrict__ dst, int W, int H, int N, int M) {
+// (also resets the two reductions of the spectrum kernels that follow it on the stream: min / max as ordered words, the sum of squares)
+__global__ void __launch_bounds__(256) k_pad_complex(const uint8_t* __restrict__ src, float2* __restrict__ dst, int W, int H, int N, int M,
+                                                     unsigned* __restrict__ minmax, unsigned long long* __restrict__ powsum) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x == 0 && y == 0) { minmax[0] = 0xffffffffu; minmax[1] = 0u; powsum[0] = 0ull; }
     if (x >= N) return;
     dst[(size_t)y * N + x] = make_float2((x < W && y < H) ? (float)src[(size_t)y * W + x] : 0.f, 0.f);
 }
@@ -203,9 +206,16 @@ __global__ void __launch_bounds__(256) k_spectrum_log(const float2* __restrict__
     if (threadIdx.x == 0) { atomicMin(&minmax[0], smin); atomicMax(&minmax[1], smax); }
 }
 // sum over rows r and bytes b < Nc of (byte b of row r of the quadrant-swapped, min-max normalised image)^2
-__global__ void __launch_bounds__(256) k_spectrum_bytes(const float* __restrict__ mag, float scale, float shift, int Nc, int Mc,
+// cv::normalize(.., 0, 1, NORM_MINMAX) into CV_32F (OCV/core/src/norm.cpp:1384-1397): the scale is rounded to float first and the shift is built from that
+// rounded scale, then convertTo(CV_32F, scale, shift).  Every thread forms the two from the min / max words of k_spectrum_log (the reference's double
+// arithmetic: one correctly rounded division, one product, three roundings to float) — on the host until round 4, at the price of a round trip in mid-chain.
+__global__ void __launch_bounds__(256) k_spectrum_bytes(const float* __restrict__ mag, const unsigned* __restrict__ minmax, int Nc, int Mc,
                                                         unsigned long long* __restrict__ powsum) {
     __shared__ unsigned long long ssum;
+    const unsigned o0 = minmax[0], o1 = minmax[1];
+    const double smin = (double)__uint_as_float((o0 & 0x80000000u) ? (o0 & 0x7fffffffu) : ~o0), smax = (double)__uint_as_float((o1 & 0x80000000u) ? (o1 & 0x7fffffffu) : ~o1);
+    const double scale_d = (double)(float)((1.0 - 0.0) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0.));
+    const float scale = (float)scale_d, shift = (float)((double)((float)0.0 - (float)(smin * scale_d)));
     if (threadIdx.x == 0) ssum = 0;
     __syncthreads();
     const int cx = Nc / 2, cy = Mc / 2;
@@ -470,14 +480,14 @@ void launch_dft2d_exact(const float2* src, float2* tmp, float2* dst, int n, int 
     hipLaunchKernelGGL(k_dft_lines, dim3((n + 63) / 64), dim3(64), 0, s, tmp, dst, n, 1, n, cols);
 }
 
-void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, hipStream_t s) {
-    hipLaunchKernelGGL(k_pad_complex, dim3((n + 255) / 256, m), dim3(256), 0, s, src, dst, w, h, n, m);
+void launch_pad_complex(const uint8_t* src, float2* dst, int w, int h, int n, int m, unsigned* minmax, unsigned long long* powsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_pad_complex, dim3((n + 255) / 256, m), dim3(256), 0, s, src, dst, w, h, n, m, minmax, powsum);
 }
 void launch_spectrum_log(const float2* spec, float* mag, const float* d_logtab, unsigned* minmax, int n, int m, int nc, int mc, hipStream_t s) {
     hipLaunchKernelGGL(k_spectrum_log, dim3(std::min(kSpectrumBlocks, ((nc + 255) / 256) * mc)), dim3(256), 0, s, spec, mag, d_logtab, minmax, n, m, nc, mc);
 }
-void launch_spectrum_bytes(const float* mag, float scale, float shift, int nc, int mc, unsigned long long* powsum, hipStream_t s) {
-    hipLaunchKernelGGL(k_spectrum_bytes, dim3(std::min(kSpectrumBlocks, (((nc + 3) / 4 + 255) / 256) * mc)), dim3(256), 0, s, mag, scale, shift, nc, mc, powsum);
+void launch_spectrum_bytes(const float* mag, const unsigned* minmax, int nc, int mc, unsigned long long* powsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_spectrum_bytes, dim3(std::min(kSpectrumBlocks, (((nc + 3) / 4 + 255) / 256) * mc)), dim3(256), 0, s, mag, minmax, nc, mc, powsum);
 }
 
 }  // namespace poppy_hip

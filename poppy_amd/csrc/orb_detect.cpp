@@ -22,7 +22,7 @@ namespace poppy_hip {
 namespace {
 inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
 
-struct Cand { int x, y, level; float response; };
+struct Cand { int x, y, level; float response; float angle = 0.f; };
 struct Key { float response; int i; };            // what retainBest compares, plus where the candidate sits in the raster-ordered list
 struct ByResponse { template <typename T> bool operator()(const T& a, const T& b) const { return a.response > b.response; } };
 
@@ -250,17 +250,22 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
     if (all.empty()) return 0;
     // retainBest keeps every tie with the n-th response (keypoint.cpp:69-90) and FAST scores are small integers: on noise-like content the survivors
     // of the first selection can outnumber any fixed buffer — the keypoint buffers grow to what was selected
-    if ((int)all.size() > kp_cap) ORB_CHK(grow_keypoints((int)all.size() + (int)all.size() / 4));
+    // (room for two floats per selected candidate: Harris response and angle come back in one copy)
+    if (2 * (int)all.size() > kp_cap) ORB_CHK(grow_keypoints(2 * (int)all.size() + (int)all.size() / 2));
 
     auto upload = [&](const std::vector<Cand>& v) -> hipError_t {
         for (size_t i = 0; i < v.size(); ++i) { h_kp[3 * i] = v[i].level; h_kp[3 * i + 1] = v[i].x; h_kp[3 * i + 2] = v[i].y; }
         return hipMemcpyAsync(d_kp, h_kp, v.size() * 3 * sizeof(int), hipMemcpyHostToDevice, s);
     };
     ORB_CHK(upload(all));
+    // Harris responses AND the intensity-centroid angles of all survivors of the first selection in one submission: the angle of a keypoint does not
+    // depend on the second selection, so computing it for the ~2 x nfeatures candidates (a few us more) saves the second round trip of upload,
+    // launch, copy and wait that followed the host's retainBest until round 4
     launch_harris(d_atlas, S, d_kp, (int)all.size(), d_val, s);
-    ORB_CHK(hipMemcpyAsync(h_val, d_val, all.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    launch_ic_angle(d_atlas, S, d_kp, (int)all.size(), d_val + all.size(), s);
+    ORB_CHK(hipMemcpyAsync(h_val, d_val, 2 * all.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     ORB_CHK(hipStreamSynchronize(s));
-    for (size_t i = 0; i < all.size(); ++i) all[i].response = h_val[i];
+    for (size_t i = 0; i < all.size(); ++i) { all[i].response = h_val[i]; all[i].angle = h_val[all.size() + i]; }
     ms_harris = since();
 
     std::vector<Cand> fin;
@@ -272,15 +277,11 @@ int OrbDetector::detect_finish(int nfeatures, hipStream_t s, std::vector<OrbKeyP
         fin.insert(fin.end(), k.begin(), k.end());
     }
     if (fin.empty()) return 0;
-    ORB_CHK(upload(fin));
-    launch_ic_angle(d_atlas, S, d_kp, (int)fin.size(), d_val, s);
-    ORB_CHK(hipMemcpyAsync(h_val, d_val, fin.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    ORB_CHK(hipStreamSynchronize(s));
     out.resize(fin.size());
     last_levels.resize(fin.size() * 3);
     for (size_t i = 0; i < fin.size(); ++i) {
         const float sc = S.lv[fin[i].level].scale;
-        out[i] = OrbKeyPoint{(float)fin[i].x * sc, (float)fin[i].y * sc, patch * sc, h_val[i], fin[i].response, fin[i].level, -1};
+        out[i] = OrbKeyPoint{(float)fin[i].x * sc, (float)fin[i].y * sc, patch * sc, fin[i].angle, fin[i].response, fin[i].level, -1};
         last_levels[3 * i] = fin[i].level; last_levels[3 * i + 1] = fin[i].x; last_levels[3 * i + 2] = fin[i].y;
     }
     if (stage_times) {

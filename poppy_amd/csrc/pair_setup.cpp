@@ -274,10 +274,13 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
                 errs[i] = c->err.empty() ? "gabor2: stream wait failed" : c->err; rcs[i] = POPPY_E_DEVICE; return;
             }
         }
-        if (fg.detail(gf, W, H, st, &d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
-        publish.now();
+        // dft_detail2 and the ORB input both read goodFeatures: the ORB input's kernels are queued behind dft_detail2's before the host waits for the detail value
+        // (until round 4 the chain's stream ran dry twice in mid-chain, at the two read-backs of dft_detail2)
+        if (fg.detail_begin(gf, W, H, st)) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         const uint8_t* gi = fg.orb_input(gf, W, H, 0, st);
         if (!gi) { errs[i] = "orb_input: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        if (fg.detail_end(&d[i])) { errs[i] = "dft_detail2: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
+        publish.now();
         g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
         auto gabor2_behind_this_chain = [&]() {
             if (hipEventRecord(c->setup_ev, st) != hipSuccess || hipStreamWaitEvent(c->copy_stream, c->setup_ev, 0) != hipSuccess || !gabor2_on_side_stream()) {
