@@ -83,20 +83,49 @@ __global__ void __launch_bounds__(256) k_orb_resize(const uint8_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16
 // ------------------------------------------------------------------------------------------------
-__constant__ int c_ring[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
-                                  {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
-
-__device__ __forceinline__ bool run9(unsigned m) {       // 16-bit circular mask has >= 9 consecutive ones
-    unsigned x = m | (m << 16);
-    unsigned a = x & (x >> 1);
-    a &= a >> 2;
-    a &= a >> 4;
-    a &= x >> 8;
-    return (a & 0xFFFFu) != 0;
-}
-
 constexpr int kFastRows = 4;      // rows of one level per block: the grid spans the LARGEST level, so most blocks of the small levels fall outside their
                                   // level and only cost their dispatch; fewer, taller blocks cut that four-fold
+
+__device__ __forceinline__ constexpr int ring_dx(int k) { constexpr int t[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}; return t[k]; }
+__device__ __forceinline__ constexpr int ring_dy(int k) { constexpr int t[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}; return t[k]; }
+
+// FAST-9/16 corner score of the pixel at c (0: no corner), threshold t (fast.cpp:57-292, fast_score.cpp:115-200).  A 9-arc of the 16-ring holds one of every
+// two opposite ring pixels, so four opposite pairs are looked at first, as the reference's own loop does (fast.cpp:110-131): a pair with no pixel brighter
+// than v + t rules the bright arc out, one with none darker than v - t the dark arc; most pixels end there, after two loads.
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int st, int threshold) {
+    const int v = c[0];
+    int d[16];
+    unsigned poss = 3;                                          // bit 0: a dark arc (ring < v - t) is still possible, bit 1: a bright one
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        d[k] = v - (int)c[ring_dy(k) * st + ring_dx(k)];
+        d[k + 8] = v - (int)c[ring_dy(k + 8) * st + ring_dx(k + 8)];
+        poss &= ((d[k] > threshold || d[k + 8] > threshold) ? 1u : 0u) | ((d[k] < -threshold || d[k + 8] < -threshold) ? 2u : 0u);
+        if (!poss) return 0;
+    }
+#pragma unroll
+    for (int k = 1; k < 8; k += 2) {
+        d[k] = v - (int)c[ring_dy(k) * st + ring_dx(k)];
+        d[k + 8] = v - (int)c[ring_dy(k + 8) * st + ring_dx(k + 8)];
+    }
+    // With d = v - ring: a dark 9-arc exists iff some arc's MINIMUM of d exceeds t, a bright one iff some arc's MAXIMUM lies below -t; the score (the largest
+    // threshold at which the pixel is still a corner, fast_score.cpp:115-200) is max(largest arc minimum, -(smallest arc maximum)) - 1.  So the two extremes
+    // decide AND score.  The sixteen arcs share their pieces: three-in-a-row extremes (16 x min3 / max3), an arc = three of those.
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int best_min = -1000, best_max = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        best_min = max(best_min, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));
+        best_max = min(best_max, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));
+    }
+    const int sc = max(best_min, -best_max);
+    return sc > threshold ? (int)(uint8_t)(sc - 1) : 0;
+}
 
 __global__ void __launch_bounds__(256) k_fast_score(const uint8_t* __restrict__ atlas, OrbLevelSet S, uint8_t* __restrict__ scores, int threshold) {
     const OrbLevel L = S.lv[blockIdx.z];
@@ -106,30 +135,8 @@ __global__ void __launch_bounds__(256) k_fast_score(const uint8_t* __restrict__ 
         const int y = blockIdx.y * kFastRows + rr;
         if (y >= L.h) return;
         uint8_t result = 0;
-        if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-            const uint8_t* c = atlas + L.offset + (size_t)(y + kOrbBorder) * L.stride + (x + kOrbBorder);
-            int v = c[0];
-            int d[16];
-            unsigned dark = 0, bright = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                d[k] = v - (int)c[c_ring[k][1] * (int)L.stride + c_ring[k][0]];
-                dark |= (unsigned)(d[k] > threshold) << k;          // ring < v - t
-                bright |= (unsigned)(d[k] < -threshold) << k;       // ring > v + t
-            }
-            if (run9(dark) || run9(bright)) {
-                int best_min = -1000, best_max = 1000;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    int mn = d[k], mx = d[k];
-#pragma unroll
-                    for (int j = 1; j < 9; ++j) { int e = d[(k + j) & 15]; mn = min(mn, e); mx = max(mx, e); }
-                    best_min = max(best_min, mn);
-                    best_max = min(best_max, mx);
-                }
-                result = (uint8_t)(max(best_min, -best_max) - 1);
-            }
-        }
+        if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3)
+            result = (uint8_t)fast_score_at(atlas + L.offset + (size_t)(y + kOrbBorder) * L.stride + (x + kOrbBorder), (int)L.stride, threshold);
         scores[L.score_offset + (size_t)y * L.w + x] = result;
     }
 }

@@ -54,6 +54,30 @@ long hypotf_selfcheck(long n, unsigned long long seed) {
 // first of them is found by evaluating the real expression on the few s below s_min (1 + 2^-20), no other root is taken.  Taken points are
 // removed from the (order-preserving) candidate arrays instead of being skipped; (-1, -1), which the reference uses as its tombstone and
 // therefore never pairs, is dropped up front.
+// the squared distances of one point to the m candidates, and their minimum (the caller's inner loops; cloned for AVX2 hosts: the arithmetic is the same
+// per element — double products and one sum, no contraction — only eight of them at a time)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+static double squared_distances(const float* __restrict__ x, const float* __restrict__ y, size_t m, float ax, float ay, double* __restrict__ sq) {
+    for (size_t j = 0; j < m; ++j) {
+        const float dx = x[j] - ax, dy = y[j] - ay;
+        sq[j] = (double)dx * (double)dx + (double)dy * (double)dy;
+    }
+    // the minimum as the plain scan `s = sq[j] < s ? sq[j] : s` finds it: a NaN in front stays (the caller then takes the reference's loop as it stands),
+    // NaNs elsewhere are passed over; four running minima only cut the scan's dependency chain
+    if (!(sq[0] == sq[0])) return sq[0];
+    double m0 = sq[0], m1 = m0, m2 = m0, m3 = m0;
+    size_t j = 1;
+    for (; j + 3 < m; j += 4) {
+        m0 = sq[j] < m0 ? sq[j] : m0; m1 = sq[j + 1] < m1 ? sq[j + 1] : m1;
+        m2 = sq[j + 2] < m2 ? sq[j + 2] : m2; m3 = sq[j + 3] < m3 ? sq[j + 3] : m3;
+    }
+    for (; j < m; ++j) m0 = sq[j] < m0 ? sq[j] : m0;
+    m0 = m1 < m0 ? m1 : m0; m2 = m3 < m2 ? m3 : m2;
+    return m2 < m0 ? m2 : m0;
+}
+
 void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, std::vector<PointPair>& pairs) {
     std::vector<float> X, Y;
     X.reserve(src2.size()); Y.reserve(src2.size());
@@ -66,12 +90,7 @@ void greedy_pairs(const std::vector<P2f>& src1, const std::vector<P2f>& src2, st
         if (!m) break;                                          // (the reference goes on, finding nothing)
         const float ax = a.x, ay = a.y;
         float* const x = X.data(); float* const y = Y.data(); double* const sq = S.data();
-        for (size_t j = 0; j < m; ++j) {
-            const float dx = x[j] - ax, dy = y[j] - ay;
-            sq[j] = (double)dx * (double)dx + (double)dy * (double)dy;
-        }
-        double s_min = sq[0];
-        for (size_t j = 1; j < m; ++j) s_min = sq[j] < s_min ? sq[j] : s_min;
+        const double s_min = squared_distances(x, y, m, ax, ay, sq);
         size_t pick = 0;
         if (s_min == s_min) {                                   // (a NaN coordinate: fall through to the plain scan below)
             const float best = (float)std::sqrt(s_min);
