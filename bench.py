@@ -296,12 +296,14 @@ def content_sensitivity(capi, ctx, w, h):
             p1, _ = ctx.pair_points()
             k0 = ctx.warp_counts()
             ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
-            reps = 5
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                ctx.reset(); ctx.render_many(shapes, chain=True)
-            ctx.sync()
-            us = (time.perf_counter() - t0) / (reps * FRAMES) * 1e6
+            reps, blocks = 2, []                  # the fastest of four blocks of two sequences (a single block has shown 150 - 180 us on one box, run to run)
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.reset(); ctx.render_many(shapes, chain=True)
+                ctx.sync()
+                blocks.append((time.perf_counter() - t0) / (reps * FRAMES) * 1e6)
+            us = min(blocks)
             k1 = ctx.warp_counts()
             out[name] = {"pair_setup_ms_from_host_images": round(sorted(t)[len(t) // 2], 3), "point_pairs": int(len(p1)), "chained_frame_us": round(us, 1),
                          "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), (int(y - x) for x, y in zip(k0, k1))))}
@@ -336,12 +338,14 @@ def odd_width(capi, dev_index):
             p1, _ = ctx.pair_points()
             k0 = ctx.warp_counts()
             ctx.reset(); ctx.render_many(shapes, chain=True); ctx.sync()
-            reps = 5
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                ctx.reset(); ctx.render_many(shapes, chain=True)
-            ctx.sync()
-            us = (time.perf_counter() - t0) / (reps * FRAMES) * 1e6
+            reps, blocks = 2, []                  # the fastest of four blocks of two sequences (a single block has shown 150 - 180 us on one box, run to run)
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.reset(); ctx.render_many(shapes, chain=True)
+                ctx.sync()
+                blocks.append((time.perf_counter() - t0) / (reps * FRAMES) * 1e6)
+            us = min(blocks)
             k1 = ctx.warp_counts()
             out[name] = {"pair_setup_ms_from_host_images": round(sorted(t)[len(t) // 2], 3), "point_pairs": int(len(p1)), "chained_frame_us": round(us, 1),
                          "frames_by_kernel": dict(zip(("k_warp_bin", "k_warp_tile", "k_warp4"), (int(y - x) for x, y in zip(k0, k1))))}
@@ -455,7 +459,7 @@ def main():
                     "set-up's on every rank, and use it in the timed region when it is both identical and faster.  Opt-in: its RCCL transport has not run on more than one GPU yet (the default is the pair set-up on rank 0 + one broadcast of the pair state)")
     ap.add_argument("--no-shard-setup", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the 512x512x30 whole-morph CPU figure (~40 s of oracle time)")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 3 (measured on one box, pairs per step 4 / 8: 2 contexts 5.11k / 5.03k frames/s, 3: 5.35k / 5.51k, 4: 5.26k / 5.36k; the roofline kernel's in-bench launches stretch from 21.6 to 23.5-24.8 and 27 us as more kernels compete)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts (host threads) a rank's pairs are spread over; default 6 = one per pair of a step (round 5, ms per step of 6 pairs on one box, ten pools each: 3 contexts 59.2 - 60.4 with the chains of a set-up one after the other — side by side one pool in four ran at 75 -, 4: 57.2 - 59.3, 5: 57.1 - 60.5, 6: 55.9 - 59.4; profiles/r05_notes.md section 6)")
     args = ap.parse_args()
     global W, H, FRAMES, PAIRS
     if args.width and args.height:
@@ -472,7 +476,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.contexts <= 0:
-        args.contexts = 3
+        args.contexts = 6
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:

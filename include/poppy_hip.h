@@ -258,6 +258,11 @@ int poppy_hip_gabor_field(poppy_hip_ctx* ctx, const uint8_t* bgr, size_t stride,
  * midpoint, out[2] pixels formed again because of them. */
 int poppy_hip_set_gabor_direct(poppy_hip_ctx* ctx, int on);
 int poppy_hip_gabor_doubt(unsigned long long out[3]);
+/* How poppy_hip_pair_begin* runs the two images' filter chains (Extractor::foreground -> dft_detail2 -> ORB input -> detector, src/extractor.cpp:33-83, once per image):
+ * serial = 0 (default of a context) side by side on two streams and two host threads — the shortest set-up when the context has the GPU to itself —, serial != 0 one
+ * after the other.  The contexts of a pool with three or more contexts per device are created with serial = 1: their set-ups run side by side anyway, and six chains on
+ * the process's four hardware queues made the pool's speed a lottery.  Both orders leave the same pair state in every bit.                                          */
+int poppy_hip_set_setup_chains(poppy_hip_ctx* ctx, int serial);
 int poppy_radial_gradient(int width, int height, float* out);
 int poppy_radial_mask(int width, int height, float* out);
 /* Host-side tables behind two device kernels, exposed for tests that run without a GPU (no reference counterpart):

@@ -34,7 +34,7 @@ SYMBOLS = [
     "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_comm_info", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_sharded_setups", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
-    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
+    "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_set_setup_chains", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         L.poppy_hip_orb_input.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
         L.poppy_hip_gabor_field.argtypes = [vp, vp, sz, i, i, vp]
         L.poppy_hip_set_gabor_direct.argtypes = [vp, i]
+        L.poppy_hip_set_setup_chains.argtypes = [vp, i]
         L.poppy_radial_gradient.argtypes = [i, i, vp]
         L.poppy_radial_mask.argtypes = [i, i, vp]
         L.poppy_gabor_tables.argtypes = [i, vp, vp]
@@ -664,6 +665,10 @@ class Context:
     def set_gabor_direct(self, on=True):
         """Gabor banks as direct double sums (True) or tiled FFTs (False, the default)."""
         self._chk(lib().poppy_hip_set_gabor_direct(self.h, int(on)), "set_gabor_direct")
+
+    def set_setup_chains(self, serial=True):
+        """pair set-up: the two images' chains one after the other (True; what a pool of >= 3 contexts uses) or side by side (False, a context's default)."""
+        self._chk(lib().poppy_hip_set_setup_chains(self.h, int(serial)), "set_setup_chains")
 
     def gabor_field(self, bgr):
         a = np.ascontiguousarray(bgr, np.uint8)

@@ -609,6 +609,7 @@ poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int con
         for (int k = 0; k < contexts_per_device; ++k) {
             poppy_hip_ctx* c = poppy_hip_create(devices[d], settings);
             if (!c) { set_err(err, err_len, std::string("poppy_hip_create: ") + poppy_hip_create_error()); poppy_hip_pool_destroy(p); return nullptr; }
+            c->setup_serial = contexts_per_device >= 3;           // (pair_setup.cpp: with three set-ups side by side the chains of a pair run one after the other)
             p->ctx.push_back(c); p->device_of.push_back(devices[d]);
         }
     return p;

@@ -124,6 +124,7 @@ struct poppy_hip_ctx {
     uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr;
     static const int kStageRing = 8;          // most pinned frames in flight towards the writer (POPPY_HIP_RING, default 3)
     hipStream_t dl_stream = nullptr;
+    bool setup_serial = false;                  // pair set-up: the two images' chains one after the other (set by pools of >= 3 contexts per device and by poppy_hip_set_setup_chains)
     hipEvent_t dl_done[kStageRing] = {};
 };
 

@@ -191,7 +191,11 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     c->c2_raw_valid = false;
     const size_t P = (size_t)W * H;
     static const bool gabor2_first = getenv("POPPY_GABOR2_FIRST") != nullptr;
-    static const bool serial_chains = getenv("POPPY_SETUP_SERIAL") != nullptr;    // measurement aid: one image's chain alone on the GPU
+    // One image's chain after the other on the GPU: a context of a pool of three or more (three set-ups side by side fill the GPU; two chains each would only put
+    // six chains on the process's four hardware queues — which layout a pool of three got was a lottery with a 25 % slower outcome in one pool of four, profiles/r05_notes.md
+    // section 6), a caller's choice (poppy_hip_set_setup_chains), or POPPY_SETUP_SERIAL
+    static const bool serial_env = getenv("POPPY_SETUP_SERIAL") != nullptr;
+    const bool serial_chains = serial_env || c->setup_serial;
     // Host images: the second image is uploaded by its own chain's thread on that chain's stream, so the first image's chain — stream-ordered behind its
     // own upload — has the GPU to itself for the length of a copy instead of both waiting for both (POPPY_SETUP_UPLOAD_BOTH=1: the order before round 5)
     static const bool upload_both = getenv("POPPY_SETUP_UPLOAD_BOTH") != nullptr;
@@ -449,6 +453,12 @@ int poppy_hip_orb_input(poppy_hip_ctx* c, const uint8_t* good_features, int W, i
 int poppy_hip_set_gabor_direct(poppy_hip_ctx* c, int on) {
     if (!c) return POPPY_E_ARG;
     c->foreground.gabor_direct = c->foreground_b.gabor_direct = on != 0;
+    return POPPY_OK;
+}
+
+int poppy_hip_set_setup_chains(poppy_hip_ctx* c, int serial) {
+    if (!c) return POPPY_E_ARG;
+    c->setup_serial = serial != 0;
     return POPPY_OK;
 }
 

@@ -63,6 +63,30 @@ def test_pair_begin_from_raw_images_reproduces_poppy_morph(case):
     c.close()
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_pair_begin_with_the_chains_one_after_the_other(case):
+    """poppy_hip_set_setup_chains(1) — what the contexts of a pool of three or more use: the two images' chains one after the other instead of side by side.  The same
+    pair state as the default order and as the real poppy::morph: detail values, nfeatures, prepared point pairs, gabor2, the last frame."""
+    from poppy_amd import capi
+    inp = G.astage_inputs(case)
+    c = capi.Context(0, number_of_frames=int(inp["cfg"][0]))
+    nf0, det0 = c.pair_begin(inp["img1"], inp["img2"])
+    a0, b0 = c.pair_points()
+    g0 = c.fetch("gabor2")
+    c.set_setup_chains(True)
+    nf, det = c.pair_begin(inp["img1"], inp["img2"])
+    ref = G.full(case, "detail")
+    assert nf == nf0 == int(ref[3]) and det == det0 == (ref[0], ref[1])
+    p1, p2 = c.pair_points()
+    assert np.array_equal(p1, a0) and np.array_equal(p2, b0)
+    G.check(case, "prepared1", p1)
+    G.check(case, "prepared2", p2)
+    assert np.array_equal(c.fetch("gabor2").view(np.uint32), g0.view(np.uint32))
+    frames = c.morph_frames(-1.0)
+    G.check(case, f"frame{len(frames) - 1}", frames[-1])
+    c.close()
+
+
 @pytest.mark.parametrize("case", ["a_256x256_radial", "a_320x200_radial"])
 def test_pair_begin_with_radial_mask_reproduces_poppy_morph(case):
     """Settings::enable_radial_mask (the CLI's --radial; src/extractor.cpp:178-197, src/draw.cpp:21-38) against the REAL reference run with the
