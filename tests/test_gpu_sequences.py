@@ -328,6 +328,51 @@ def test_morph_pairs_one_device():
             G.check(cases[p], f"frame{j}", f)
 
 
+def test_morph_pairs_on_three_contexts():
+    """A pool of three contexts per device runs a pair set-up's two image chains one after the other (poppy_hip_set_setup_chains, set by poppy_hip_pool_create from
+    three contexts on): four pairs over three contexts, every frame of every pair as the reference's."""
+    from poppy_amd import capi
+    case = "a_256x256_chain"
+    inp = G.astage_inputs(case)
+    n = int(inp["cfg"][0])
+    out = capi.morph_pairs([0], [(inp["img1"], inp["img2"])] * 4, contexts_per_device=3, number_of_frames=n)
+    assert sorted(out) == [0, 1, 2, 3]
+    for p in out:
+        assert len(out[p]) == n
+        for j, f in enumerate(out[p]):
+            G.check(case, f"frame{j}", f)
+
+
+def test_tuned_pool_and_communicator_info():
+    """poppy_hip_pool_create_tuned makes candidate pools, times the built-in calibration batch on each and hands out one of them, which then renders device-resident
+    pairs like any pool; poppy_hip_comm_info without a communicator reports -1 for what RCCL would say, and the world of one after comm_init."""
+    import ctypes as C
+    from poppy_amd import capi
+    inp = G.astage_inputs("a_256x256_chain")
+    n = int(inp["cfg"][0])
+    h, w = inp["img1"].shape[:2]
+    pool = capi.Pool([0], contexts_per_device=2, tuned_for=(w, h), max_candidates=2, number_of_frames=n)
+    assert 1 <= len(pool.candidates_ms) <= 2 and all(ms > 0 for ms in pool.candidates_ms) and 0 <= pool.kept < len(pool.candidates_ms)
+    hip = C.CDLL("libamdhip64.so")
+    ptrs = []
+    for img in (inp["img1"], inp["img2"]):
+        a = np.ascontiguousarray(img)
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        ptrs.append(d.value)
+    assert pool.morph_pairs_device_counted([tuple(ptrs)] * 3, w, h, -1.0) == 3 * n
+    pool.close()
+    for p in ptrs:
+        hip.hipFree(C.c_void_p(p))
+    ctx = capi.Context(0, number_of_frames=1)
+    assert ctx.comm_info()[2:] == (-1, -1)
+    ctx.comm_init(0, 1, capi.comm_id())
+    assert ctx.comm_info() == (0, 1, 0, 1)
+    ctx.comm_free()
+    ctx.close()
+
+
 def test_pool_refuses_several_pairs_under_auto_align():
     """With --autoalign the reference's pairs form a chain (src/poppy.cpp:326: img1 = corrected2.clone(), the ALIGNED image): the pool, which
     hands pairs out concurrently, refuses more than one of them instead of silently rendering a different sequence."""
