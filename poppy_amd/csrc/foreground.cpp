@@ -112,7 +112,8 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     for (int i = 0; i < 12; ++i) {
         uint8_t* med = meds + (size_t)i * P;
         const int ksize = i * 8 + 1;
-        if (ksize <= 1) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy");
+        // medianBlur(ksize 1) is a copy: MOG2 reads the grey image itself unless the caller wants every stage plane
+        if (ksize <= 1) { if (dbg && dbg->stages) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy"); else med = grey; }
         if (ask_device && ksize >= median_cols_min_ksize()) {
             chk(easy_ev ? hipEventSynchronize(easy_ev) : hipStreamSynchronize(s), "sync");
             const MedianColsGeom g = median_cols_geom(w, h);
@@ -140,9 +141,8 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
     launch_mog2_all(inputs, alphaT, prune, kMog2Steps, flows, n, s);
     // 3. fgMask: accumulate the masks, blurring the accumulator after each of the twelve median steps
     const float acc_scale = (float)(1.0 / (12 / 2.0));       // flow * (1.0 / (iterations / 2.0)), iterations = 12
-    chk(hipMemsetAsync(acc[0], 0, P, s), "memset");
-    int cur = 0;                                              // acc[cur] is fgMask
-    launch_acc_flow(acc[cur], flows, n, acc_scale, s);
+    int cur = 0;                                              // acc[cur] is fgMask (Mat::zeros: the first step writes it)
+    launch_acc_flow(acc[cur], flows, n, acc_scale, s, true);
     stage_out(0, flows); stage_out(1, acc[cur]);
     // accumulate + blur: POPPY_ACC_STEPS of the twelve dependent steps per launch (1, 2, 3, 4, 6; 0: the byte-per-thread kernel, one step each)
     static const int acc_steps = getenv("POPPY_ACC_STEPS") ? atoi(getenv("POPPY_ACC_STEPS")) : 3;

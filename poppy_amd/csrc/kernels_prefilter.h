@@ -17,7 +17,7 @@ void launch_bgr2gray(const uint8_t* bgr, size_t stride, uint8_t* gray, int w, in
 constexpr int kMog2Steps = 13;         // Extractor::foreground: one apply on the grey image, twelve on its progressive medians
 // flows: steps planes of n_px mask bytes (0 / 127 / 255); alphaT / prune: per-step learning rate and -rate * 0.05 (CT)
 void launch_mog2_all(const uint8_t* const* imgs, const float* alphaT, const float* prune, int steps, uint8_t* flows, int n_px, hipStream_t s);
-void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scale, hipStream_t s);   // acc += sat(round(flow * scale))
+void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scale, hipStream_t s, bool first = false);   // first: acc counts as zeros and is only written   // acc += sat(round(flow * scale))
 
 // medianBlur(src, dst, ksize) for odd ksize >= 3 on a 1-channel 8-bit image (replicated border, exact median)
 bool prepare_median_u8();               // raises the kernel's LDS limit once; call outside stream capture

@@ -175,12 +175,13 @@ __global__ void __launch_bounds__(256) k_mog2_all(Mog2Inputs in, uint8_t* __rest
 
 // fgMask += flow * scale: convertTo(u8, alpha) rounds to nearest even and saturates, then a saturating add
 // (matrix_expressions.cpp:270-275,1330-1336)
-__global__ void __launch_bounds__(256) k_acc_flow(uint8_t* __restrict__ acc, const uint8_t* __restrict__ flow, int n, float acc_scale) {
+// (first: the accumulator is all zeros — Mat::zeros, src/extractor.cpp — and is written, not read: saves the launch that would clear it)
+__global__ void __launch_bounds__(256) k_acc_flow(uint8_t* __restrict__ acc, const uint8_t* __restrict__ flow, int n, float acc_scale, int first) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     int t = cv_round_x86((float)flow[p] * acc_scale + 0.f);
     t = t < 0 ? 0 : t > 255 ? 255 : t;
-    const int sum = acc[p] + t;
+    const int sum = (first ? 0 : (int)acc[p]) + t;
     acc[p] = (uint8_t)(sum > 255 ? 255 : sum);
 }
 
@@ -189,8 +190,8 @@ void launch_mog2_all(const uint8_t* const* imgs, const float* alphaT, const floa
     for (int i = 0; i < kMog2Steps; ++i) { in.img[i] = imgs[i < steps ? i : 0]; in.alphaT[i] = alphaT[i < steps ? i : 0]; in.prune[i] = prune[i < steps ? i : 0]; }
     hipLaunchKernelGGL(k_mog2_all, dim3((n_px + 255) / 256), dim3(256), 0, s, in, flows, n_px, steps);
 }
-void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scale, hipStream_t s) {
-    hipLaunchKernelGGL(k_acc_flow, dim3((n_px + 255) / 256), dim3(256), 0, s, acc, flow, n_px, acc_scale);
+void launch_acc_flow(uint8_t* acc, const uint8_t* flow, int n_px, float acc_scale, hipStream_t s, bool first) {
+    hipLaunchKernelGGL(k_acc_flow, dim3((n_px + 255) / 256), dim3(256), 0, s, acc, flow, n_px, acc_scale, first ? 1 : 0);
 }
 
 // ---- large-kernel median ---------------------------------------------------------------------------------------------
