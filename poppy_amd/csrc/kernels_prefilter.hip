@@ -435,7 +435,10 @@ void launch_median_padded(const uint8_t* padded_src, uint8_t* dst, uint8_t* padd
 }
 size_t median_padded_bytes(int w, int h) { return (size_t)(w + 2 * kMedPad) * h + 16; }
 int median_cols_min_ksize() {
-    static const int v = getenv("POPPY_MED_COLS_MIN") ? atoi(getenv("POPPY_MED_COLS_MIN")) : 25;      // (below: k_median_u8 is as fast or faster on every content)
+    // every window of the chain since the column kernel needs 34 KB of LDS (four workgroups per compute unit): alone on the GPU k_median_u8 is as fast up to ksize 17
+    // (44 / 47 against 40 / 41 us), beside other chains the column kernel shares the compute units better — 4K set-up 7.95 -> 7.72 ms, a pool step 57.5 -> 56.6 ms
+    // (tools/experiments/median_min_ab.sh); 25 until then
+    static const int v = getenv("POPPY_MED_COLS_MIN") ? atoi(getenv("POPPY_MED_COLS_MIN")) : 9;
     return v;
 }
 int median_cols_min_ksize_hard() {
