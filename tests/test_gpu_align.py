@@ -57,11 +57,14 @@ def test_auto_align_vs_reference(ctx, case):
     G.check(case, "aa_img", img)
 
 
+@pytest.mark.parametrize("serial", [False, True])
 @pytest.mark.parametrize("case", ["a_256x256_align", "a_384x288_align"])
-def test_pair_begin_with_auto_align_reproduces_poppy_morph(case):
-    """poppy::morph with Settings::enable_auto_align from the raw pair: prepared points and every frame, bit for bit."""
+def test_pair_begin_with_auto_align_reproduces_poppy_morph(case, serial):
+    """poppy::morph with Settings::enable_auto_align from the raw pair: prepared points and every frame, bit for bit — with the two images' chains side by side
+    (a context's default) and one after the other (poppy_hip_set_setup_chains: what the contexts of a pool of three or more use)."""
     inp = G.astage_inputs(case)
     c = capi.Context(0, number_of_frames=int(inp["cfg"][0]), enable_auto_align=1)
+    c.set_setup_chains(serial)
     nf, _ = c.pair_begin(inp["img1"], inp["img2"])
     assert nf == int(G.full(case, "detail")[3])
     p1, p2 = c.pair_points()
