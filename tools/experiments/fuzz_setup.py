@@ -6,6 +6,9 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import oracle_lib as O
 from poppy_amd import capi, synth
 
+import os, ctypes as C
+on_device = os.environ.get("FUZZ_DEVICE") == "1"
+hip = C.CDLL("libamdhip64.so") if on_device else None
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0; t0 = time.time()
@@ -26,7 +29,19 @@ for i in range(cases):
         a, b = np.ascontiguousarray(pa[y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(pb[y0:y0 + h, x0:x0 + w])
     c = capi.Context(0, number_of_frames=4)
     try:
-        nf, det = c.pair_begin(a, b)
+        if on_device:                                                      # FUZZ_DEVICE=1: the pair from device memory (poppy_hip_pair_begin_device: the device decides the median kernel per image)
+            ptrs = []
+            for img in (a, b):
+                d = C.c_void_p(); arr = np.ascontiguousarray(img)
+                assert hip.hipMalloc(C.byref(d), C.c_size_t(arr.nbytes)) == 0 and hip.hipMemcpy(d, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), 1) == 0
+                ptrs.append(d)
+            try:
+                c.pair_begin_device(ptrs[0].value, ptrs[1].value, w, h)
+                nf = c.pair_begin_info()[0]
+            finally:
+                for d in ptrs: hip.hipFree(d)
+        else:
+            nf, det = c.pair_begin(a, b)
         p1, p2 = c.pair_points()
         g = c.fetch("gabor2")
     except capi.PoppyError as e:
