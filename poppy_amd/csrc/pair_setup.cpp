@@ -190,12 +190,15 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     c->pair_ready = false;
     c->c2_raw_valid = false;
     const size_t P = (size_t)W * H;
-    static const bool gabor2_first = getenv("POPPY_GABOR2_FIRST") != nullptr;
+    static const bool gabor2_first_env = getenv("POPPY_GABOR2_FIRST") != nullptr;
     // One image's chain after the other on the GPU: a context of a pool of three or more (three set-ups side by side fill the GPU; two chains each would only put
     // six chains on the process's four hardware queues — which layout a pool of three got was a lottery with a 25 % slower outcome in one pool of four, profiles/r05_notes.md
     // section 6), a caller's choice (poppy_hip_set_setup_chains), or POPPY_SETUP_SERIAL
     static const bool serial_env = getenv("POPPY_SETUP_SERIAL") != nullptr;
     const bool serial_chains = serial_env || c->setup_serial;
+    // gabor2 (the second raw image only) at the very start of the set-up, beside the first image's chain: with the chains one after the other the context has one chain in flight
+    // and room beside it (a pool step of six pairs 56.7 -> 56.0 ms); with two chains side by side it tripled the first medians' time (round 3) and waits for them
+    const bool gabor2_first = gabor2_first_env || (serial_chains && getenv("POPPY_GABOR2_LATE") == nullptr);
     // Host images: the second image is uploaded by its own chain's thread on that chain's stream, so the first image's chain — stream-ordered behind its
     // own upload — has the GPU to itself for the length of a copy instead of both waiting for both (POPPY_SETUP_UPLOAD_BOTH=1: the order before round 5)
     static const bool upload_both = getenv("POPPY_SETUP_UPLOAD_BOTH") != nullptr;
