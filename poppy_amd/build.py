@@ -35,7 +35,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, experiments=False):
+    """experiments=True: -DPOPPY_EXPERIMENTS, the build in which the result-changing measurement switches (POPPY_MED_COLS_SKIP, POPPY_GABOR_NO_REDO,
+    POPPY_GABOR_BAND) are read at all; it is written to libpoppy_hip_experiments.so, never to the shipped library's name."""
+    if experiments:
+        return _build_experiments(verbose)
     if not force and not needs_build():
         return OUT
     objs = []
@@ -63,5 +67,25 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def _build_experiments(verbose=True):
+    objdir = os.path.join(HERE, "build", "experiments")
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(HERE, "libpoppy_hip_experiments.so")
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + ["-DPOPPY_EXPERIMENTS"] + PER_FILE_FLAGS.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"])
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--experiments" in sys.argv:
+        print(build(experiments=True))
+    else:
+        build(force="--force" in sys.argv)

@@ -8,7 +8,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libpoppy_hip.so")
+# POPPY_HIP_LIB: another build of the same sources (tools/experiments load libpoppy_hip_experiments.so, `python -m poppy_amd.build --experiments`,
+# the only build in which the result-changing measurement switches exist); tests and bench.py run on the shipped library
+SO_PATH = os.environ.get("POPPY_HIP_LIB") or os.path.join(HERE, "libpoppy_hip.so")
 
 _lib = None
 

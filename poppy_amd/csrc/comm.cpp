@@ -89,7 +89,7 @@ int poppy_hip_comm_init(poppy_hip_ctx* c, int rank, int world, const uint8_t* id
     if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, POPPY_E_ARG, "bad rank / world / id");
     Rccl* r = rccl();
     if (!r->err.empty()) return fail(c, POPPY_E_UNSUPPORTED, r->err.c_str());
-    if (c->comm) return fail(c, POPPY_E_STATE, "this context already has a communicator");
+    if (c->comm.load() || c->comm_aborted.load()) return fail(c, POPPY_E_STATE, "this context already has a communicator (poppy_hip_comm_free first)");
     HIPCHK(c, hipSetDevice(c->device));
     Id128 id;
     memcpy(id.b, id128, 128);
@@ -113,9 +113,10 @@ int poppy_hip_comm_info(poppy_hip_ctx* c, int* rank, int* world, int* nccl_rank,
     if (world) *world = c->comm_world;
     int nr = -1, nc = -1;
     Rccl* r = rccl();
-    if (c->comm && r->handle) {
-        if (r->CommUserRank && r->CommUserRank(c->comm, &nr) != 0) nr = -1;
-        if (r->CommCount && r->CommCount(c->comm, &nc) != 0) nc = -1;
+    void* cm = c->comm.load();
+    if (cm && r->handle) {
+        if (r->CommUserRank && r->CommUserRank(cm, &nr) != 0) nr = -1;
+        if (r->CommCount && r->CommCount(cm, &nc) != 0) nc = -1;
     }
     if (nccl_rank) *nccl_rank = nr;
     if (nccl_count) *nccl_count = nc;
@@ -124,12 +125,13 @@ int poppy_hip_comm_info(poppy_hip_ctx* c, int* rank, int* world, int* nccl_rank,
 
 int poppy_hip_comm_free(poppy_hip_ctx* c) {
     if (!c) return POPPY_E_ARG;
-    if (c->comm) {
+    void* cm = c->comm.exchange(nullptr);                           // (an aborted communicator is gone already: its pointer was taken by the abort)
+    if (cm) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
-        if (!c->comm_aborted.exchange(false)) (void)rccl()->CommDestroy(c->comm);
-        c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+        (void)rccl()->CommDestroy(cm);
     }
+    c->comm_aborted = false; c->comm_rank = 0; c->comm_world = 1;
     return POPPY_OK;
 }
 
@@ -145,7 +147,7 @@ int poppy_hip_pair_state_bytes(int width, int height, size_t* bytes) {
 // error while the others are already blocked inside the broadcast.
 int poppy_hip_pair_broadcast(poppy_hip_ctx* c, int root, int W, int H) {
     if (!c) return POPPY_E_ARG;
-    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+    if (!c->comm.load()) return fail(c, POPPY_E_STATE, c->comm_aborted.load() ? "the communicator was aborted" : "no communicator (poppy_hip_comm_init)");
     if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");   // the same on every rank
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
@@ -163,7 +165,9 @@ int poppy_hip_pair_broadcast(poppy_hip_ctx* c, int root, int W, int H) {
         if (rc != POPPY_OK) return rc;
         if (worst != 0.0) return fail(c, POPPY_E_STATE, "another rank could not take part in the broadcast (its own error says why)");
     } else if (rc != POPPY_OK) return rc;
-    const int nr = rccl()->Broadcast(c->arena, c->arena, c->arena_bytes, kNcclUint8, root, c->comm, c->stream);
+    void* cm = c->comm.load();
+    if (!cm) return fail(c, POPPY_E_STATE, "the communicator was aborted");
+    const int nr = rccl()->Broadcast(c->arena, c->arena, c->arena_bytes, kNcclUint8, root, cm, c->stream);
     if (nr != 0) return rccl_fail(c, "ncclBroadcast", nr);
     if (c->comm_rank != root) return adopt_pair_state(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -178,9 +182,11 @@ static int comm_max_n(poppy_hip_ctx* c, double* values, int n) {
     // returns its error afterwards), so that no rank is left alone inside ncclAllReduce
     if (!c->d_comm_scratch) return fail(c, POPPY_E_STATE, "communicator without its scratch (poppy_hip_comm_init allocates it)");
     double* d = c->d_comm_scratch;
+    void* cm = c->comm.load();                                      // once: the abort path may take it away at any moment
+    if (!cm) return fail(c, POPPY_E_STATE, "the communicator was aborted");   // (nobody is waiting for this rank in an aborted job)
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-    const int nr = rccl()->AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclMax, c->comm, c->stream);   // entered whatever `e` says: see above
+    const int nr = rccl()->AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclMax, cm, c->stream);   // entered whatever `e` says: see above
     if (e == hipSuccess && nr == 0) e = hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (nr != 0) return rccl_fail(c, "ncclAllReduce", nr);
@@ -189,7 +195,7 @@ static int comm_max_n(poppy_hip_ctx* c, double* values, int n) {
 }
 int poppy_hip_comm_max(poppy_hip_ctx* c, double* value) {
     if (!c || !value) return POPPY_E_ARG;
-    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+    if (!c->comm.load()) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
     return comm_max_n(c, value, 1);
 }
 
@@ -425,7 +431,7 @@ unsigned long long poppy_hip_sharded_setups(void) { return g_sharded_setups.load
 
 int poppy_hip_pair_begin_sharded(poppy_hip_ctx* c, const void* d1, const void* d2, int W, int H, int root) {
     if (!c) return POPPY_E_ARG;
-    if (!c->comm) return fail(c, POPPY_E_STATE, "no communicator (poppy_hip_comm_init)");
+    if (!c->comm.load()) return fail(c, POPPY_E_STATE, c->comm_aborted.load() ? "the communicator was aborted" : "no communicator (poppy_hip_comm_init)");
     if (root < 0 || root >= c->comm_world || W <= 0 || H <= 0) return fail(c, POPPY_E_ARG, "bad root / geometry");
     // a world of one needs no exchange — unless POPPY_HIP_SHARD_WORLD1 asks for the protocol anyway: all three roles on this rank, every
     // broadcast and reduction a real RCCL call on the one-rank communicator (what a box with a single GPU can run of the multi-rank path)
@@ -434,7 +440,9 @@ int poppy_hip_pair_begin_sharded(poppy_hip_ctx* c, const void* d1, const void* d
     Transport T;
     T.rank = c->comm_rank; T.world = c->comm_world;
     T.bcast = [](poppy_hip_ctx* cc, void* buf, size_t bytes, int r) -> int {
-        const int nr = rccl()->Broadcast(buf, buf, bytes, kNcclUint8, r, cc->comm, cc->stream);
+        void* cm = cc->comm.load();
+        if (!cm) return fail(cc, POPPY_E_STATE, "the communicator was aborted");
+        const int nr = rccl()->Broadcast(buf, buf, bytes, kNcclUint8, r, cm, cc->stream);
         if (nr != 0) return rccl_fail(cc, "ncclBroadcast", nr);
         if (hipStreamSynchronize(cc->stream) != hipSuccess) return fail(cc, POPPY_E_DEVICE, "broadcast");
         return POPPY_OK;
@@ -551,9 +559,14 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
         std::call_once(abort_once, [&]() {
             Rccl* r = rccl();
             if (n_devices > 1 && r->CommAbort)
-                // (the communicator pointers stay where they are — the device threads read c->comm without a lock, and an aborted communicator
-                // fails their collectives —; the flag tells poppy_hip_comm_free that the abort already released it)
-                for (int k = 0; k < n_devices; ++k) if (ctx[k]->comm && !ctx[k]->comm_aborted.exchange(true)) (void)r->CommAbort(ctx[k]->comm);
+                // (ncclCommAbort FREES the communicator: the pointer is taken out of the context first, so a device thread that enters a collective
+                // later finds null and fails with POPPY_E_STATE instead of handing RCCL a freed handle; one that is inside a collective already
+                // is what ncclCommAbort exists to unblock; the flag keeps the context from being given a new communicator before comm_free)
+                for (int k = 0; k < n_devices; ++k) {
+                    ctx[k]->comm_aborted = true;
+                    void* cm = ctx[k]->comm.exchange(nullptr);
+                    if (cm) (void)r->CommAbort(cm);
+                }
         });
     };
     std::atomic<int> past_setup{0};

@@ -98,6 +98,7 @@ struct poppy_hip_ctx {
     ForegroundFilter foreground, foreground_b;      // two instances: the images of a pair are filtered side by side
     hipStream_t aux_stream = nullptr;
     hipEvent_t setup_ev = nullptr;                  // "the second image's medians are through" (pair set-up: gabor2 starts there)
+    hipEvent_t c2_up_ev = nullptr;                  // "the second host image is in c2" (recorded on aux_stream by the second chain's thread; gabor2 on copy_stream waits for it)
     double initial_morph_dist = 0;
     int last_nfeatures = 0;
     AutoAligner aligner;
@@ -107,8 +108,10 @@ struct poppy_hip_ctx {
     struct LastWarp { const float* rec = nullptr; const void* tile_data = nullptr; size_t tile_bytes = 0; const int* toff = nullptr; int tile_w = 0;
                       const uint8_t* c1 = nullptr; const uint8_t* c2 = nullptr; uint8_t* tr1 = nullptr; uint8_t* tr2 = nullptr; WarpExtras ex; bool valid = false; } last_warp;
     int last_descriptor_matches = 0;               // symmetric matches kept by the last pair_begin_descriptors
-    void* comm = nullptr; int comm_rank = 0, comm_world = 1;        // RCCL communicator of this context (comm.cpp), or null
-    std::atomic<bool> comm_aborted{false};                          // ncclCommAbort ran on it (and freed it): poppy_hip_comm_free only forgets the pointer
+    // RCCL communicator of this context (comm.cpp), or null.  Atomic: morph_sharded's abort path takes the pointer AWAY (exchange to null) before
+    // ncclCommAbort frees the communicator, and every collective wrapper loads it once — a late entrant finds null (POPPY_E_STATE), never a freed handle
+    std::atomic<void*> comm{nullptr}; int comm_rank = 0, comm_world = 1;
+    std::atomic<bool> comm_aborted{false};                          // the communicator was aborted under this context: its collectives fail with POPPY_E_STATE until poppy_hip_comm_free
     double* d_comm_scratch = nullptr;                               // 8 doubles for the small reductions (comm.cpp), allocated on first use
     unsigned warp_seq = 0;                      // warp launches issued in timing mode 2 (every kWarpStampStride-th is stamped)
     bool last_warp_fast = false;                   // which warp kernel the last submitted frame used

@@ -35,7 +35,7 @@ public:
     int detail_begin(const uint8_t* d_gf, int w, int h, hipStream_t s);      // the same in two halves: everything queued, no host round trip ...
     int detail_end(double* out);                                             // ... and the value, once the stream has passed it
     const uint8_t* orb_input(const uint8_t* d_gf, int w, int h, int which, hipStream_t s, float* h_us = nullptr, float* h_gb = nullptr);
-    const float* gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s);
+    const float* gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s, std::string* err_out = nullptr);
     uint8_t* bgr_staging() { return d_bgr; }
     // medianBlur(src, ksize) on a host image by one of the two kernels (diagnostics / tests): form 1 = a lane per column (k_median_u8), 2 = column
     // histograms with the presence map, 3 = column histograms, every tile on all 256 values, 4 = with the map but no tile on 64 ranks; 0 = what the chain

@@ -236,12 +236,16 @@ const uint8_t* ForegroundFilter::orb_input(const uint8_t* d_gf, int w, int h, in
 }
 
 // gabor_filter(corrected2 / 255) with the default arguments: 3-channel float field (device in u8 BGR packed, device out f32x3)
-const float* ForegroundFilter::gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s) {
-    if (ensure(w, h) || ensure2(w, h)) return nullptr;
+// err_out: a caller on a SECOND thread (the pair set-up queues gabor2 from the first image's thread while the second image's thread uses this object's
+// chain) passes its own string; the buffers must then be in place already (prepare / prepare2) and no member is written.
+const float* ForegroundFilter::gabor_field(const uint8_t* d_bgr_packed, int w, int h, hipStream_t s, std::string* err_out) {
+    if (err_out) {
+        if (w != W || h != H || w != W2 || h != H2) { *err_out = "gabor_field: buffers not prepared for this size"; return nullptr; }
+    } else if (ensure(w, h) || ensure2(w, h)) return nullptr;
     launch_u8_to_f32(d_bgr_packed, c3_in, w * h * 3, s);
     if (fft13 && !gabor_direct) launch_gabor_fft13_c3(c3_in, fft13, bank13, doubt_list13, c3_out, w, h, s);
     else launch_gabor_bank13_c3(c3_in, bank13, c3_out, w, h, s);
-    if (hipGetLastError() != hipSuccess) { err = "gabor_field launch failed"; return nullptr; }
+    if (hipGetLastError() != hipSuccess) { (err_out ? *err_out : err) = "gabor_field launch failed"; return nullptr; }
     return c3_out;
 }
 

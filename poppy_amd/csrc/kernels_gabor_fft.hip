@@ -341,11 +341,11 @@ bool gabor_fft_prepare() {                                     // the twiddle ta
 }
 
 // POPPY_GABOR_NO_REDO (measurement aid): the transform alone, as until round 4 — a plane value in ~1e8 then lands on the other neighbouring float
-static bool gabor_redo_on() { static const bool on = getenv("POPPY_GABOR_NO_REDO") == nullptr; return on; }
+static bool gabor_redo_on() { static const bool on = poppy_experiment_env("POPPY_GABOR_NO_REDO") == nullptr; return on; }
 // The width of the doubt band in units of max(1, the patch's largest magnitude): 1e-13 = ten times the largest distance between the two forms
 // measured on ~1e5 plane values (1.1e-14).  The equality of the forms rests on that measurement, not on a proof: POPPY_GABOR_BAND widens the
 // band for checks (1e30: every pixel is re-formed as direct sums — a fuzz run under it and one without must agree in every bit).
-static double gabor_band_unit() { static const double v = getenv("POPPY_GABOR_BAND") ? atof(getenv("POPPY_GABOR_BAND")) : 1e-13; return v; }
+static double gabor_band_unit() { static const double v = poppy_experiment_env("POPPY_GABOR_BAND") ? atof(poppy_experiment_env("POPPY_GABOR_BAND")) : 1e-13; return v; }
 
 // list: 2 + w * h * channels words, device (this launch resets and fills it; k_gabor_redo reads it)
 void launch_gabor_fft31(const float* src, const double* d_tables, const double* d_bank, unsigned* d_list, float* dst, int w, int h, hipStream_t s) {

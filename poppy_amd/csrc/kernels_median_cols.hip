@@ -440,7 +440,7 @@ int median_cols_hint_from_host(const uint8_t* bgr, size_t stride, int w, int h) 
 void launch_median_cols(const uint8_t* padded_src, uint8_t* dst, uint8_t* padded_next, int w, int h, int ksize, const uint32_t* pres_in, uint32_t* pres_out,
                         int force, hipStream_t s) {
     const MedianColsGeom g = median_cols_geom(w, h);
-    static const int dbg = getenv("POPPY_MED_COLS_SKIP") ? atoi(getenv("POPPY_MED_COLS_SKIP")) : 0;    // timing experiments: parts left out (wrong results)
+    static const int dbg = poppy_experiment_env("POPPY_MED_COLS_SKIP") ? atoi(poppy_experiment_env("POPPY_MED_COLS_SKIP")) : 0;    // timing experiments: parts left out (wrong results)
     hipLaunchKernelGGL(k_median_cols, dim3(g.tiles_x, g.tiles_y), dim3(kMcWaves * 64), 0, s, padded_src, dst, padded_next, w, h, ksize, g.rows, pres_in,
                        pres_out, force, dbg);
 }

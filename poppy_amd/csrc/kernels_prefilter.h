@@ -5,6 +5,19 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+
+// Switches that can change a RESULT BIT (parts of a kernel left out for timing, the Gabor transform without its exactness hand-over) exist only
+// in a build made with -DPOPPY_EXPERIMENTS (python -m poppy_amd.build --experiments): the shipped library ignores these variables, so a stray
+// environment variable on a user's box cannot break parity.  The tuning variables read with plain getenv never change a result (include/poppy_hip.h lists them).
+inline const char* poppy_experiment_env(const char* name) {
+#ifdef POPPY_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 namespace poppy_hip {
 

@@ -233,14 +233,17 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     // gabor2 depends on the second image alone, not on its chain (and has its own buffers): it goes to the plan-upload stream — idle during a
     // set-up — and starts when the second image's medians are through, beside the strings of small dependent launches that follow them (at
     // the very start it ran beside the first medians, one wave per histogram set, and tripled their time; POPPY_GABOR2_FIRST: that order)
-    auto gabor2_on_side_stream = [&]() -> bool {
-        const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream);
-        if (!gab) { c->err = "gabor_field: " + c->foreground_b.err; return false; }
-        if (hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->copy_stream) != hipSuccess) { c->err = "gabor2 copy failed"; return false; }
+    // (errors go to the CALLING thread's string: with gabor2_late the first image's thread queues this while the second image's thread is inside foreground_b)
+    auto gabor2_on_side_stream = [&](std::string& e, bool other_thread_in_fg_b) -> bool {
+        std::string ge;
+        const float* gab = c->foreground_b.gabor_field(c->c2, W, H, c->copy_stream, other_thread_in_fg_b ? &ge : nullptr);
+        if (!gab) { e = "gabor_field: " + (other_thread_in_fg_b ? ge : c->foreground_b.err); return false; }
+        if (hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->copy_stream) != hipSuccess) { e = "gabor2 copy failed"; return false; }
         return true;
     };
-    if (!align_first && gabor2_first && !gabor2_on_side_stream()) return POPPY_E_DEVICE;
+    if (!align_first && gabor2_first && !gabor2_on_side_stream(c->err, false)) return POPPY_E_DEVICE;
     if (!c->setup_ev) HIPCHK(c, hipEventCreateWithFlags(&c->setup_ev, hipEventDisableTiming));
+    if (!c->c2_up_ev) HIPCHK(c, hipEventCreateWithFlags(&c->c2_up_ev, hipEventDisableTiming));
     // POPPY_GABOR2_AT: where gabor2 starts — 0 behind the second image's medians, 1 / 2 behind the FIRST image's ORB input / FAST kernels (queued by that
     // image's thread): the first image's chain is through earlier than the second's, gabor2 then fills the GPU beside the second chain's tail of small launches
     static const int gabor2_at = getenv("POPPY_GABOR2_AT") ? atoi(getenv("POPPY_GABOR2_AT")) : 2;      // (1080p 3.03 -> 2.96 ms, 4K 8.5 -> 8.1: tools/experiments/gabor2_at_ab.sh)
@@ -255,6 +258,11 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         void add() { { std::lock_guard<std::mutex> g(m); ++n; } cv.notify_all(); }
         void wait_for(int k) { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return n >= k; }); }
     } details;
+    // The staged upload of the second image happens on the second chain's thread and stream; gabor2 reads c2 on copy_stream, queued by the FIRST chain's
+    // thread: that thread waits (host) until the upload has been QUEUED and its event recorded, then makes copy_stream wait for the event (device).
+    // 0 = not yet, 1 = event recorded, -1 = the upload failed (round 5 had no such edge: gabor2 could read a half-written c2 when the helper thread was late)
+    Details c2_uploaded;
+    std::atomic<int> c2_upload_state{staged ? 0 : 1};
     std::vector<OrbKeyPoint> k1, k2;
     int nfeatures = 0;
     struct Publish {                                                      // counts once, at the detail or at whichever exit comes before it
@@ -268,18 +276,25 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     }
     auto chain_of = [&](int i) {
         Publish publish{details};
+        struct UploadKnown {                                      // whichever way the second chain leaves, the first is not left waiting for its upload
+            Details& d; std::atomic<int>& state; bool mine;
+            ~UploadKnown() { if (mine && state.load() == 0) { state = -1; d.add(); } }
+        } upload_known{c2_uploaded, c2_upload_state, i == 1 && staged};
         if (hipSetDevice(c->device) != hipSuccess) { errs[i] = "hipSetDevice failed"; rcs[i] = POPPY_E_DEVICE; return; }
         ForegroundFilter& fg = i ? c->foreground_b : c->foreground;
         hipStream_t st = i ? c->aux_stream : c->stream;
-        if (i == 1 && staged && copy_rows_async(c->c2, (size_t)W * 3, bgr2, s2, (size_t)W * 3, H, hipMemcpyHostToDevice, st) != hipSuccess) {
-            errs[i] = "pair_begin: upload of the second image failed"; rcs[i] = POPPY_E_DEVICE; return;
+        if (i == 1 && staged) {
+            const bool ok = copy_rows_async(c->c2, (size_t)W * 3, bgr2, s2, (size_t)W * 3, H, hipMemcpyHostToDevice, st) == hipSuccess &&
+                            hipEventRecord(c->c2_up_ev, st) == hipSuccess;
+            c2_upload_state = ok ? 1 : -1;
+            c2_uploaded.add();
+            if (!ok) { errs[i] = "pair_begin: upload of the second image failed"; rcs[i] = POPPY_E_DEVICE; return; }
         }
         const uint8_t* gf = fg.run_device(i ? c->c2 : c->c1, (size_t)W * 3, W, H, st, nullptr);
         if (!gf) { errs[i] = "foreground: " + fg.err; rcs[i] = POPPY_E_DEVICE; return; }
         if (i == 1 && fg.medians_done) {                          // gabor2 starts when the second image's medians are through (queued now, long before)
-            if (hipStreamWaitEvent(c->copy_stream, fg.medians_done, 0) != hipSuccess || !gabor2_on_side_stream()) {
-                errs[i] = c->err.empty() ? "gabor2: stream wait failed" : c->err; rcs[i] = POPPY_E_DEVICE; return;
-            }
+            if (hipStreamWaitEvent(c->copy_stream, fg.medians_done, 0) != hipSuccess) { errs[i] = "gabor2: stream wait failed"; rcs[i] = POPPY_E_DEVICE; return; }
+            if (!gabor2_on_side_stream(errs[i], false)) { rcs[i] = POPPY_E_DEVICE; return; }
         }
         // dft_detail2 and the ORB input both read goodFeatures: the ORB input's kernels are queued behind dft_detail2's before the host waits for the detail value
         // (until round 4 the chain's stream ran dry twice in mid-chain, at the two read-backs of dft_detail2)
@@ -290,9 +305,15 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         publish.now();
         g_dev[i] = gi;                                            // the detector reads it where it lies; only ORB::compute wants a host copy
         auto gabor2_behind_this_chain = [&]() {
-            if (hipEventRecord(c->setup_ev, st) != hipSuccess || hipStreamWaitEvent(c->copy_stream, c->setup_ev, 0) != hipSuccess || !gabor2_on_side_stream()) {
-                errs[i] = c->err.empty() ? "gabor2: stream wait failed" : c->err; rcs[i] = POPPY_E_DEVICE; return false;
+            if (staged) {                                         // c2 is written on the other chain's stream: order copy_stream behind that copy
+                c2_uploaded.wait_for(1);
+                if (c2_upload_state.load() < 0) return false;     // (the other chain reports the error)
+                if (hipStreamWaitEvent(c->copy_stream, c->c2_up_ev, 0) != hipSuccess) { errs[i] = "gabor2: stream wait failed"; rcs[i] = POPPY_E_DEVICE; return false; }
             }
+            if (hipEventRecord(c->setup_ev, st) != hipSuccess || hipStreamWaitEvent(c->copy_stream, c->setup_ev, 0) != hipSuccess) {
+                errs[i] = "gabor2: stream wait failed"; rcs[i] = POPPY_E_DEVICE; return false;
+            }
+            if (!gabor2_on_side_stream(errs[i], true)) { rcs[i] = POPPY_E_DEVICE; return false; }
             return true;
         };
         if (i == 0 && gabor2_late == 1 && !gabor2_behind_this_chain()) return;

@@ -121,6 +121,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); c->dl_stream = nullptr; }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->setup_ev) (void)hipEventDestroy(c->setup_ev);
+    if (c->c2_up_ev) (void)hipEventDestroy(c->c2_up_ev);
     for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
     (void)hipStreamSynchronize(c->copy_stream);

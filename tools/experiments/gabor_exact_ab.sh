@@ -3,6 +3,6 @@ cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for k in synthetic photo textured; do
   a=$(python3 tools/experiments/setup_content.py $k 1920 1080 25 2>&1 | tail -1)
-  b=$(POPPY_GABOR_NO_REDO=1 python3 tools/experiments/setup_content.py $k 1920 1080 25 2>&1 | tail -1)
+  b=$(POPPY_HIP_LIB=$PWD/poppy_amd/libpoppy_hip_experiments.so POPPY_GABOR_NO_REDO=1 python3 tools/experiments/setup_content.py $k 1920 1080 25 2>&1 | tail -1)
   echo "with redo:    $a"; echo "without redo: $b"
 done; done
