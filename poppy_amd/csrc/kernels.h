@@ -119,6 +119,17 @@ void launch_collapse2(const float* gL, const float* gR, const float* gM, const f
                       const float* nL, const float* nR, const float* nB, float* outB,
                       int w, int h, int w1, int h1, int w2, int h2, hipStream_t s);
 
+// The way up through SEVERAL small levels in one launch (kernels_pyramid_cone.hip, round 6): blended level `levels[0]` from the blended level
+// `levels[n]` (the tail kernel's, or mix_top's), 2 <= n <= kConeMaxLevels; the blended levels in between exist in LDS only, rebuilt by every
+// workgroup for the cone under its own 64 x 16 tile.  All four pyramid buffers are addressed through the levels' offsets and pitches.
+constexpr int kConeMaxLevels = 6;
+constexpr size_t kConeMaxPixels = 600000;          // output level: 960 x 540 and below (level 1 at 1080p, level 2 at 4K)
+constexpr int kConeTileX = 64, kConeTileY = 16;
+struct ConeLevel { int w, h, pitch; unsigned off3, off1; };
+struct ConeArgs { int n; ConeLevel lv[kConeMaxLevels + 1]; };
+bool collapse_cone_eligible(const PyrLevel* levels, int n);
+void launch_collapse_cone(const float* pyrL, const float* pyrR, const float* pyrM, float* pyrB, const PyrLevel* levels, int n, hipStream_t s);
+
 // blended smallest level = L*m + R*(1-m), for pyramids whose coarsest level does not fit the tail kernel's LDS
 void launch_mix_top(const float* l, const float* r, const float* m, float* out, int n_px, hipStream_t s);
 

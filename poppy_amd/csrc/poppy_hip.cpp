@@ -543,7 +543,20 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
     else launch_mix_top(f.pyrL + c->levels[L].off3, f.pyrR + c->levels[L].off3, f.pyrM + c->levels[L].off1, f.pyrB + c->levels[L].off3,
                         c->levels[L].w * c->levels[L].h, s);
     if (tm) tm->mark("pyr_tail");
-    for (int j = ft; j > 0;) {                     // blended level j is known; produce level j-2 or j-1
+    // The way up: the small levels in ONE launch (round 6, kernels_pyramid_cone.hip): from the tail's level to the largest level of at most kConeMaxPixels
+    // (level 1 at 1080p, level 2 at 4K).  POPPY_HIP_NOCONE: the launches of round 5 (k_collapse2 pairs + one k_collapse_level per remaining level).
+    static const bool cone = getenv("POPPY_HIP_NOCONE") == nullptr;
+    int j_top = ft;
+    if (fuse && cone) {
+        int k = 1;
+        while (k < ft && (size_t)c->levels[k].w * c->levels[k].h > kConeMaxPixels) ++k;
+        if (ft - k > kConeMaxLevels) k = ft - kConeMaxLevels;
+        if (ft - k >= 2 && collapse_cone_eligible(&c->levels[k], ft - k)) {
+            launch_collapse_cone(f.pyrL, f.pyrR, f.pyrM, f.pyrB, &c->levels[k], ft - k, s);
+            j_top = k;
+        }
+    }
+    for (int j = j_top; j > 0;) {                  // blended level j is known; produce level j-2 or j-1
         if (fuse && j - 2 >= 1) {
             const PyrLevel &a = c->levels[j - 2], &m = c->levels[j - 1], &n = c->levels[j];
             if (a.pitch == a.w && m.pitch == m.w && collapse2_eligible(a.w, a.h, m.w, m.h, n.w, n.h)) {
