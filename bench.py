@@ -67,30 +67,34 @@ def synth_pair(w, h, k):
 
 
 def measured_traffic(kernel, w, h):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r05_warp_pmc.json) — only when those passes were
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r06_warp_pmc.json) — only when those passes were
     taken from the kernel sources that are being run (hash of the source files recorded with them); otherwise None."""
     import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r06_warp_pmc.json")))
         hsh = hashlib.sha256()
         for f in ("kernels_warp_bin.hip", "warp_fast_device.h", "warp_device.h"):
             hsh.update(open(os.path.join(ROOT, "poppy_amd", "csrc", f), "rb").read())
         if hsh.hexdigest()[:16] != pm.get("kernel_src_sha16"):
-            return None, "profiles/r05_warp_pmc.json was taken from other kernel sources: not quoted"
+            return None, "profiles/r06_warp_pmc.json was taken from other kernel sources: not quoted"
         e = pm.get(f"{w}x{h}", {}).get(kernel)
         if not e:
-            return None, "no counter pass for this kernel / size in profiles/r05_warp_pmc.json"
-        return e["fetch_bytes"] + e["write_bytes"], "profiles/r05_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; profiles/r05_z_pmc.md)"
+            return None, "no counter pass for this kernel / size in profiles/r06_warp_pmc.json"
+        return e["fetch_bytes"] + e["write_bytes"], ("profiles/r06_warp_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, same kernel sources; "
+                                                     "profiles/r06_z_pmc.md; run id %s)" % pm.get("run_id"))
     except (OSError, ValueError, KeyError):
-        return None, "profiles/r05_warp_pmc.json missing"
+        return None, "profiles/r06_warp_pmc.json missing"
 
 
 def profile_facts(kernel, w, h):
-    """What the committed profiles say about `kernel` at this size (profiles/r05_warp_facts.json, written by tools/warp_facts.py from the
+    """What the committed profiles say about `kernel` at this size (profiles/r06_warp_facts.json, written by tools/warp_facts.py from the
     round's rocprofv3 kernel trace and from the kernel's ISA): the trace's average duration and the kernel's vector-issue bound."""
     try:
-        f = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_facts.json")))
-        return f.get(f"{w}x{h}", {}).get(kernel)
+        f = json.load(open(os.path.join(ROOT, "profiles", "r06_warp_facts.json")))
+        e = f.get(f"{w}x{h}", {}).get(kernel)
+        if e is not None:
+            e = dict(e, run_id=f.get("run_id"))          # tools/profile_round.sh: the one gpurun call trace, counters and (when it is that call) this line come from
+        return e
     except (OSError, ValueError):
         return None
 
@@ -117,7 +121,7 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
             ach_p = contract / (facts["trace_avg_us"] * 1e-6) / 1e9
             out["from_profiles"] = {"avg_launch_us": facts["trace_avg_us"], "achieved": round(ach_p, 1), "frac": round(ach_p / HBM_PEAK_GBS, 4),
                                     "moved_frac": round(12.0 * P / (facts["trace_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "source": facts.get("trace_source")}
+                                    "source": facts.get("trace_source"), "run_id": facts.get("run_id")}
         if facts.get("issue_cycles_per_wave"):
             waves = (w // 4) * h / 64.0
             clk = facts.get("clock_GHz", 2.4)
@@ -130,12 +134,17 @@ def roofline_of(ctx, warp_ms, warp_n, w, h):
                            # the kernel's arithmetic run ALONE on register data (tools/micro/warp_alu.hip, profiles/r04_warp_alu.txt) and what deleting pieces of
                            # TODAY'S kernel does to its time in the chained loop (tools/experiments/abl_build.sh + abl_run.sh, profiles/r05_warp_ablation.txt)
                            "alu_floor_us": {"1920x1080": 7.7, "3840x2160": 30.5}.get(f"{w}x{h}"),
-                           "ablation_4k_us": {"as_shipped": 45.8, "no_division": 46.8, "constant_weights": 46.3, "no_blend": 43.9, "no_footprint_loads": 41.4, "all_four": 30.2,
-                                              "reading": "no single deletion moves the kernel by more than 10 % (the division: +2 %), all four together by a third: it is not bound by "
-                                                         "instruction issue — the arithmetic-only 30.5 us is not its floor — but by its workgroups' turnover (ids + record slots -> barrier -> "
-                                                         "taps -> gathers -> stores: 30 us of it remain with no arithmetic and no gather at all); DESIGN.md section 4"}}
+                           "ablation_4k_us": {"as_shipped": 45.8, "no_division": 46.8, "constant_weights": 46.3, "no_blend": 43.9, "no_footprint_loads": 41.4, "all_four": 30.2},
+                           # round 6 (tools/micro/warp_skeleton2.hip, profiles/r06_warp_skeleton.txt): the kernel's SKELETON alone — id bytes, record slots through LDS + barrier,
+                           # five 16-byte record reads per pixel, two 12-byte stores per four pixels, nothing else — in today's geometry and in eleven others
+                           "skeleton_alone_us": {"3840x2160": {"as_shipped_256x4": 16.6, "best_found_256x16": 13.0, "stores_only": 13.3, "three_dword_stores": 21.0, "scalar_records": 23.2},
+                                                 "1920x1080": {"as_shipped_256x4": 4.7, "best_found": 4.7, "stores_only": 4.0},
+                                                 "reading": "the skeleton is not the defect: alone it moves its 9.5 B/px at 4.75 TB/s (16.6 us at 4K, 4.7 at 1080p); what the all-four "
+                                                            "ablation still held was arithmetic (rounding, clamps, tap addresses).  The kernel's time is its arithmetic (30.5 us alone at 4K) "
+                                                            "plus the memory time the co-resident waves of a round, in lock step, do not hide; at 1080p — one round — a wave priority per "
+                                                            "workgroup takes them out of step: 17.6 -> 14.6 us (pyramid_device.h: stagger_priority); at 4K, four rounds, nothing; DESIGN.md section 4"}}
     try:        # the frame's other full-resolution kernels, from the same committed trace: duration, algorithmic bytes (DESIGN.md's kernel table), fraction of 8 TB/s
-        allf = json.load(open(os.path.join(ROOT, "profiles", "r05_warp_facts.json"))).get(f"{w}x{h}", {})
+        allf = json.load(open(os.path.join(ROOT, "profiles", "r06_warp_facts.json"))).get(f"{w}x{h}", {})
         others = {v["kernel"]: {k2: v[k2] for k2 in ("what", "algo_bytes_per_px", "trace_avg_us", "achieved_GBps", "frac_of_8_TBps")}
                   for k, v in allf.items() if k != "k_warp_bin" and "kernel" in v}
         if others:
@@ -571,6 +580,9 @@ def bench_single(args, torch, capi, dev, local):
         "dtype": "u8+f32",
         "dtype_note": "u8 pixels and fixed-point remap, f32 pyramid and unsharp, f64 Gabor sums; bit-compatible with the reference (no FMA contraction)",
         "data": "synthetic (integer-defined shapes pairs, seeds 1234+k: poppy_amd/synth.py); point sets and mask field come from the real pair set-up",
+        "run": {"hostname": __import__("socket").gethostname(), "run_id": os.environ.get("POPPY_RUN_ID"),
+                "note": "run_id is set by tools/profile_round.sh: the one gpurun call that wrote profiles/<tag>_trace.md, _pmc.md and the <round>_warp_*.json this line quotes "
+                        "(null: a bench run outside that script — then roofline.from_profiles quotes the committed profiles of another run, its own run_id says which)"},
         "config": {"workload": f"{W}x{H} pairs, {FRAMES}-frame morph each, default chained mode (BASELINE.json configs[1]): per step {PAIRS} pairs x "
                                "(pair set-up from the raw images + 60 chained frames handed to a writer through pinned host memory), pyramid_levels 64",
                    "pairs_per_step": PAIRS, "contexts": args.contexts, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
@@ -662,6 +674,26 @@ def bench_single(args, torch, capi, dev, local):
                                    "fps": round(r480 * TOTAL / dt480, 1), "ms_per_job": round(dt480 / r480 * 1e3, 3), "jobs_timed": r480,
                                    "serial_part_ms": out["pair_setup_ms"],
                                    "amdahl_note": "with the set-up serial, N GPUs cannot beat (set-up + frames) / (set-up + frames / N)"}
+    if not args.headline_only:
+        # parity of THAT job (outside every timed region): the whole job once more through a capturing writer; its middle frame against the oracle's
+        # frame from the same pair state, frame 0 against image 1 (the phase == 0 copy, src/poppy.hpp:54-70)
+        import oracle_lib as O
+        mid = TOTAL // 2
+        kept, k480 = {}, [0]
+
+        def keep480(f):
+            if k480[0] in (0, mid):
+                kept[k480[0]] = f.copy()
+            k480[0] += 1
+        ctx.pair_begin_device(ta.data_ptr(), tb.data_ptr(), W, H)
+        ctx.render_phases(ph480, write=keep480)
+        a0_h, b0_h = ta.cpu().numpy().reshape(H, W, 3), tb.cpu().numpy().reshape(H, W, 3)
+        p1_, p2_ = ctx.pair_points()
+        want, _ = O.morph_images(a0_h, b0_h, ctx.fetch("gabor2"), p1_, p2_, float(ph480[mid]), float(ph480[mid]), 64)
+        out["scaling_baseline_480"]["parity_check"] = {
+            "frames_written": k480[0], "frame0_is_image1": bool(np.array_equal(kept.get(0), a0_h)),
+            "frame": mid, "equal": bool(np.array_equal(kept.get(mid), want)),
+            "what": f"frame {mid} (t = {float(ph480[mid])}) of the {TOTAL}-frame job as handed to a writer vs the oracle's phase-mode frame from the same pair state"}
     out["scaling_baseline_480"]["predicted_speedup"] = predicted_speedups(dt480 / r480 * 1e3, out["pair_setup_ms"], capi.pair_state_bytes(W, H))
     # the headline step once more with the raw pairs copied from pinned host memory inside the step (the reference's morph() takes host images)
     pinned = [(torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory()) for a, b in pairs_host]

@@ -295,8 +295,9 @@ def pair_state_bytes(w, h):
     return n.value
 
 
-def morph_sharded(devices, bgr1, bgr2, total_frames, collect=True, **settings):
-    """One total_frames-frame phase-mode morph across `devices` (one process, one thread per GPU): list of frames by index."""
+def morph_sharded(devices, bgr1, bgr2, total_frames, collect=True, reduce=None, **settings):
+    """One total_frames-frame phase-mode morph across `devices` (one process, one thread per GPU): list of frames by index.
+    reduce(index, frame_view) -> what is kept instead of a copy of the frame (a digest, None ...): a 480-frame 1080p job is 3 GB of frames."""
     a = np.ascontiguousarray(bgr1, np.uint8); b = np.ascontiguousarray(bgr2, np.uint8)
     h, w = a.shape[:2]
     s = PoppySettings(); lib().poppy_settings_default(C.byref(s))
@@ -307,7 +308,8 @@ def morph_sharded(devices, bgr1, bgr2, total_frames, collect=True, **settings):
     lock = threading.Lock()
 
     def cb(user, idx, ptr, ww, hh, stride):
-        f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy()
+        f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3)
+        f = reduce(idx, f) if reduce else f.copy()
         with lock:
             frames[idx] = f
     fn = WRITE_INDEXED_CB(cb) if collect else None
@@ -320,7 +322,7 @@ def morph_sharded(devices, bgr1, bgr2, total_frames, collect=True, **settings):
     return [frames[j] for j in sorted(frames)]
 
 
-def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True, **settings):
+def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True, reduce=None, **settings):
     """`pairs` = list of (bgr1, bgr2): every pair one whole poppy::morph, spread over the devices.  Returns {pair: [frames]}
     (or the number of frames written when collect is False)."""
     pairs = [(np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)) for a, b in pairs]
@@ -340,7 +342,8 @@ def morph_pairs(devices, pairs, contexts_per_device=2, phase=-1.0, collect=True,
 
     def wr(user, p, j, ptr, ww, hh, stride):
         if collect:
-            f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3).copy()
+            f = np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3)
+            f = reduce(p, j, f) if reduce else f.copy()      # reduce(pair, index, frame_view) -> what is kept instead of a copy
             with lock:
                 out.setdefault(p, {})[j] = f
         else:

@@ -26,6 +26,9 @@ inline hipError_t copy_rows_async(void* dst, size_t dpitch, const void* src, siz
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
 }
 
+// Wave-priority stagger (pyramid_device.h: stagger_priority): the kernel argument for kernel `bit` of POPPY_STAGGER
+int stagger_flag(int bit);
+
 // --- once per pair ---------------------------------------------------------------------------
 // m2 = 1 - gray(gabor2)   (src/algo.cpp:250-252)
 void launch_gray_inv(const float* gabor2, float* m2, int n_px, hipStream_t s);
@@ -165,17 +168,17 @@ void launch_pyr_tail(const float* pyrL, const float* pyrR, const float* pyrM, fl
 // that the launch can sit in a captured graph while the value changes per frame.
 // `done` (optional): an event that completes with the launch's last kernel; for the tile kernel it rides on the dispatch
 // itself instead of being a packet of its own behind it.
-// src_pitch: pixels per row of src (0 = w; the outputs are tight).  A padded source takes the tile kernel.
+// src_pitch: pixels per row of src (0 = w; the outputs are tight).
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
                     int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done = nullptr, int src_pitch = 0);
 
 // The streaming form (kernels_unsharp_stream.hip: a wave per 60-pixel column strip, rows kept in registers); launch_unsharp uses it
-// for frames of 4 Mpx and more among the geometries it takes (w % 4 == 0, w >= 64, h >= 16) unless POPPY_UNSHARP_TILE is set;
+// for frames of 4 Mpx and more among the geometries it takes (w >= 64, h >= 16; any width and source pitch since round 6) unless POPPY_UNSHARP_TILE is set;
 // POPPY_UNSHARP_STREAM forces it for all of them.  norm2_min: see launch_unsharp.
 bool unsharp_stream_takes(int w, int h);
 bool unsharp_stream_eligible(int w, int h);
 void launch_unsharp_stream(const float* src, uint8_t* out_u8, float* out_f32_or_null, int w, int h, float amount, const float* d_amount,
-                           double norm2_min, hipStream_t s, hipEvent_t done);
+                           double norm2_min, hipStream_t s, hipEvent_t done, int src_pitch = 0);
 
 // u8 cross-dissolve fallback (src/poppy.hpp:129)
 void launch_dissolve(const uint8_t* a, const uint8_t* b, uint8_t* dst, size_t n, float wa, float wb, hipStream_t s);

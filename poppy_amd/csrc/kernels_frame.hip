@@ -10,6 +10,7 @@
 // Reference routines are cited per kernel (OCV = third/opencv-4.6.0/modules).
 #include "kernels.h"
 #include "pyramid_device.h"
+#include <atomic>
 #include "warp_device.h"
 #include <hip/hip_ext.h>
 #include <climits>
@@ -614,13 +615,14 @@ __device__ __forceinline__ float median_of_cols(const Col3& a, const Col3& b, co
 }
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int SP) {
+                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int SP, int stagger) {
     // SP: pixels per row of src (the blended level 0: PyrLevel::pitch); the frame goes out tight
     const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
     __shared__ __attribute__((aligned(16))) float S[kUSy * kUSs];
     __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
     float* const D = R;                 // the difference rows take R's place once every thread has read its R rows (phase 3)
     const int tid = threadIdx.x;
+    stagger_priority(blockIdx.x, stagger);
     const int tiles_x = (W + kUTx - 1) / kUTx;
     const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_y = blk / tiles_x, tile_x = blk - tile_y * tiles_x;
@@ -753,6 +755,15 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     else phase4(std::true_type{});
 }
 
+int stagger_flag(int bit) {
+#ifdef POPPY_EXPERIMENTS
+    static const int ab = getenv("POPPY_STAGGER_AB") ? atoi(getenv("POPPY_STAGGER_AB")) : 0;      // kernels that alternate, launch by launch
+    static std::atomic<unsigned> calls[16];
+    if ((ab >> bit) & 1) return (int)(calls[bit & 15].fetch_add(1) & 1u);
+#endif
+    return (POPPY_STAGGER >> bit) & 1;
+}
+
 void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u8, float* out_f32_or_null,
                     int w, int h, float amount, const float* d_amount, float threshold, hipStream_t s, hipEvent_t done, int src_pitch) {
     if (src_pitch <= 0) src_pitch = w;
@@ -766,9 +777,9 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
         static const bool tile_only = getenv("POPPY_UNSHARP_TILE") != nullptr;
-        if (!tile_only && src_pitch == w && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done); return; }
+        if (!tile_only && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done, src_pitch); return; }
         dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
-        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, src_pitch);
+        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, src_pitch, stagger_flag(1));
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);

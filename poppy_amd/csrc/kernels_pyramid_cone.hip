@@ -92,13 +92,14 @@ struct Region { int x0, y0, pw, ph; };                       // first pixel, siz
 
 template <int NL>
 __global__ void __launch_bounds__(kThreads) k_collapse_cone(const float* __restrict__ pyrL, const float* __restrict__ pyrR, const float* __restrict__ pyrM,
-                                                             float* __restrict__ pyrB, ConeArgs a, int tiles_x) {
+                                                             float* __restrict__ pyrB, ConeArgs a, int tiles_x, int stagger) {
     // planes of level j = 1 .. NL (relative to the output level): L, R, blended; the mask of levels 1 .. NL-1
     __shared__ float s1[3][kSlot1], sN[NL > 1 ? NL - 1 : 1][3][kSlotN], sM1[kPh1 * kPw1], sMN[NL > 1 ? NL - 1 : 1][kPhN * kPwN];
     const int tid = threadIdx.x;
     // tiles in row-major order, an XCD's workgroups a contiguous run of them: the band of the output level an XCD writes is the band the next
     // launch's workgroups on that XCD read (k_collapse_level numbers its blocks the same way), so it is still in that XCD's L2
     // (without: k_collapse_level<true> 18.9 -> 23.7 us at 1080p)
+    stagger_priority(blockIdx.x, stagger);
     const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ty = blk / tiles_x, tx = blk - ty * tiles_x;
     const ConeLevel& l0 = a.lv[0];
@@ -224,11 +225,11 @@ void launch_collapse_cone(const float* pyrL, const float* pyrR, const float* pyr
     const int tiles_x = (levels[0].w + kTx - 1) / kTx, tiles_y = (levels[0].h + kTy - 1) / kTy;
     const dim3 grid(tiles_x * tiles_y), block(kThreads);
     switch (n) {
-        case 2: hipLaunchKernelGGL(k_collapse_cone<2>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x); break;
-        case 3: hipLaunchKernelGGL(k_collapse_cone<3>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x); break;
-        case 4: hipLaunchKernelGGL(k_collapse_cone<4>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x); break;
-        case 5: hipLaunchKernelGGL(k_collapse_cone<5>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x); break;
-        default: hipLaunchKernelGGL(k_collapse_cone<6>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x); break;
+        case 2: hipLaunchKernelGGL(k_collapse_cone<2>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x, stagger_flag(4)); break;
+        case 3: hipLaunchKernelGGL(k_collapse_cone<3>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x, stagger_flag(4)); break;
+        case 4: hipLaunchKernelGGL(k_collapse_cone<4>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x, stagger_flag(4)); break;
+        case 5: hipLaunchKernelGGL(k_collapse_cone<5>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x, stagger_flag(4)); break;
+        default: hipLaunchKernelGGL(k_collapse_cone<6>, grid, block, 0, s, pyrL, pyrR, pyrM, pyrB, a, tiles_x, stagger_flag(4)); break;
     }
 }
 

@@ -204,7 +204,8 @@ template <bool U8>
 __global__ void __launch_bounds__(256) k_pyrdown_level(const void* __restrict__ srcL, const void* __restrict__ srcR, const float* __restrict__ srcM,
                                                        float* __restrict__ dstL, float* __restrict__ dstR, float* __restrict__ dstM,
                                                        DownGeom g3, DownGeom g1, VecBounds b, int gx, int gy, int nborder, int x0, int x1, int y0, int y1,
-                                                       const double* __restrict__ mask_ab) {
+                                                       const double* __restrict__ mask_ab, int stagger) {
+    stagger_priority(blockIdx.x, stagger);
     if (U8 && mask_ab) pyrdown_level_body<U8>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
     else               pyrdown_level_body<U8>(srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
 }
@@ -242,8 +243,8 @@ bool launch_pyrdown_vec(const void* srcL, const void* srcR, const float* srcM, b
     const int x0 = 4, x1 = 4 * b.t1 + 3, y0 = 1, y1 = b.y1;
     const int nb = border_count(g3.dw, g3.dh, x0, x1, y0, y1);
     const int nborder = (nb * 7 + 255) / 256, blocks = 2 * ((g3.dw / 2 + 63) / 64) * ((gy + 1) / 2) + gx * gy + nborder;
-    if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
-    else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
+    if (src_u8) hipLaunchKernelGGL(k_pyrdown_level<true>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, mask_ab, src_u8 ? stagger_flag(2) : 0);
+    else        hipLaunchKernelGGL(k_pyrdown_level<false>, dim3(blocks), dim3(64, 4), 0, s, srcL, srcR, srcM, dstL, dstR, dstM, g3, g1, b, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr, 0);
     return true;
 }
 
@@ -370,7 +371,8 @@ template <bool U8>
 __global__ void __launch_bounds__(256) k_collapse_level(const void* __restrict__ gL, const void* __restrict__ gR, const float* __restrict__ gM,
                                                         const float* __restrict__ nL, const float* __restrict__ nR, const float* __restrict__ nB,
                                                         float* __restrict__ outB, int w, int h, int nw, int nh, CollapsePitch cp, int gx, int gy, int nborder,
-                                                        int x0, int x1, int y0, int y1, const double* __restrict__ mask_ab) {
+                                                        int x0, int x1, int y0, int y1, const double* __restrict__ mask_ab, int stagger) {
+    stagger_priority(blockIdx.x, stagger);
     if (U8 && mask_ab) collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, mask_source(mask_ab));
     else               collapse_level_body<U8>(gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, MaskPlain());
 }
@@ -384,8 +386,8 @@ bool launch_collapse_vec(const void* gL, const void* gR, bool g_u8, const float*
     const int x0 = 4, x1 = 4 * t1 + 3, y0 = 2, y1 = 2 * (nh - 2) + 1;
     const int nb = border_count(w, h, x0, x1, y0, y1);
     const int nborder = (nb * 3 + 255) / 256, blocks = gx * gy + nborder;
-    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, mask_ab);
-    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr);
+    if (g_u8) hipLaunchKernelGGL(k_collapse_level<true>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, mask_ab, stagger_flag(3));
+    else      hipLaunchKernelGGL(k_collapse_level<false>, dim3(blocks), dim3(64, 4), 0, s, gL, gR, gM, nL, nR, nB, outB, w, h, nw, nh, cp, gx, gy, nborder, x0, x1, y0, y1, (const double*)nullptr, 0);
     return true;
 }
 

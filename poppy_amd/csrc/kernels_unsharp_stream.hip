@@ -85,10 +85,15 @@ __device__ __forceinline__ float med3s(float a, float b, float c) { return __bui
 }  // namespace
 
 __global__ void __launch_bounds__(256, POPPY_US_WAVES) k_unsharp_stream(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                        int W, int H, int seg_rows, int n_strips, int blocks_x,
-                                                        float amount_arg, const float* __restrict__ amount_ptr, double norm2_min) {
+                                                        int W, int H, int SP, int seg_rows, int n_strips, int blocks_x,
+                                                        float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int stagger) {
+    // SP: pixels per row of src (the blended level 0: PyrLevel::pitch, a multiple of 4 or W itself); the frame and outF go out tight, W pixels per row.
+    // Any width (round 6): a width that is no multiple of 4 leaves a last group of fewer than four pixels per row — those go out byte by byte — and
+    // rows that begin on any byte — the other groups' dword stores are then unaligned, which global stores take (3838 x 2160: 358 -> ~330 us per frame,
+    // it ran on the tile kernel before)
     __shared__ float lds[4 * kWaveLds];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stagger_priority(blockIdx.x, stagger);
     const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
     const int by = blk / blocks_x, bx = blk - by * blocks_x;
     const int strip = bx * 4 + wv;
@@ -109,7 +114,8 @@ __global__ void __launch_bounds__(256, POPPY_US_WAVES) k_unsharp_stream(const fl
     const bool stores = lane >= 1 && lane <= kStripPx;
     const int j4 = (lane - 1) & 3;                                   // position in the group of four pixels that becomes three dwords
     const int xg = X0 + ((lane - 1) & ~3);                           // first pixel of that group
-    const bool st_dw = stores && j4 < 3 && xg < W;
+    const bool st_dw = stores && j4 < 3 && xg + 3 < W;              // a whole group of four pixels: three dwords
+    const bool st_px = stores && xg + 3 >= W && X0 - 1 + lane < W;  // the row's last, shorter group: every lane its own three bytes
 
     const float t2f = (float)norm2_min;
     float R[9][3], D[3][3];
@@ -117,14 +123,14 @@ __global__ void __launch_bounds__(256, POPPY_US_WAVES) k_unsharp_stream(const fl
     for (int a = 0; a < 9; ++a) { R[a][0] = R[a][1] = R[a][2] = 0.f; }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { D[a][0] = D[a][1] = D[a][2] = 0.f; }
-    const size_t pitch = (size_t)W * 3;
+    const size_t pitch = (size_t)W * 3, spitch = (size_t)SP * 3;
     // source rows are requested kAhead steps before they are staged: a step is ~400 issue cycles per wave, memory is 1-2 us away
     constexpr int kAhead = POPPY_US_AHEAD;
     static_assert(9 % kAhead == 0, "the request ring is indexed by the step number modulo 9");
     u3 pa[kAhead], pb[kAhead];
     const uint32_t row_bytes = (uint32_t)W * 12u;
     auto request = [&](int logical_row, u3& a, u3& b) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)reflect_clamp(logical_row, H) * pitch),
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)reflect_clamp(logical_row, H) * spitch),
                                                                             0, (int)row_bytes, 0x00020000);
         a = __builtin_amdgcn_raw_buffer_load_b96(rs, ca, 0, 0);
         b = __builtin_amdgcn_raw_buffer_load_b96(rs, cb, 0, 0);
@@ -215,6 +221,10 @@ __global__ void __launch_bounds__(256, POPPY_US_WAVES) k_unsharp_stream(const fl
                     const uint32_t dw = (P >> (8 * j4)) | (Pn << (24 - 8 * j4));
                     *(uint32_t*)(out + (size_t)yo * pitch + (size_t)xg * 3 + 4 * j4) = dw;
                 }
+                if (st_px) {
+                    uint8_t* o = out + (size_t)yo * pitch + (size_t)(X0 - 1 + lane) * 3;
+                    o[0] = (uint8_t)P; o[1] = (uint8_t)(P >> 8); o[2] = (uint8_t)(P >> 16);
+                }
                 if (outF && stores && X0 - 1 + lane < W) {
                     float* o = outF + (size_t)yo * pitch + (size_t)(X0 - 1 + lane) * 3;
                     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
@@ -232,14 +242,14 @@ __global__ void __launch_bounds__(256, POPPY_US_WAVES) k_unsharp_stream(const fl
 // Geometry the kernel can take, and where it pays: at 4K it runs in 57-63 us against 75-80 for the tile kernel; a 1080p frame is ONE
 // round of 3-4 waves per SIMD whose 18-22 dependent row steps cannot hide each other's latency (26-28 us against 21-25: the tile
 // kernel stays below 4 Mpx).  POPPY_UNSHARP_STREAM forces it for every geometry it can take (the GPU tests run both).
-bool unsharp_stream_takes(int w, int h) { return (w & 3) == 0 && w >= 64 && h >= 16; }
+bool unsharp_stream_takes(int w, int h) { return w >= 64 && h >= 16; }
 bool unsharp_stream_eligible(int w, int h) {
     static const bool forced = getenv("POPPY_UNSHARP_STREAM") != nullptr;
     return unsharp_stream_takes(w, h) && (forced || (long long)w * h >= 4000000);
 }
 
 void launch_unsharp_stream(const float* src, uint8_t* out_u8, float* out_f32_or_null, int w, int h, float amount, const float* d_amount,
-                           double norm2_min, hipStream_t s, hipEvent_t done) {
+                           double norm2_min, hipStream_t s, hipEvent_t done, int src_pitch) {
     const int n_strips = (w + kStripPx - 1) / kStripPx, blocks_x = (n_strips + 3) / 4;
     // rows per segment: about as many waves as the chip holds at once (1024 SIMDs x 4-5), not so few rows that the ten warm-up rows
     // dominate (4K: 27 rows, 56.7 us; 18-36 rows 58-63 us)
@@ -248,7 +258,7 @@ void launch_unsharp_stream(const float* src, uint8_t* out_u8, float* out_f32_or_
     seg = seg < 8 ? 8 : (seg > 64 ? 64 : seg);
     const int blocks_y = (h + seg - 1) / seg;
     hipExtLaunchKernelGGL(k_unsharp_stream, dim3(blocks_x * blocks_y), dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null,
-                          w, h, seg, n_strips, blocks_x, amount, d_amount, norm2_min);
+                          w, h, src_pitch > 0 ? src_pitch : w, seg, n_strips, blocks_x, amount, d_amount, norm2_min, stagger_flag(7));
 }
 
 }  // namespace poppy_hip

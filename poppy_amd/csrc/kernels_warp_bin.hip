@@ -28,6 +28,24 @@
 // all SLOWER (4K: 50-57 us against 45-46), and measured why: the kernel's arithmetic ALONE, on register data with 8 waves per SIMD and no
 // memory instruction, takes 0.99 us per tile-wave per SIMD = 31 us at 4K (tools/micro/warp_alu.hip).  The kernels are in the history
 // (commits 17fafdb, a82110b), the measurements in profiles/r04_notes.md.
+// POPPY_WARP_PRIO (timing builds, tools/experiments/prio_build.sh; results unchanged): wave priorities / start offsets that take the co-resident waves of a
+// SIMD out of lock step — a round of workgroups starts together, so its waves wait for their ids together, divide together, gather together and store
+// together: the arithmetic (30 us at 4K alone) and the memory time (16.6 us for the skeleton alone, profiles/r06_warp_skeleton.txt) ADD UP instead of overlapping.
+//   1  a workgroup's priority = (blockIdx.x >> 8) & 3 (the 8 workgroups of a CU in a round get 4 levels)
+//   2  priority 3 from the moment a wave's gathers are issued (blend + store first), 0 before
+//   3  both: (blockIdx.x >> 8) & 1 before the gathers, 2 + that after
+//   4  start offsets: s_sleep ((blockIdx.x >> 8) & 7) * 8
+//   5  priority 3 before the gathers (get the loads out first), 0 after
+#ifndef POPPY_WARP_PRIO
+#define POPPY_WARP_PRIO 0
+#endif
+#if POPPY_WARP_PRIO == 2
+#define POPPY_WARP_AFTER_GATHERS __builtin_amdgcn_s_setprio(3)
+#elif POPPY_WARP_PRIO == 3
+#define POPPY_WARP_AFTER_GATHERS do { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } while (0)
+#elif POPPY_WARP_PRIO == 5
+#define POPPY_WARP_AFTER_GATHERS __builtin_amdgcn_s_setprio(0)
+#endif
 #include "warp_fast_device.h"
 #ifndef POPPY_WARP_WAVES
 #define POPPY_WARP_WAVES 8      // waves per SIMD the register allocation must leave room for (64 VGPRs: the 2025 workgroups of a 1080p frame are then ONE round)
@@ -125,6 +143,7 @@ constexpr int kSlots = 32;
 constexpr int kTileSlotBytes = kSlots * kEntryBytes;
 constexpr int kTileIdBytes = 1024;
 constexpr int kMaxTileEntries = 255;                      // an id is a byte
+constexpr unsigned kOneRoundBlocks = 2304;                // 256 CUs x 8 workgroups of 256 threads (+ the first finishers' successors): a 1080p frame is 2025 / 2040
 
 template <int kTileW>
 __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ rec, const RasterTriDev* __restrict__ tris,
@@ -195,12 +214,37 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
                                                   const int* __restrict__ tile_off,
                                                   const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                   uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
-                                                  int tiles_x, uint32_t data_bytes, WarpExtras ex) {
+                                                  int tiles_x, uint32_t data_bytes, WarpExtras ex, int stagger) {
     constexpr int kTileH = 1024 / kTileW, kTileTx = kTileW / 4;
     __shared__ float4 s_rec[kSlots * 5];
     __shared__ uint32_t s_ids[256];
 
     const int tid = threadIdx.x;
+#if POPPY_WARP_PRIO == 0
+    stagger_priority(blockIdx.x, stagger);
+#elif POPPY_WARP_PRIO == 1
+    switch ((blockIdx.x >> 8) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
+#elif POPPY_WARP_PRIO >= 6
+    {
+        const unsigned b = blockIdx.x, n = gridDim.x;
+        const unsigned pr = POPPY_WARP_PRIO == 6 ? (((b >> 8) & 1u) | (b * 2u < n ? 2u : 0u))
+                          : POPPY_WARP_PRIO == 7 ? 3u - min(3u, b >> 11)
+                          : POPPY_WARP_PRIO == 8 ? ((b >> 9) & 3u)
+                          : POPPY_WARP_PRIO == 9 ? ((b >> 7) & 3u)
+                          : POPPY_WARP_PRIO == 10 ? (((b >> 8) & 1u) * 3u)
+                          : POPPY_WARP_PRIO == 11 ? ((b >> 10) & 3u)
+                          : POPPY_WARP_PRIO == 12 ? ((b >> 3) & 3u)
+                          : ((b >> 5) & 3u);
+        switch (pr) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
+    }
+#elif POPPY_WARP_PRIO == 3
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#elif POPPY_WARP_PRIO == 4
+    switch ((blockIdx.x >> 8) & 7) { case 1: __builtin_amdgcn_s_sleep(8); break; case 2: __builtin_amdgcn_s_sleep(16); break; case 3: __builtin_amdgcn_s_sleep(24); break; case 4: __builtin_amdgcn_s_sleep(32); break;
+                                     case 5: __builtin_amdgcn_s_sleep(40); break; case 6: __builtin_amdgcn_s_sleep(48); break; case 7: __builtin_amdgcn_s_sleep(56); break; default: break; }
+#elif POPPY_WARP_PRIO == 5
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x), n_tiles = (int)gridDim.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int row = tid / kTileTx, xg = tid % kTileTx;           // this thread's pixels: (tx0 + 4 xg .. + 3, ty0 + row)
@@ -302,7 +346,8 @@ void launch_warp_bin(const float* records, const void* tile_data, size_t tile_da
 #define LB(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
     hipExtLaunchKernelGGL(k_warp_bin<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const float4*)records, \
                           (const uint8_t*)tile_data, tile_off, c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, \
-                          w, h, tiles_x, (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u), ex); }
+                          w, h, tiles_x, (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u), ex, \
+                          (unsigned)(tiles_x * tiles_y) <= kOneRoundBlocks ? stagger_flag(0) : stagger_flag(8)); }
     if (tile_w == 128) LB(128) else LB(64)
 #undef LB
 }

@@ -19,6 +19,24 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
     return x * per + (x < rem ? x : rem) + s;
 }
 
+// Wave priorities against lock step (round 6).  The workgroups of a launch that fits the chip in one round start together, and the waves that share a
+// SIMD then move through the kernel's phases together — all wait for their loads, all compute, all store —, so memory time and arithmetic add up
+// instead of overlapping.  Giving every second workgroup OF A COMPUTE UNIT the high priority (hardware block b runs on XCD b % 8 and, there, on CU
+// (b / 8) % 32: the co-resident workgroups of a CU differ in b >> 8) lets those run ahead: k_warp_bin 17.6 -> 14.6 us at 1080p, bit-identical
+// (profiles/r06_notes.md section 2; at 4K, four rounds, the workgroups are out of step by themselves and it changes nothing; changing the priority in
+// mid-kernel, or a start offset by s_sleep, was worth nothing or cost a factor).  POPPY_STAGGER = the kernels that do it, one bit each (timing builds:
+// tools/experiments/stagger_build.sh):  1 k_warp_bin (one-round grids), 2 k_unsharp_tile, 4 k_pyrdown_level<true>, 8 k_collapse_level<true>, 16 k_collapse_cone,
+// 128 k_unsharp_stream, 256 k_warp_bin (larger grids)
+#ifndef POPPY_STAGGER
+#define POPPY_STAGGER 1
+#endif
+// `on`: a kernel argument from stagger_flag(bit) (kernels.h) — the bit of POPPY_STAGGER, or, in a -DPOPPY_EXPERIMENTS build under POPPY_STAGGER_AB=<mask>,
+// on and off launch by launch, so that ONE traced process holds both forms of a kernel side by side (tools/experiments/stagger_ab.py splits a kernel's dispatches
+// by parity; between processes the same kernel's average moves by +-10 % on these boxes, more than most of the effects looked for)
+__device__ __forceinline__ void stagger_priority(unsigned hw_block, int on) {
+    if (on && ((hw_block >> 8) & 1u)) __builtin_amdgcn_s_setprio(3);
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     if ((unsigned)p < (unsigned)len) return p;
     if (len == 1) return 0;

@@ -126,6 +126,9 @@ __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amd
 #endif
         }
     }
+#ifdef POPPY_WARP_AFTER_GATHERS
+    POPPY_WARP_AFTER_GATHERS;
+#endif
     uint32_t p[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -108,3 +108,30 @@ def test_reference_demo_pairs_whole_morph(case):
     assert rc == 0 and len(fr) == 1
     assert G.sha(fr[0]) == G.entries(case)["phase0_frame"]["sha256"]
     c1.close()
+
+
+def test_streaming_unsharp_on_odd_widths():
+    """k_unsharp_stream takes any width and source pitch since round 6 (4K-class odd widths ran on the tile kernel before: 3838 x 2160 +10 % per frame): the row's
+    last, shorter pixel group goes out byte by byte, the other groups' dword stores are unaligned.  The stage and chained tests of this file once more with the
+    streaming kernel forced for every size (POPPY_UNSHARP_STREAM is read once per process), and one 4K-class odd width, where it is the kernel launch_unsharp
+    picks by itself, against the oracle."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("POPPY_UNSHARP_STREAM") or os.environ.get("POPPY_UNSHARP_TILE"):
+        pytest.skip("a kernel form is already forced in this process")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "frame_stages or chained_sequence"],
+                       env=dict(os.environ, POPPY_UNSHARP_STREAM="1"), capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    w, h = 2878, 1618                      # 4.66 Mpx: the streaming kernel by launch_unsharp's own choice; width 2 more than a multiple of 4
+    c = capi.Context(0)
+    try:
+        p1, p2 = _points(w, h, 120, 77, 9.0)
+        c1 = synth.textured_bgr(w, h, 43); c2 = synth.textured_bgr(w, h, 44)
+        g = synth.unit_field(w, h, 9)
+        want, _ = O.morph_images(c1, c2, g, p1, p2, 0.4, 0.4, 64)
+        got, _ = c.morph_images(c1, c2, g, p1, p2, 0.4, 0.4)
+        assert c.last_warp_kind() == 2
+        _same(f"frame {w}x{h}", got, want)
+    finally:
+        c.close()

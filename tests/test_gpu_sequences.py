@@ -314,6 +314,60 @@ def test_morph_sharded_one_device_equals_phase_frames():
     G.check(case, "phase1_frame", frames[2])          # t = 2/4
 
 
+def test_cfg4_480_frame_job_on_one_device():
+    """BASELINE.json configs[3] at full size on the one device a test box has: poppy_hip_morph_sharded([0], 1080p pair, 480) — the whole job a node would
+    split eight ways.  Frame 0 is image 1 (the phase == 0 short-circuit, src/poppy.hpp:54-70); frames 120 and 240 (t = 0.25, 0.5) are the REAL reference's
+    phase-mode frames (fixture a_1920x1080_chain60); four more sampled frames equal the oracle's from the same pair state; and all 480 equal, by sha256,
+    what poppy_hip_render_phases makes of the same t_j on an ordinary context (property: a shard's frames are the single-GPU frames)."""
+    import hashlib
+    import oracle_lib as O
+    from poppy_amd import capi
+    case = "a_1920x1080_chain60"
+    inp = G.astage_inputs(case)
+    total = 480
+    sampled = {0: None, 1: None, 97: None, 120: None, 240: None, 311: None, 479: None}
+
+    def keep(idx, f):
+        if idx in sampled:
+            sampled[idx] = f.copy()
+        return hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest()
+    shas = capi.morph_sharded([0], inp["img1"], inp["img2"], total, reduce=keep)
+    assert len(shas) == total
+    assert np.array_equal(sampled[0], inp["img1"])
+    G.check(case, "phase0_frame", sampled[120])
+    G.check(case, "phase1_frame", sampled[240])
+    c = _ctx(number_of_frames=1)
+    c.pair_begin(inp["img1"], inp["img2"])
+    p1, p2 = c.pair_points()
+    g = c.fetch("gabor2")
+    for j in (1, 97, 311, 479):
+        t = j / float(total)
+        want, _ = O.morph_images(inp["img1"], inp["img2"], g, p1, p2, t, t, 64)
+        assert np.array_equal(want, sampled[j]), j
+    got = []
+    c.render_many(np.arange(1, total) / float(total), chain=False, write=lambda f: got.append(hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest()))
+    c.close()
+    assert got == shas[1:], [j + 1 for j in range(total - 1) if got[j] != shas[j + 1]][:8]
+    # the whole job's digest (a checksum of checksums), for the record of what ran
+    print("cfg4 480-frame job sha256:", hashlib.sha256("".join(shas).encode()).hexdigest())
+
+
+def test_cfg5_pooled_1080p_pairs_on_one_device():
+    """BASELINE.json configs[4] at full size on one device: poppy_hip_morph_pairs([0], 2 x the 1080p pair x 60 chained frames, contexts_per_device = 2) — what a
+    GPU of the node renders of the 64-pair batch, two pairs side by side.  Every frame of both pairs against the real reference's (fixture a_1920x1080_chain60, sha256)."""
+    import hashlib
+    from poppy_amd import capi
+    case = "a_1920x1080_chain60"
+    inp = G.astage_inputs(case)
+    out = capi.morph_pairs([0], [(inp["img1"], inp["img2"])] * 2, contexts_per_device=2, number_of_frames=60,
+                           reduce=lambda p, j, f: hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest())
+    assert sorted(out) == [0, 1]
+    for p in out:
+        assert len(out[p]) == 60
+        bad = [j for j, h in enumerate(out[p]) if h != G.entries(case)[f"frame{j}"]["sha256"]]
+        assert not bad, f"pair {p}: frames {bad} differ from the reference"
+
+
 def test_morph_pairs_one_device():
     """poppy_hip_morph_pairs: three pairs over two contexts of one GPU; each pair's frames equal the single-context run."""
     from poppy_amd import capi

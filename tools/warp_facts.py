@@ -41,7 +41,8 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(ROOT, "poppy_amd", "csrc", "kernels_warp_bin.hip"), "-o", out],
                               stderr=subprocess.DEVNULL)
         asm = open(out).read()
-    facts = {"note": "issue cycles: static listing of the main path priced at 2 / 4 / 8 cycles per wave-instruction (profiles/r03_notes.md section 1); "
+    facts = {"run_id": os.environ.get("POPPY_RUN_ID"),
+             "note": "issue cycles: static listing of the main path priced at 2 / 4 / 8 cycles per wave-instruction (profiles/r03_notes.md section 1); "
                      "trace: rocprofv3 --kernel-trace --stats of tools/experiments/frames_only.py W H 60 chain 3 (tools/profile_round.sh)"}
     for (w, h), tw in (((1920, 1080), 64), ((3840, 2160), 128)):
         cyc, n, hist = issue_cycles(asm, f"_ZN9poppy_hip10k_warp_binILi{tw}E")
