@@ -12,6 +12,23 @@
  *     does: src/poppy.hpp:162,229).
  *   - one ctx per GPU, used from one host thread at a time; different ctx are independent.
  *   - there is NO CPU fallback: without a usable gfx950 device poppy_hip_create() fails.
+ *
+ * Environment variables (read once per process).  NONE of those the shipped library reads changes a result bit — they choose
+ * between forms that the tests hold to the same bytes (tests/test_gpu_prefilter.py::test_setup_alternative_forms_stay_exact,
+ * test_gpu_bstage.py::test_unsharp_kernel_forms_on_every_geometry, ::test_pyramid_launch_forms_stay_exact) or print timings:
+ *   frames    POPPY_HIP_SLOTS (frames in flight, 4), POPPY_HIP_RING (pinned frames towards the writer, 3), POPPY_HIP_NOGRAPH,
+ *             POPPY_HIP_NOFUSE (one launch per small pyramid level), POPPY_HIP_NOCONE (the way up in pairs of levels, as round 5),
+ *             POPPY_TAIL_PX, POPPY_TILE_W (64 / 128), POPPY_HIP_IDMAP, POPPY_HIP_GENERALWARP, POPPY_HIP_LBMASK_RIDER,
+ *             POPPY_HIP_DL_DEVWAIT, POPPY_HIP_DONE_PACKET, POPPY_PHASE_OWN_STREAMS, POPPY_UNSHARP_STREAM / _TILE / _ROWS,
+ *             POPPY_HIP_WARP_STAMP_STRIDE, POPPY_SEQ_TIMING (stderr)
+ *   set-up    POPPY_SETUP_SERIAL, POPPY_SETUP_UPLOAD_BOTH, POPPY_GABOR2_FIRST / _LATE / _AT, POPPY_GABOR_DIRECT, POPPY_ACC_STEPS,
+ *             POPPY_MED_SETS / _WAVES, POPPY_MED_COLS_MIN / _MIN_HARD / _FORCE / _ROWS, POPPY_ORB_GUESS / _CAP / _KPCAP (test
+ *             forms: short lists that must grow), POPPY_SETUP_TIMING (stderr)
+ *   several GPUs  POPPY_HIP_RCCL (path of librccl), POPPY_HIP_SHARD_SETUP, POPPY_HIP_SHARD_WORLD1
+ * Measurement switches that DO change results (parts of a kernel left out, the Gabor transform without its exactness hand-over:
+ * POPPY_MED_COLS_SKIP, POPPY_GABOR_NO_REDO, POPPY_GABOR_BAND, POPPY_DL_SKIP_COPY) and the launch-by-launch A/B of wave priorities
+ * (POPPY_STAGGER_AB) exist only in a build made with -DPOPPY_EXPERIMENTS (`python -m poppy_amd.build --experiments` writes
+ * libpoppy_hip_experiments.so beside the shipped library, never in its place); the shipped library does not read them.
  */
 #ifndef POPPY_HIP_H_
 #define POPPY_HIP_H_

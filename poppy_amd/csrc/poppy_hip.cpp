@@ -191,7 +191,7 @@ static int ensure_ring(poppy_hip_ctx* c, int n_points) {
     c->tile_bytes = warp_bin_data_bytes(ntiles, c->bins_cap);
     const size_t bytes = ((kBlobHeader + (size_t)(need + 1) * kWarpRecordFloats * 4 +
                           (size_t)need * (6 * 4 + 18 * 4 + sizeof(RasterTri)) + items * 8 +
-                          (size_t)need * 3 * sizeof(OutlineSeg) + (ntiles + 1) * 4 + c->bins_cap * 2 + 64 + 15) / 16) * 16;
+                          (size_t)need * 3 * sizeof(OutlineSeg) + (ntiles + 1) * 4 + c->bins_cap * 2 + 64 + 6 * 16 + 15) / 16) * 16;
     for (FrameSlot& f : c->slots) {
         if (f.body) { (void)hipGraphExecDestroy(f.body); f.body = nullptr; }      // it holds a pointer into the blob
         if (f.h_blob) (void)hipHostFree(f.h_blob);
@@ -447,6 +447,10 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         const auto t0 = clk::now();
         hipError_t e = dev_wait ? hipStreamWaitEvent(c->dl_stream, f.done, 0) : hipEventSynchronize(f.done);
         ms_done += lap(t0);
+#ifdef POPPY_EXPERIMENTS
+        static const bool skip_copy = getenv("POPPY_DL_SKIP_COPY") != nullptr;      // timing experiment: every wait and event of the writer path, no bytes moved (wrong frames)
+        if (!skip_copy)
+#endif
         if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * slot_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(c->dl_done[r], c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(f.downloaded, c->dl_stream);          // the slot's own: ring events are re-recorded every R frames
@@ -618,53 +622,59 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
     ((double*)(f.h_blob + kBlobMaskAB))[0] = 1.0 - mask;           // lbmask = clamp(alpha + m2 * beta), read by the level-0 blend kernels
     ((double*)(f.h_blob + kBlobMaskAB))[1] = -mask;
+    // The slot's plan blob: header | warp records | fill-edge tables | (fused path) outline segments, per-tile offsets, per-tile triangle lists |
+    // (id-map path only) integer triangles, inverse matrices, k_raster's work list.  A frame uploads what ITS kernels read: the fused path's two kernels
+    // never look at the last group (round 6: ~255 KB instead of ~400 KB per 1080p frame over PCIe, k_upload 12 -> 8 us).
     const size_t rec_bytes = (size_t)(T + 1) * kWarpRecordFloats * sizeof(float);
-    int* h_tri = (int*)(f.h_blob + kBlobHeader + rec_bytes);
-    float* h_inv = (float*)(h_tri + (size_t)T * 6);
-    RasterTri* h_edges = (RasterTri*)(h_inv + (size_t)T * 18);      // byte offset 144 + 176*T: 8-byte aligned
-    int* h_work = (int*)(h_edges + T);
     const int n_work = (int)(c->plan.work.size() / 2);
-    // the fused raster+warp kernel's inputs follow the work list: outline segments, per-tile offsets, per-tile triangle lists
-    const size_t work_ints = ((size_t)n_work * 2 + 3) & ~(size_t)3;       // the work list padded to 16 bytes: what follows is read as int4
-    OutlineSeg* h_outl = (OutlineSeg*)(h_work + work_ints);
-    int* h_toff = (int*)(h_outl + (size_t)T * 3);
     const size_t n_toff = c->plan.tile_off.size(), n_ttri = c->plan.tile_tris.size();
-    uint16_t* h_ttri = (uint16_t*)(h_toff + n_toff);
     static const bool idmap_only = getenv("POPPY_HIP_IDMAP") != nullptr;
     const bool bins = c->plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap && c->plan.max_tile_entries <= warp_bin_max_tile_entries() &&
                       c->plan.tile_w == warp_bin_tile_width(W, H);
-    const size_t used = kBlobHeader + rec_bytes + (size_t)T * (6 + 18) * 4 + (size_t)T * sizeof(RasterTri) + work_ints * 4 +
-                        (bins ? (size_t)T * 3 * sizeof(OutlineSeg) + n_toff * 4 + n_ttri * 2 : 0);
-    if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
-    if (T) {
-        memcpy(h_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
-        memcpy(h_inv, c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
-        memcpy(h_inv + (size_t)T * 9, c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
-        memcpy(h_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
-        memcpy(h_work, c->plan.work.data(), (size_t)n_work * 8);
-    }
-    if (bins) {
-        if (T) memcpy(h_outl, c->plan.outline.data(), (size_t)T * 3 * sizeof(OutlineSeg));
-        memcpy(h_toff, c->plan.tile_off.data(), n_toff * 4);
-        if (n_ttri) memcpy(h_ttri, c->plan.tile_tris.data(), n_ttri * 2);
-    }
-    // the fast warp kernel takes the frame when every matrix passes the host's range check (always, short of degenerate input)
+    // the fast warp kernels take the frame when every matrix passes the host's range check (always, short of degenerate input)
     static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
+    if (kBlobHeader + rec_bytes > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
     const bool records_ok = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), c->plan.tri_xy.data()) && !exact_warp_only;
     // raster fused into the warp kernel: no id map at all.  Any width whose level-0 rows begin on 16-byte boundaries: multiples of 4, and every width from
     // 150 001 pixels up (level_pitch); small images of other widths keep the id-map path
     const bool bin_warp = records_ok && bins && warp_bin_geometry(W, H) && (c->levels[0].pitch & 3) == 0;
     const bool fast_warp = bin_warp || (records_ok && warp_fast_geometry(W, H));
+    auto pad16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    size_t off = kBlobHeader + rec_bytes;
+    const size_t o_edges = off; off += (size_t)T * sizeof(RasterTri);                       // 96-byte entries: stays 16-byte aligned
+    size_t o_outl = 0, o_toff = 0, o_ttri = 0, o_tri = 0, o_inv = 0, o_work = 0;
+    if (bin_warp) {
+        o_outl = off; off += (size_t)T * 3 * sizeof(OutlineSeg);
+        o_toff = off; off += pad16(n_toff * 4);
+        o_ttri = off; off += pad16(n_ttri * 2);
+    } else {
+        o_tri = off; off += pad16((size_t)T * 6 * sizeof(int));
+        o_inv = off; off += pad16((size_t)T * 18 * sizeof(float));
+        o_work = off; off += pad16((size_t)n_work * 8);
+    }
+    const size_t used = off;
+    if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
+    if (T) memcpy(f.h_blob + o_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
+    if (bin_warp) {
+        if (T) memcpy(f.h_blob + o_outl, c->plan.outline.data(), (size_t)T * 3 * sizeof(OutlineSeg));
+        memcpy(f.h_blob + o_toff, c->plan.tile_off.data(), n_toff * 4);
+        if (n_ttri) memcpy(f.h_blob + o_ttri, c->plan.tile_tris.data(), n_ttri * 2);
+    } else if (T) {
+        memcpy(f.h_blob + o_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
+        memcpy(f.h_blob + o_inv, c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(f.h_blob + o_inv + (size_t)T * 9 * sizeof(float), c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(f.h_blob + o_work, c->plan.work.data(), (size_t)n_work * 8);
+    }
     c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;
     ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
     const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
-    const int* d_tri = (const int*)(f.d_blob + kBlobHeader + rec_bytes);
-    const float* d_inv = (const float*)(d_tri + (size_t)T * 6);
-    const RasterTri* d_edges = (const RasterTri*)(d_inv + (size_t)T * 18);
-    const int* d_work = (const int*)(d_edges + T);
-    const OutlineSeg* d_outl = (const OutlineSeg*)(d_work + work_ints);
-    const int* d_toff = (const int*)(d_outl + (size_t)T * 3);
-    const uint16_t* d_ttri = (const uint16_t*)(d_toff + n_toff);
+    const RasterTri* d_edges = (const RasterTri*)(f.d_blob + o_edges);
+    const OutlineSeg* d_outl = (const OutlineSeg*)(f.d_blob + o_outl);
+    const int* d_toff = (const int*)(f.d_blob + o_toff);
+    const uint16_t* d_ttri = (const uint16_t*)(f.d_blob + o_ttri);
+    const int* d_tri = (const int*)(f.d_blob + o_tri);
+    const float* d_inv = (const float*)(f.d_blob + o_inv);
+    const int* d_work = (const int*)(f.d_blob + o_work);
 
     // Streams.  Device-side waits between streams that sit on different hardware queues cost 12-20 us each on this part
     // (profiles/r01_e_streams.md), and which streams share a queue is the runtime's choice (GPU_MAX_HW_QUEUES); phase-mode frames

@@ -27,8 +27,10 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
 // mid-kernel, or a start offset by s_sleep, was worth nothing or cost a factor).  POPPY_STAGGER = the kernels that do it, one bit each (timing builds:
 // tools/experiments/stagger_build.sh):  1 k_warp_bin (one-round grids), 2 k_unsharp_tile, 4 k_pyrdown_level<true>, 8 k_collapse_level<true>, 16 k_collapse_cone,
 // 128 k_unsharp_stream, 256 k_warp_bin (larger grids)
+// Shipped: 1 + 4 + 8 + 16 + 256 — in-process A/B, on / off (profiles/r06_notes.md section 3): k_warp_bin 1080p 15.0 / 17.4 us (4K 44.1 / 44.5), k_collapse_level<true> 21.7 / 22.9
+// (4K 66.0 / 67.4), k_pyrdown_level<true> 4K 41.5 / 42.3, k_collapse_cone 13.7 / 13.9; k_unsharp_tile is SLOWER with it (24.5 / 23.5), k_unsharp_stream indifferent.
 #ifndef POPPY_STAGGER
-#define POPPY_STAGGER 1
+#define POPPY_STAGGER 285
 #endif
 // `on`: a kernel argument from stagger_flag(bit) (kernels.h) — the bit of POPPY_STAGGER, or, in a -DPOPPY_EXPERIMENTS build under POPPY_STAGGER_AB=<mask>,
 // on and off launch by launch, so that ONE traced process holds both forms of a kernel side by side (tools/experiments/stagger_ab.py splits a kernel's dispatches

@@ -321,3 +321,18 @@ def test_unsharp_kernel_forms_on_every_geometry():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_sequences.py"), "-q", "-x", "-m", "gpu", "-k", "cfg3_4k"],
                        env=dict(os.environ, POPPY_UNSHARP_TILE="1"), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_pyramid_launch_forms_stay_exact():
+    """The small pyramid levels' launches come in three forms with the same bits: the way up as ONE cone launch (k_collapse_cone, the default since round 6),
+    as round 5's pairs of levels (POPPY_HIP_NOCONE: k_collapse2 + k_collapse_level), and one launch per level (POPPY_HIP_NOFUSE: also no k_pyrdown2).  The
+    fixture, ragged-size, 1080p and chained tests of this file once more under each switch (read once per process)."""
+    import subprocess
+    import sys
+    if os.environ.get("POPPY_HIP_NOCONE") or os.environ.get("POPPY_HIP_NOFUSE"):
+        pytest.skip("a form is already forced in this process")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for form in ({"POPPY_HIP_NOCONE": "1"}, {"POPPY_HIP_NOFUSE": "1"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bstage.py"), "-q", "-x", "-m", "gpu", "-k",
+                            "fixtures or 1080p or ragged or chained_sequence"], env=dict(os.environ, **form), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, str(form) + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
