@@ -18,6 +18,9 @@ struct PyrLevel {        // geometry of one pyramid level and of the pyrDown tha
 // in or gets back.  The small levels (the fused and the tail kernels' domain) stay tight.
 constexpr size_t kPitchMinPixels = 150001;          // (= above kFuseMaxPixels)
 inline int level_pitch(int w, int h) { return ((w & 3) && (size_t)w * h >= kPitchMinPixels) ? (w + 3) & ~3 : w; }
+// Level 1 under a padded level 0 is padded too whatever its size (round 6): the level-0 pyrDown's 16-byte stores and the level-0 collapse's loads take it then
+// (749 x 480: level 1 is 375 x 240 — tight, the level-0 pyrDown fell back to the per-element kernel, 12.7 us against 7.0 at 752); k_pyrdown2 reads it by its pitch.
+inline int level1_pitch(int w1, int h1, int pitch0, int w0) { return ((w1 & 3) && pitch0 != w0) ? (w1 + 3) & ~3 : level_pitch(w1, h1); }
 
 // hipMemcpy2DAsync, except that rows which are tight on both sides go as ONE linear copy: a 2-D copy whose row length is no multiple of 4 bytes
 // takes a slow path of the runtime (639 x 480 x 3: 4 ms against 0.03; 1918 x 1080 x 3: 9 ms)
@@ -114,7 +117,7 @@ constexpr size_t kFuseMaxPixels = 150000;          // first level of the pair: 4
 bool pyrdown2_eligible(int sw, int sh);
 // A (sw x sh) -> B -> C for L, R (3 channels) and the mask (1 channel); B and C are both written.
 void launch_pyrdown2(const float* aL, const float* aR, const float* aM, float* bL, float* bR, float* bM,
-                     float* cL, float* cR, float* cM, int sw, int sh, hipStream_t s);
+                     float* cL, float* cR, float* cM, int sw, int sh, hipStream_t s, int src_pitch = 0);      // src_pitch: pixels per row of A's buffers (0 = sw)
 bool collapse2_eligible(int w, int h, int w1, int h1, int w2, int h2);
 // blended level k (w x h) from blended level k+2: g* = Gaussian level k, m* = level k+1, n* = level k+2 (nB blended).
 // The blended level k+1 only exists in LDS.

@@ -83,7 +83,7 @@ __device__ __forceinline__ void stage_rect(const float* __restrict__ src, size_t
 template <int CN>
 __device__ __forceinline__ void pyrdown2_body(const float* __restrict__ A, float* __restrict__ B, float* __restrict__ C,
                                               const DownGeom& gA, const DownGeom& gB, int tx, int ty, float* __restrict__ patch,
-                                              float* __restrict__ apatch) {
+                                              float* __restrict__ apatch, int pitchA) {
     const int tid = threadIdx.x;
     const int wa = gA.sw, ha = gA.sh, wb = gA.dw, hb = gA.dh, wc = gB.dw, hc = gB.dh;
     const int cx0 = tx * kD2Tx, cy0 = ty * kD2Ty;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void pyrdown2_body(const float* __restrict__ A, float
     // ... and so do the A pixels under those
     const int ax0 = max(2 * bx0 - 2, 0), ax1 = min(2 * bx1 + 2, wa - 1);
     const int ay0 = max(2 * by0 - 2, 0), ay1 = min(2 * by1 + 2, ha - 1);
-    stage_rect(A, (size_t)wa * CN, ay0, ax0 * CN, (ax1 - ax0 + 1) * CN, ay1 - ay0 + 1, apatch, kD2As);
+    stage_rect(A, (size_t)pitchA * CN, ay0, ax0 * CN, (ax1 - ax0 + 1) * CN, ay1 - ay0 + 1, apatch, kD2As);      // (pitchA: pixels per row of A's buffer; B and C are tight)
     __syncthreads();
     const int pw = (bx1 - bx0 + 1) * CN, ph = by1 - by0 + 1;
     const float inv_pw = 1.f / (float)pw;
@@ -120,14 +120,14 @@ __device__ __forceinline__ void pyrdown2_body(const float* __restrict__ A, float
 __global__ void __launch_bounds__(256) k_pyrdown2(const float* __restrict__ aL, const float* __restrict__ aR, const float* __restrict__ aM,
                                                   float* __restrict__ bL, float* __restrict__ bR, float* __restrict__ bM,
                                                   float* __restrict__ cL, float* __restrict__ cR, float* __restrict__ cM,
-                                                  DownGeom gA3, DownGeom gA1, DownGeom gB3, DownGeom gB1, int tiles_x) {
+                                                  DownGeom gA3, DownGeom gA1, DownGeom gB3, DownGeom gB1, int tiles_x, int pitchA) {
     __shared__ float patch[kD2Pr * kD2Ps];
     __shared__ float apatch[kD2Ar * kD2As];
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int which = blockIdx.y;
-    if (which == 0)      pyrdown2_body<3>(aL, bL, cL, gA3, gB3, tx, ty, patch, apatch);
-    else if (which == 1) pyrdown2_body<3>(aR, bR, cR, gA3, gB3, tx, ty, patch, apatch);
-    else                 pyrdown2_body<1>(aM, bM, cM, gA1, gB1, tx, ty, patch, apatch);
+    if (which == 0)      pyrdown2_body<3>(aL, bL, cL, gA3, gB3, tx, ty, patch, apatch, pitchA);
+    else if (which == 1) pyrdown2_body<3>(aR, bR, cR, gA3, gB3, tx, ty, patch, apatch, pitchA);
+    else                 pyrdown2_body<1>(aM, bM, cM, gA1, gB1, tx, ty, patch, apatch, pitchA);
 }
 
 // ---- pyrUp out of an LDS patch of the low-resolution level ------------------------------------------------------------
@@ -264,11 +264,11 @@ bool pyrdown2_eligible(int sw, int sh) {
 }
 
 void launch_pyrdown2(const float* aL, const float* aR, const float* aM, float* bL, float* bR, float* bM,
-                     float* cL, float* cR, float* cM, int sw, int sh, hipStream_t s) {
+                     float* cL, float* cR, float* cM, int sw, int sh, hipStream_t s, int src_pitch) {
     const DownGeom gA3 = make_down_geom(sw, sh, 3), gA1 = make_down_geom(sw, sh, 1);
     const DownGeom gB3 = make_down_geom(gA3.dw, gA3.dh, 3), gB1 = make_down_geom(gA3.dw, gA3.dh, 1);
     const int tiles_x = (gB3.dw + kD2Tx - 1) / kD2Tx, tiles_y = (gB3.dh + kD2Ty - 1) / kD2Ty;
-    hipLaunchKernelGGL(k_pyrdown2, dim3(tiles_x * tiles_y, 3), dim3(256), 0, s, aL, aR, aM, bL, bR, bM, cL, cR, cM, gA3, gA1, gB3, gB1, tiles_x);
+    hipLaunchKernelGGL(k_pyrdown2, dim3(tiles_x * tiles_y, 3), dim3(256), 0, s, aL, aR, aM, bL, bR, bM, cL, cR, cM, gA3, gA1, gB3, gB1, tiles_x, src_pitch > 0 ? src_pitch : sw);
 }
 
 bool collapse2_eligible(int w, int h, int w1, int h1, int w2, int h2) {

@@ -209,8 +209,9 @@ __global__ void __launch_bounds__(256) k_tile_expand(const float4* __restrict__ 
     ((uint32_t*)tile_data)[(size_t)tile * 256 + tid] = ids;
 }
 
-template <int kTileW>
-__global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
+// kAlignedRows: the sources' rows are a multiple of 4 bytes long (W % 4 == 0); the other instantiation (warp_fast_device.h) may take fewer waves per SIMD
+template <int kTileW, bool kAlignedRows>
+__global__ void __launch_bounds__(256, kAlignedRows ? POPPY_WARP_WAVES : POPPY_WARP_WAVES - 1) k_warp_bin(const float4* __restrict__ rec, const uint8_t* __restrict__ tile_data,
                                                   const int* __restrict__ tile_off,
                                                   const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                   uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H,
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(256, POPPY_WARP_WAVES) k_warp_bin(const float4
 #endif
         warp_taps(A, B, C, D, E, (float)(x0 + k), fy, W, H, t[0][k], t[1][k]);
     }
-    warp_fetch_blend_store(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {
+    warp_fetch_blend_store<kAlignedRows>(t, rs1, rs2, ro1, ro2, pitch, g, c1, c2, tr1, tr2, W, H, x0, y, [&](int k) -> const float* {
         const unsigned e = (s_ids[tid] >> (8 * k)) & 255u;
         if (e == 0) return (const float*)rec;
         if (e < (unsigned)kSlots) return (const float*)(tile_data + (size_t)n_tiles * kTileIdBytes + (size_t)tile * kTileSlotBytes + (size_t)e * kEntryBytes);
@@ -344,7 +345,7 @@ void launch_warp_bin(const float* records, const void* tile_data, size_t tile_da
                      const uint8_t* c1, const uint8_t* c2, uint8_t* tr1, uint8_t* tr2,
                      int w, int h, const WarpExtras& ex, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
 #define LB(TW) { const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + 1024 / TW - 1) / (1024 / TW); \
-    hipExtLaunchKernelGGL(k_warp_bin<TW>, dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const float4*)records, \
+    hipExtLaunchKernelGGL(((w & 3) ? k_warp_bin<TW, false> : k_warp_bin<TW, true>), dim3(tiles_x * tiles_y), dim3(256), 0, s, t0, t1, 0, (const float4*)records, \
                           (const uint8_t*)tile_data, tile_off, c1, c2, (uint32_t*)tr1, (uint32_t*)tr2, \
                           w, h, tiles_x, (uint32_t)std::min<size_t>(tile_data_bytes, 0xfffffff0u), ex, \
                           (unsigned)(tiles_x * tiles_y) <= kOneRoundBlocks ? stagger_flag(0) : stagger_flag(8)); }

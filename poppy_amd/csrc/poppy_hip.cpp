@@ -219,7 +219,7 @@ int alloc_pair(poppy_hip_ctx* c, int W, int H) {
     size_t off3 = 0, off1 = 0;
     int w = W, h = H;
     for (int i = 0; i <= L; ++i) {
-        const int pitch = level_pitch(w, h);                      // rows of the large levels begin on 16-byte boundaries (kernels.h)
+        const int pitch = i == 1 ? level1_pitch(w, h, c->levels[0].pitch, W) : level_pitch(w, h);      // rows of the large levels begin on 16-byte boundaries (kernels.h)
         c->levels[i] = PyrLevel{w, h, off3, off1, pitch};
         off3 += (size_t)pitch * h * 3; off1 += (size_t)pitch * h;
         w = (w + 1) / 2; h = (h + 1) / 2;
@@ -528,10 +528,10 @@ static void enqueue_body(poppy_hip_ctx* c, FrameSlot& f, hipStream_t s, Timer* t
     static const bool fuse = getenv("POPPY_HIP_NOFUSE") == nullptr;
     for (int i = 0; i < ft;) {
         const PyrLevel &a = c->levels[i], &b = c->levels[i + 1];
-        if (fuse && i >= 1 && i + 2 <= ft && a.pitch == a.w && pyrdown2_eligible(a.w, a.h)) {           // two small levels in one launch (their rows are tight)
+        if (fuse && i >= 1 && i + 2 <= ft && b.pitch == b.w && c->levels[i + 2].pitch == c->levels[i + 2].w && pyrdown2_eligible(a.w, a.h)) {     // two small levels in one launch (the two it writes are tight)
             const PyrLevel& d = c->levels[i + 2];
             launch_pyrdown2(f.pyrL + a.off3, f.pyrR + a.off3, f.pyrM + a.off1, f.pyrL + b.off3, f.pyrR + b.off3, f.pyrM + b.off1,
-                            f.pyrL + d.off3, f.pyrR + d.off3, f.pyrM + d.off1, a.w, a.h, s);
+                            f.pyrL + d.off3, f.pyrR + d.off3, f.pyrM + d.off1, a.w, a.h, s, a.pitch);
             i += 2;
             continue;
         }

@@ -2,6 +2,7 @@
 // id map; kernels_warp_bin.hip: one id byte per pixel from k_tile_expand).  The header comment of kernels_warp_fast.hip explains why each of them
 // returns the reference's bits.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 #include "warp_device.h"
 #include <hip/hip_ext.h>
@@ -106,49 +107,59 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 
 // Footprint fetch + bilinear blend + store of one thread's four pixels (both sources), given the eight taps; then the rare
 // byte-wise redo of pixels whose 2x2 footprint touches the image border.  rec_of(k) returns the record pointer of pixel k.
-template <typename RecOf>
+template <bool kAlignedRows, typename RecOf>
 __device__ __forceinline__ void warp_fetch_blend_store(FastTap (&t)[2][4], __amdgpu_buffer_rsrc_t rs1, __amdgpu_buffer_rsrc_t rs2,
                                                        __amdgpu_buffer_rsrc_t ro1, __amdgpu_buffer_rsrc_t ro2, uint32_t pitch, uint32_t g,
                                                        const uint8_t* __restrict__ c1, const uint8_t* __restrict__ c2,
                                                        uint32_t* __restrict__ tr1, uint32_t* __restrict__ tr2, int W, int H, int x0, int y, RecOf rec_of,
                                                        int out_pitch = 0) {
-    u3v ra[2][4], rb[2][4];
+    // The footprint's second row lies `pitch` bytes behind the first.  Source rows of widths that are no multiple of 4 are no multiple of 4 bytes long, so the second
+    // row's dwords begin elsewhere: it gets its own aligned address and byte shift (kAlignedRows = false: an instantiation of its own, the registers it needs would
+    // spill in the common one) — loaded at o4 + pitch the dwordx3 loads were UNALIGNED and the kernel took 71 us at 3838 x 2160 where 3840 takes 45 (round 6).
+    {
+        u3v ra[2][4], rb[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
-            const uint32_t o4 = t[im][k].off & ~3u;
+            for (int im = 0; im < 2; ++im) {
+                const uint32_t o4 = t[im][k].off & ~3u;
 #if POPPY_WARP_ABL & 8
-            ra[im][k] = u3v{o4, o4 + 1u, o4 + 2u}; rb[im][k] = u3v{o4 ^ pitch, o4 + 5u, o4 + 7u};
+                ra[im][k] = u3v{o4, o4 + 1u, o4 + 2u}; rb[im][k] = u3v{o4 ^ pitch, o4 + 5u, o4 + 7u};
 #else
-            ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
-            rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
+                ra[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, 0, 0);
+                if (kAlignedRows) rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, o4, (int)pitch, 0);
+                else rb[im][k] = __builtin_amdgcn_raw_buffer_load_b96(im ? rs2 : rs1, (t[im][k].off + pitch) & ~3u, 0, 0);
 #endif
+            }
         }
-    }
 #ifdef POPPY_WARP_AFTER_GATHERS
-    POPPY_WARP_AFTER_GATHERS;
+        POPPY_WARP_AFTER_GATHERS;
 #endif
-    uint32_t p[2][4];
+        uint32_t p[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
-            const uint32_t bs = t[im][k].off & 3u;
-            const u3v a3 = ra[im][k], b3 = rb[im][k];
-            const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
-            const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bs), __builtin_amdgcn_alignbyte(b3.z, b3.y, bs)};
-            p[im][k] = blend_fast(t[im][k], a, b);
+            for (int im = 0; im < 2; ++im) {
+                const uint32_t bs = t[im][k].off & 3u;
+                const uint32_t bsb = kAlignedRows ? bs : (t[im][k].off + pitch) & 3u;
+                const u3v a3 = ra[im][k], b3 = rb[im][k];
+                const u2v a = {__builtin_amdgcn_alignbyte(a3.y, a3.x, bs), __builtin_amdgcn_alignbyte(a3.z, a3.y, bs)};
+                const u2v b = {__builtin_amdgcn_alignbyte(b3.y, b3.x, bsb), __builtin_amdgcn_alignbyte(b3.z, b3.y, bsb)};
+                p[im][k] = blend_fast(t[im][k], a, b);
+            }
         }
+        const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
+        const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
+        __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, g * 12u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, g * 12u, 0, 0);
     }
-    const u3v o1 = {p[0][0] | (p[0][1] << 24), (p[0][1] >> 8) | (p[0][2] << 16), (p[0][2] >> 16) | (p[0][3] << 8)};
-    const u3v o2 = {p[1][0] | (p[1][1] << 24), (p[1][1] >> 8) | (p[1][2] << 16), (p[1][2] >> 16) | (p[1][3] << 8)};
-    __builtin_amdgcn_raw_buffer_store_b96(o1, ro1, g * 12u, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b96(o2, ro2, g * 12u, 0, 0);
 #ifndef POPPY_WARP_COUNT_MAIN          // tools/warp_facts.py counts the main path's instructions with the rare paths compiled out
     uint32_t edges = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) edges |= (t[0][k].inside ? 0u : 1u << k) | (t[1][k].inside ? 0u : 16u << k);
+    // pixels past the row's end (widths that are no multiple of 4: the padding of the outputs' last group, never read) are not redone — their maps point
+    // outside the image, so EVERY row's last wave took the byte-wise path for them: k_warp_bin 72 us at 3838 x 2160 where 3840 takes 45 (round 6)
+    if (x0 + 3 >= W) edges &= x0 + 2 >= W ? (x0 + 1 >= W ? 0x11u : 0x33u) : 0x77u;
     if (__builtin_amdgcn_ballot_w64(edges != 0) != 0 && edges != 0) {
         for (int e = 0; e < 8; ++e) {
             if (!((edges >> e) & 1u)) continue;

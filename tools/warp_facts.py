@@ -45,7 +45,7 @@ def main():
              "note": "issue cycles: static listing of the main path priced at 2 / 4 / 8 cycles per wave-instruction (profiles/r03_notes.md section 1); "
                      "trace: rocprofv3 --kernel-trace --stats of tools/experiments/frames_only.py W H 60 chain 3 (tools/profile_round.sh)"}
     for (w, h), tw in (((1920, 1080), 64), ((3840, 2160), 128)):
-        cyc, n, hist = issue_cycles(asm, f"_ZN9poppy_hip10k_warp_binILi{tw}E")
+        cyc, n, hist = issue_cycles(asm, f"_ZN9poppy_hip10k_warp_binILi{tw}ELb1E")      # the instantiation for widths that are multiples of 4
         entry = {"issue_cycles_per_wave": cyc, "instructions_per_wave": n, "clock_GHz": 2.4,
                  "top_instructions": dict(sorted(hist.items(), key=lambda kv: -kv[1])[:12])}
         dbs = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_chain_{w}", "*.db"))
