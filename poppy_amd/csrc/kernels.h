@@ -17,6 +17,9 @@ struct PyrLevel {        // geometry of one pyramid level and of the pyrDown tha
 // widths get up to 3 pixels of padding per row in the frame slots' own buffers (warped images, pyramid levels) — never in what a caller hands
 // in or gets back.  The small levels (the fused and the tail kernels' domain) stay tight.
 constexpr size_t kPitchMinPixels = 150001;          // (= above kFuseMaxPixels)
+// (Round 6 tried cache-line aligned rows — a pitch of a multiple of 128 pixels from a megapixel up — for the warp kernel's outputs: k_warp_bin takes 57 us at 3836 x 2160
+// and at 3844 x 2160 where 3840, 3712 and 3584, whose rows are multiples of 128 BYTES in the tight sources too, take 44 - 46; with the outputs' rows aligned it still took 57:
+// it is the gathers from the tight sources, not the stores.  tools/experiments/width_align.sh, odd_trace2.sh.)
 inline int level_pitch(int w, int h) { return ((w & 3) && (size_t)w * h >= kPitchMinPixels) ? (w + 3) & ~3 : w; }
 // Level 1 under a padded level 0 is padded too whatever its size (round 6): the level-0 pyrDown's 16-byte stores and the level-0 collapse's loads take it then
 // (749 x 480: level 1 is 375 x 240 — tight, the level-0 pyrDown fell back to the per-element kernel, 12.7 us against 7.0 at 752); k_pyrdown2 reads it by its pitch.

@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256, kAlignedRows ? POPPY_WARP_WAVES : POPPY_W
 
 
 bool warp_bin_geometry(int w, int h) {
-    return w >= 8 && h >= 2 && w <= 16384 && h <= 16384 && (long long)((w + 3) & ~3) * h * 3 + 16 < (1ll << 31);
+    return w >= 8 && h >= 2 && w <= 16384 && h <= 16384 && (long long)((w + 127) & ~127) * h * 3 + 16 < (1ll << 31);      // (the outputs' rows: level_pitch)
 }
 
 int warp_bin_tile_width(int w, int h) {
