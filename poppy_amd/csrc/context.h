@@ -66,6 +66,8 @@ struct poppy_hip_ctx {
     bool c2_raw_valid = false;           // ... and whether it belongs to the resident pair
     float *gabor2 = nullptr, *m2 = nullptr;
     std::vector<FrameSlot> slots;        // per-frame working sets, used round-robin
+    void* slot_prep_store = nullptr;     // per slot: the frame prepared there (poppy_hip.cpp: SlotPrep)
+    unsigned long long frame_seq = 0;    // submit_frame calls so far (a slot prepared ahead names the call it is for)
     hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
     const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
     hipEvent_t cur1_ready = nullptr;     // producer of cur1 when it is a slot's output, else null

@@ -20,6 +20,8 @@
 #include "context.h"
 
 static std::string g_create_error;
+static void free_slot_preps(poppy_hip_ctx* c);
+static void drop_slot_preps(poppy_hip_ctx* c);
 
 // Streams and hardware queues.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable
 // says otherwise); streams that share a queue run in order, and queues are handed out — and spread over the command processor's
@@ -120,6 +122,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); c->dl_stream = nullptr; }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    free_slot_preps(c);
     if (c->setup_ev) (void)hipEventDestroy(c->setup_ev);
     if (c->c2_up_ev) (void)hipEventDestroy(c->c2_up_ev);
     for (hipEvent_t e : c->dl_done) if (e) (void)hipEventDestroy(e);
@@ -356,6 +359,7 @@ struct Timer {
 };
 
 static int submit_frame(poppy_hip_ctx* c, double mask, bool chain);
+static int prepare_ahead(poppy_hip_ctx* c, const FramePlan& plan, double mask);
 
 // one frame on the resident pair; result in frame[slot]
 static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain) {
@@ -490,6 +494,9 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         }
         const auto t_sub = clk::now();
         rc = submit_frame(c, mask[j], chain);
+        // chained frames: the NEXT frame's plan goes up and is expanded now, behind this frame's launches (the wait for it at the head of the next
+        // submit_frame then finds it done); only when its plan is ready — the planners are normally far ahead
+        if (rc == POPPY_OK && chain && j + 1 < n && ready[j + 1].load(std::memory_order_acquire) && rcs[j + 1] == 0) rc = prepare_ahead(c, plans[j + 1], mask[j + 1]);
         ms_submit += lap(t_sub);
         if (rc != POPPY_OK) break;
         slot_of[j] = c->last_slot;
@@ -509,6 +516,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
         while (written < n && rc == POPPY_OK) deliver(written);
     }
     c->writer_attached = false;
+    drop_slot_preps(c);                    // (a frame prepared ahead and never rendered — an error exit — must not meet a later call)
     next.store(n);                         // on an error: let the workers drain
     if (!c->planners.wait() && rc == POPPY_OK) rc = fail(c, POPPY_E_DEVICE, ("frame planner thread: " + c->planners.error()).c_str());
     if (seq_times)
@@ -595,28 +603,58 @@ static int capture_body(poppy_hip_ctx* c, FrameSlot& f) {
     return POPPY_OK;
 }
 
-static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
-    const int W = c->W, H = c->H;
-    const int T = c->plan.n_tris;
-    if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
-    static_assert(((long long)kIdTagMax << kIdTagShift) + (1ll << kIdTagShift) - 1 <= 0x7fffffffll, "tagged ids must stay positive int32 values");
-    if (T + 1 >= (1 << kIdTagShift)) return fail(c, POPPY_E_UNSUPPORTED, "more triangles than the id map's tag scheme can number (2^20 - 2)");
+// A frame in two halves (round 6).  PREPARE: the slot's plan blob is filled, uploaded and expanded into id bytes + record slots (k_upload, k_tile_expand) — that depends
+// on the plan only.  RENDER: everything that reads images.  For chained frames the first half runs on the copy stream and the HOST waits for it before it launches
+// the warp kernel (no device-side wait across hardware queues, see below); until round 6 that wait sat between the two halves of the SAME frame — 38 us of every frame's
+// ~100 us of host time alone, ~500 us per frame in a pool, where the copy stream's packets queue behind other contexts' kernels.  render_sequence now prepares frame j + 1
+// right after it has launched frame j: the wait at the head of frame j + 1 finds the event complete.
+struct SlotPrep {
+    bool valid = false;
+    int T = 0, n_work = 0, tile_w = 0;
+    bool bin_warp = false, fast_warp = false, chained = false, use_graph = false;
+    unsigned long long seq = 0;            // the submit_frame call this was prepared for (0: prepared by that call itself)
+    size_t rec_bytes = 0, o_edges = 0, o_outl = 0, o_toff = 0, o_ttri = 0, o_tri = 0, o_inv = 0, o_work = 0, used = 0;
+    double mask = 0;
+    hipStream_t s = nullptr;
+    std::vector<P2f> morphed;
+};
+static std::vector<SlotPrep>& preps_of(poppy_hip_ctx* c) {             // one record per slot (kept behind a pointer: context.h stays free of frame_plan.h types)
+    if (!c->slot_prep_store) c->slot_prep_store = new std::vector<SlotPrep>();
+    auto* v = static_cast<std::vector<SlotPrep>*>(c->slot_prep_store);
+    if (v->size() != c->slots.size()) v->assign(c->slots.size(), SlotPrep());
+    return *v;
+}
+static void free_slot_preps(poppy_hip_ctx* c) { delete static_cast<std::vector<SlotPrep>*>(c->slot_prep_store); c->slot_prep_store = nullptr; }
+static void drop_slot_preps(poppy_hip_ctx* c) { if (c->slot_prep_store) for (SlotPrep& p : *static_cast<std::vector<SlotPrep>*>(c->slot_prep_store)) p.valid = false; }
 
-    // frame slot: the next one in the ring that does not hold the image this frame reads as corrected1
+// the slot the next frame renders into: the next one in the ring that does not hold the image that frame reads as corrected1
+static int pick_slot(const poppy_hip_ctx* c) {
     int fi = c->next_slot;
     if (c->slots[fi].out == c->cur1) fi = (fi + 1) % (int)c->slots.size();
-    c->next_slot = (fi + 1) % (int)c->slots.size();
-    FrameSlot& f = c->slots[fi];
-    // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
-    // `out` before that copy has read it
-    auto waited = [&](double& acc, hipEvent_t ev) -> hipError_t {     // host wait for an event, accounted (POPPY_SEQ_TIMING)
+    return fi;
+}
+
+static auto waited_on(poppy_hip_ctx* c) {
+    return [c](double& acc, hipEvent_t ev) -> hipError_t {             // host wait for an event, accounted (POPPY_SEQ_TIMING)
+        (void)c;
         const auto t0 = std::chrono::steady_clock::now();
         const hipError_t e = hipEventSynchronize(ev);
         acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return e;
     };
-    if (f.dl_pending) { HIPCHK(c, waited(c->wait_ms[0], f.downloaded)); f.dl_pending = false; }
+}
 
+// first half: `plan` into slot fi (blob, upload, expansion).  chained: on the copy stream, nobody waits here.
+static int prepare_slot(poppy_hip_ctx* c, const FramePlan& plan, double mask, bool chain, int fi) {
+    const int W = c->W, H = c->H;
+    const int T = plan.n_tris;
+    if (T > c->max_tris) return fail(c, POPPY_E_ARG, "triangle budget exceeded");
+    static_assert(((long long)kIdTagMax << kIdTagShift) + (1ll << kIdTagShift) - 1 <= 0x7fffffffll, "tagged ids must stay positive int32 values");
+    if (T + 1 >= (1 << kIdTagShift)) return fail(c, POPPY_E_UNSUPPORTED, "more triangles than the id map's tag scheme can number (2^20 - 2)");
+    FrameSlot& f = c->slots[fi];
+    SlotPrep& pr = preps_of(c)[fi];
+    pr.valid = false;
+    auto waited = waited_on(c);
     HIPCHK(c, waited(c->wait_ms[1], f.uploaded));                  // the pinned copy is free again
     const double amount = std::sin(mask * M_PI);
     *(float*)f.h_blob = (float)(1.0 - amount);                     // unsharp_mask(.., 1, 1.0 - amount, 0.3)
@@ -626,15 +664,15 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     // (id-map path only) integer triangles, inverse matrices, k_raster's work list.  A frame uploads what ITS kernels read: the fused path's two kernels
     // never look at the last group (round 6: ~255 KB instead of ~400 KB per 1080p frame over PCIe, k_upload 12 -> 8 us).
     const size_t rec_bytes = (size_t)(T + 1) * kWarpRecordFloats * sizeof(float);
-    const int n_work = (int)(c->plan.work.size() / 2);
-    const size_t n_toff = c->plan.tile_off.size(), n_ttri = c->plan.tile_tris.size();
+    const int n_work = (int)(plan.work.size() / 2);
+    const size_t n_toff = plan.tile_off.size(), n_ttri = plan.tile_tris.size();
     static const bool idmap_only = getenv("POPPY_HIP_IDMAP") != nullptr;
-    const bool bins = c->plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap && c->plan.max_tile_entries <= warp_bin_max_tile_entries() &&
-                      c->plan.tile_w == warp_bin_tile_width(W, H);
+    const bool bins = plan.bins_ok && !idmap_only && !c->debug && n_ttri <= c->bins_cap && plan.max_tile_entries <= warp_bin_max_tile_entries() &&
+                      plan.tile_w == warp_bin_tile_width(W, H);
     // the fast warp kernels take the frame when every matrix passes the host's range check (always, short of degenerate input)
     static const bool exact_warp_only = getenv("POPPY_HIP_GENERALWARP") != nullptr;
     if (kBlobHeader + rec_bytes > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
-    const bool records_ok = pack_warp_records(c->plan.inv1.data(), c->plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), c->plan.tri_xy.data()) && !exact_warp_only;
+    const bool records_ok = pack_warp_records(plan.inv1.data(), plan.inv2.data(), T, W, H, (float*)(f.h_blob + kBlobHeader), plan.tri_xy.data()) && !exact_warp_only;
     // raster fused into the warp kernel: no id map at all.  Any width whose level-0 rows begin on 16-byte boundaries: multiples of 4, and every width from
     // 150 001 pixels up (level_pitch); small images of other widths keep the id-map path
     const bool bin_warp = records_ok && bins && warp_bin_geometry(W, H) && (c->levels[0].pitch & 3) == 0;
@@ -654,27 +692,22 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     }
     const size_t used = off;
     if (used > c->blob_bytes) return fail(c, POPPY_E_ARG, "plan blob overflow");
-    if (T) memcpy(f.h_blob + o_edges, c->plan.raster.data(), (size_t)T * sizeof(RasterTri));
+    if (T) memcpy(f.h_blob + o_edges, plan.raster.data(), (size_t)T * sizeof(RasterTri));
     if (bin_warp) {
-        if (T) memcpy(f.h_blob + o_outl, c->plan.outline.data(), (size_t)T * 3 * sizeof(OutlineSeg));
-        memcpy(f.h_blob + o_toff, c->plan.tile_off.data(), n_toff * 4);
-        if (n_ttri) memcpy(f.h_blob + o_ttri, c->plan.tile_tris.data(), n_ttri * 2);
+        if (T) memcpy(f.h_blob + o_outl, plan.outline.data(), (size_t)T * 3 * sizeof(OutlineSeg));
+        memcpy(f.h_blob + o_toff, plan.tile_off.data(), n_toff * 4);
+        if (n_ttri) memcpy(f.h_blob + o_ttri, plan.tile_tris.data(), n_ttri * 2);
     } else if (T) {
-        memcpy(f.h_blob + o_tri, c->plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
-        memcpy(f.h_blob + o_inv, c->plan.inv1.data(), (size_t)T * 9 * sizeof(float));
-        memcpy(f.h_blob + o_inv + (size_t)T * 9 * sizeof(float), c->plan.inv2.data(), (size_t)T * 9 * sizeof(float));
-        memcpy(f.h_blob + o_work, c->plan.work.data(), (size_t)n_work * 8);
+        memcpy(f.h_blob + o_tri, plan.tri_xy.data(), (size_t)T * 6 * sizeof(int));
+        memcpy(f.h_blob + o_inv, plan.inv1.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(f.h_blob + o_inv + (size_t)T * 9 * sizeof(float), plan.inv2.data(), (size_t)T * 9 * sizeof(float));
+        memcpy(f.h_blob + o_work, plan.work.data(), (size_t)n_work * 8);
     }
-    c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;
-    ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
     const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
     const RasterTri* d_edges = (const RasterTri*)(f.d_blob + o_edges);
     const OutlineSeg* d_outl = (const OutlineSeg*)(f.d_blob + o_outl);
     const int* d_toff = (const int*)(f.d_blob + o_toff);
     const uint16_t* d_ttri = (const uint16_t*)(f.d_blob + o_ttri);
-    const int* d_tri = (const int*)(f.d_blob + o_tri);
-    const float* d_inv = (const float*)(f.d_blob + o_inv);
-    const int* d_work = (const int*)(f.d_blob + o_work);
 
     // Streams.  Device-side waits between streams that sit on different hardware queues cost 12-20 us each on this part
     // (profiles/r01_e_streams.md), and which streams share a queue is the runtime's choice (GPU_MAX_HW_QUEUES); phase-mode frames
@@ -714,18 +747,49 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
     const bool use_graph = !no_graph && !chained && !c->debug && !all_marks && W > 1 && H > 1;
     if (use_graph && !f.body) { int rc = capture_body(c, f); if (rc) return rc; }
 
-    Timer tm(c, s);
-    if (all_marks) tm.mark(nullptr);
+    pr.T = T; pr.n_work = n_work; pr.tile_w = plan.tile_w; pr.bin_warp = bin_warp; pr.fast_warp = fast_warp; pr.chained = chained; pr.use_graph = use_graph;
+    pr.rec_bytes = rec_bytes; pr.o_edges = o_edges; pr.o_outl = o_outl; pr.o_toff = o_toff; pr.o_ttri = o_ttri; pr.o_tri = o_tri; pr.o_inv = o_inv; pr.o_work = o_work; pr.used = used;
+    pr.mask = mask; pr.s = s; pr.morphed = plan.morphed; pr.seq = c->frame_seq;
     hipStream_t up = chained ? c->copy_stream : s;
     if (chained) HIPCHK(c, waited(c->wait_ms[2], f.done));        // the frame that last read this slot's device copy of the plan (2+ frames back)
     launch_upload(f.h_blob_dev, f.d_blob, used, up);
     // the raster of the frame, as one id byte per pixel + the tiles' record slots: needs the plan only
-    if (bin_warp) launch_tile_expand(d_rec, d_edges, d_outl, d_toff, d_ttri, f.tile_data, c->plan.tile_w, W, H, up);
+    if (bin_warp) launch_tile_expand(d_rec, d_edges, d_outl, d_toff, d_ttri, f.tile_data, plan.tile_w, W, H, up);
     // (The blend mask also depends on the plan only.  Taking it out of the warp kernel — a kernel of its own on this stream —
     // made that kernel faster (20.5 -> 18.1 us at 1080p, 53.6 -> 46.5 us at 4K) and the chained FRAME slower (183.8 -> 188.3 us,
     // 403 -> 411 us): the extra traffic beside the chain costs the chain's bandwidth-bound kernels more than the rider did.
     // profiles/r02_notes.md.)
     HIPCHK(c, hipEventRecord(f.uploaded, up));
+    pr.valid = true;
+    return POPPY_OK;
+}
+
+// second half: the frame prepared in slot fi
+static int render_slot(poppy_hip_ctx* c, int fi, bool chain) {
+    const int W = c->W, H = c->H;
+    FrameSlot& f = c->slots[fi];
+    SlotPrep& pr = preps_of(c)[fi];
+    if (!pr.valid) return fail(c, POPPY_E_STATE, "frame slot not prepared");
+    pr.valid = false;
+    auto waited = waited_on(c);
+    const int T = pr.T, n_work = pr.n_work;
+    const bool bin_warp = pr.bin_warp, fast_warp = pr.fast_warp, chained = pr.chained, use_graph = pr.use_graph;
+    const double mask = pr.mask, amount = std::sin(mask * M_PI);
+    hipStream_t s = pr.s;
+    const float* d_rec = (const float*)(f.d_blob + kBlobHeader);
+    const RasterTri* d_edges = (const RasterTri*)(f.d_blob + pr.o_edges);
+    const int* d_toff = (const int*)(f.d_blob + pr.o_toff);
+    const int* d_tri = (const int*)(f.d_blob + pr.o_tri);
+    const float* d_inv = (const float*)(f.d_blob + pr.o_inv);
+    const int* d_work = (const int*)(f.d_blob + pr.o_work);
+    c->last_warp_fast = fast_warp; c->last_warp_bin = bin_warp;
+    ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
+    // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
+    // `out` before that copy has read it
+    if (f.dl_pending) { HIPCHK(c, waited(c->wait_ms[0], f.downloaded)); f.dl_pending = false; }
+    const bool all_marks = c->timing == 1;
+    Timer tm(c, s);
+    if (all_marks) tm.mark(nullptr);
     if (chained) HIPCHK(c, waited(c->wait_ms[3], f.uploaded));
     // -- independent of the previous frame ---------------------------------------------------------------------
     // Id-map path only (debug mode, POPPY_HIP_IDMAP, oversized tile lists).  The id map is not cleared between frames: every
@@ -757,19 +821,19 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         static const int stride = getenv("POPPY_HIP_WARP_STAMP_STRIDE") ? std::max(1, atoi(getenv("POPPY_HIP_WARP_STAMP_STRIDE"))) : kWarpStampStride;
         const bool stamp = (c->warp_seq++ % (unsigned)stride) == 0;
         hipEvent_t t0 = stamp ? tm.take(nullptr) : nullptr, t1 = stamp ? tm.take("warp") : nullptr;
-        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, pr.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
         else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s, t0, t1);
     } else {
         if (!all_marks) tm.mark(nullptr);
-        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, c->plan.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
+        if (bin_warp) launch_warp_bin(d_rec, f.tile_data, c->tile_bytes, d_toff, pr.tile_w, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         else if (fast_warp) launch_warp_fast(f.triMap, d_rec, T + 1, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         else launch_warp(f.triMap, d_inv, d_inv + (size_t)T * 9, c->cur1, c->c2, f.tr1, f.tr2, W, H, ex, s);
         tm.mark("warp");
     }
     if (bin_warp) {
         c->last_warp.rec = d_rec; c->last_warp.tile_data = f.tile_data; c->last_warp.tile_bytes = c->tile_bytes;
-        c->last_warp.toff = d_toff; c->last_warp.tile_w = c->plan.tile_w; c->last_warp.c1 = c->cur1; c->last_warp.c2 = c->c2;
+        c->last_warp.toff = d_toff; c->last_warp.tile_w = pr.tile_w; c->last_warp.c1 = c->cur1; c->last_warp.c2 = c->c2;
         c->last_warp.tr1 = f.tr1; c->last_warp.tr2 = f.tr2; c->last_warp.ex = ex; c->last_warp.valid = true;
     } else c->last_warp.valid = false;
     // The frame's completion event rides on its last dispatch when the kernels are launched one by one: an event record of
@@ -785,9 +849,32 @@ static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
         c->cur1 = f.out;
         c->cur1_ready = f.done;
         c->cur1_stream = s;
-        c->pts1 = c->plan.morphed;
+        c->pts1 = pr.morphed;
     }
     return POPPY_OK;
+}
+
+
+static int submit_frame(poppy_hip_ctx* c, double mask, bool chain) {
+    const int fi = pick_slot(c);
+    c->next_slot = (fi + 1) % (int)c->slots.size();
+    ++c->frame_seq;
+    SlotPrep& pr = preps_of(c)[fi];
+    if (!(pr.valid && pr.seq == c->frame_seq && pr.chained && chain)) {             // (not prepared ahead for THIS call: both halves now)
+        drop_slot_preps(c);
+        int rc = prepare_slot(c, c->plan, mask, chain, fi); if (rc) return rc;
+    }
+    return render_slot(c, fi, chain);
+}
+
+// Chained frames only: the first half of the NEXT frame, launched behind the frame just submitted.  `plan` is that frame's; its slot is the one submit_frame will pick.
+static int prepare_ahead(poppy_hip_ctx* c, const FramePlan& plan, double mask) {
+    static const bool off = getenv("POPPY_HIP_NO_PREPARE_AHEAD") != nullptr;
+    if (off || c->debug || c->timing != 0 || c->slots.size() < 3) return POPPY_OK;
+    const int fi = pick_slot(c);
+    const int rc = prepare_slot(c, plan, mask, true, fi);
+    if (rc == POPPY_OK) preps_of(c)[fi].seq = c->frame_seq + 1;
+    return rc;
 }
 
 int upload_image(poppy_hip_ctx* c, uint8_t* dst, const uint8_t* src, size_t stride, int W, int H) {
