@@ -19,7 +19,7 @@
  *   frames    POPPY_HIP_SLOTS (frames in flight, 4), POPPY_HIP_RING (pinned frames towards the writer, 3), POPPY_HIP_NOGRAPH,
  *             POPPY_HIP_NOFUSE (one launch per small pyramid level), POPPY_HIP_NOCONE (the way up in pairs of levels, as round 5),
  *             POPPY_TAIL_PX, POPPY_TILE_W (64 / 128), POPPY_HIP_IDMAP, POPPY_HIP_GENERALWARP, POPPY_HIP_LBMASK_RIDER,
- *             POPPY_HIP_DL_DEVWAIT, POPPY_HIP_DONE_PACKET, POPPY_PHASE_OWN_STREAMS, POPPY_UNSHARP_STREAM / _TILE / _ROWS,
+ *             POPPY_HIP_DL_DEVWAIT, POPPY_HIP_DL_EVENTS (one download stream + an event per frame copy, as until round 5), POPPY_HIP_DONE_PACKET, POPPY_HIP_NO_PREPARE_AHEAD, POPPY_PHASE_OWN_STREAMS, POPPY_UNSHARP_STREAM / _TILE / _ROWS,
  *             POPPY_HIP_WARP_STAMP_STRIDE, POPPY_SEQ_TIMING (stderr)
  *   set-up    POPPY_SETUP_SERIAL, POPPY_SETUP_UPLOAD_BOTH, POPPY_GABOR2_FIRST / _LATE / _AT, POPPY_GABOR_DIRECT, POPPY_ACC_STEPS,
  *             POPPY_MED_SETS / _WAVES, POPPY_MED_COLS_MIN / _MIN_HARD / _FORCE / _ROWS, POPPY_ORB_GUESS / _CAP / _KPCAP (test

@@ -45,6 +45,7 @@ struct FrameSlot {
     hipGraphExec_t body = nullptr;                  // pyrdown .. unsharp of this slot, captured once per pair geometry
     hipEvent_t downloaded = nullptr;                // completes when the last download of this slot's `out` towards the writer has read it
     bool dl_pending = false;                        // ... and whether such a download was issued since the slot was last rendered into
+    int dl_ring_idx = -1;                           // POPPY_HIP_DL_STREAMS: the ring stream that carries that download
 };
 constexpr size_t kBlobHeader = 64;            // [0] float: unsharp amount; [16], [24] double: the frame's mask (alpha, beta)
 constexpr size_t kBlobMaskAB = 16;
@@ -131,6 +132,7 @@ struct poppy_hip_ctx {
     hipStream_t dl_stream = nullptr;
     bool setup_serial = false;                  // pair set-up: the two images' chains one after the other (set by pools of >= 3 contexts per device and by poppy_hip_set_setup_chains)
     hipEvent_t dl_done[kStageRing] = {};
+    hipStream_t dl_ring[kStageRing] = {};     // POPPY_HIP_DL_STREAMS: a stream per pinned ring buffer, carrying nothing but that buffer's copies (no event is recorded behind a copy)
 };
 
 // ---- packed pair state (see poppy_hip_ctx::arena) -------------------------------------------------------------------------

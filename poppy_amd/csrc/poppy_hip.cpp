@@ -121,6 +121,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); c->dl_stream = nullptr; }
+    for (hipStream_t& st : c->dl_ring) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     free_slot_preps(c);
     if (c->setup_ev) (void)hipEventDestroy(c->setup_ev);
@@ -445,12 +446,26 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     auto lap = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     std::vector<int> slot_of(n, -1);
     int issued = 0;                                               // downloads queued so far (frames 0 .. issued-1)
+    // Round 6: a frame copy goes to the stream of its pinned ring buffer, which carries nothing else, and NO event is recorded behind it — whoever needs the copy
+    // finished synchronises that stream.  An event record behind a copy is a marker packet that waits, in one of the process's four hardware queues, for the copy's
+    // signal, and every kernel of every stream mapped to that queue waits with it for the length of a frame copy (~120 us): a pool of six with the writer 6.2 -> 6.6-6.9k
+    // frames/s (7.4-7.6k on the runtime bundled with torch), one context 5.2 -> 5.4k, the 480-frame phase-mode job 6.0-6.2 -> 7.2-7.5k (profiles/r06_dl_streams.txt).
+    // POPPY_HIP_DL_EVENTS=1: one download stream + an event per copy, as until round 5.
+    static const bool dl_streams = getenv("POPPY_HIP_DL_EVENTS") == nullptr && !dev_wait;
     auto issue_download = [&](int k) -> bool {
         FrameSlot& f = c->slots[slot_of[k]];
         const int r = k % R;
         const auto t0 = clk::now();
         hipError_t e = dev_wait ? hipStreamWaitEvent(c->dl_stream, f.done, 0) : hipEventSynchronize(f.done);
         ms_done += lap(t0);
+        if (dl_streams) {
+            if (e == hipSuccess && !c->dl_ring[r]) e = hipStreamCreateWithFlags(&c->dl_ring[r], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_stage + (size_t)r * slot_bytes, f.out, frame_bytes, hipMemcpyDeviceToHost, c->dl_ring[r]);
+            f.dl_pending = true; f.dl_ring_idx = r;
+            if (e != hipSuccess) { c->err = std::string("frame download: ") + hipGetErrorString(e); rc = POPPY_E_DEVICE; return false; }
+            return true;
+        }
+        f.dl_ring_idx = -1;
 #ifdef POPPY_EXPERIMENTS
         static const bool skip_copy = getenv("POPPY_DL_SKIP_COPY") != nullptr;      // timing experiment: every wait and event of the writer path, no bytes moved (wrong frames)
         if (!skip_copy)
@@ -465,7 +480,7 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     auto deliver = [&](int k) -> bool {
         const int rr = k % R;
         const auto t0 = clk::now();
-        if (hipEventSynchronize(c->dl_done[rr]) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; return false; }
+        if ((dl_streams ? hipStreamSynchronize(c->dl_ring[rr]) : hipEventSynchronize(c->dl_done[rr])) != hipSuccess) { c->err = "frame download failed"; rc = POPPY_E_DEVICE; return false; }
         ms_deliver += lap(t0);
         write(user, c->h_stage + (size_t)rr * slot_bytes, W, H, row);
         ++written;
@@ -786,7 +801,14 @@ static int render_slot(poppy_hip_ctx* c, int fi, bool chain) {
     ++(bin_warp ? c->n_warp_bin : fast_warp ? c->n_warp_fast : c->n_warp_general);
     // a frame of this slot may still be on its way to the writer (the ring only orders the HOST side): nothing may render into
     // `out` before that copy has read it
-    if (f.dl_pending) { HIPCHK(c, waited(c->wait_ms[0], f.downloaded)); f.dl_pending = false; }
+    if (f.dl_pending) {
+        if (f.dl_ring_idx >= 0) {                                  // (POPPY_HIP_DL_STREAMS: the copy's own stream instead of an event)
+            const auto t0 = std::chrono::steady_clock::now();
+            HIPCHK(c, hipStreamSynchronize(c->dl_ring[f.dl_ring_idx]));
+            c->wait_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else HIPCHK(c, waited(c->wait_ms[0], f.downloaded));
+        f.dl_pending = false;
+    }
     const bool all_marks = c->timing == 1;
     Timer tm(c, s);
     if (all_marks) tm.mark(nullptr);
