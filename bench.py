@@ -553,6 +553,13 @@ def bench_single(args, torch, capi, dev, local):
     plain = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
     plain.morph_pairs_device_counted(ptrs, W, H, -1.0)                    # allocates
     n_plain, dt_plain, _ = timed_region(plain, False)
+    # the same pairs handed to the pool in ONE call (informational, not `value`): the contexts take pairs off a shared counter and run out of step — one pair's set-up
+    # beside other pairs' frames — where the bench's steps start six set-ups together and then render together
+    torch.cuda.synchronize()
+    t1c = time.perf_counter()
+    n_one = plain.morph_pairs_device_counted(ptrs * args.steps, W, H, -1.0)
+    torch.cuda.synchronize()
+    dt_one = time.perf_counter() - t1c
     plain.close()
     pool = capi.Pool([local], contexts_per_device=args.contexts, tuned_for=(W, H), number_of_frames=FRAMES)
     pool_selection = {"candidates_ms_per_batch": [round(x, 2) for x in pool.candidates_ms], "kept": pool.kept, "made_by": "poppy_hip_pool_create_tuned",
@@ -570,6 +577,9 @@ def bench_single(args, torch, capi, dev, local):
         "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "value_unselected": round(n_plain / dt_plain, 2),
+        "pairs_in_one_call": {"fps": round(n_one / dt_one, 2), "pairs": len(ptrs) * args.steps,
+                              "what": "the timed region's pairs (steps x pairs per step) handed to the unselected pool in ONE poppy_hip_pool_morph_pairs call instead of one call per step: "
+                                      "informational — what the step structure (six contexts start six set-ups together, then render together) costs; not `value`"},
         "pool_selection": pool_selection,
         "step_ms": {"min": round(min(step_ms), 3), "median": round(sorted(step_ms)[len(step_ms) // 2], 3), "max": round(max(step_ms), 3),
                     "what": "the timed steps one by one (diagnostic: `value` is all of them over their total time)"},
