@@ -114,6 +114,9 @@ const uint8_t* ForegroundFilter::run_device(const uint8_t* bgr, size_t stride, i
         const int ksize = i * 8 + 1;
         // medianBlur(ksize 1) is a copy: MOG2 reads the grey image itself unless the caller wants every stage plane
         if (ksize <= 1) { if (dbg && dbg->stages) chk(hipMemcpyAsync(med, grey, P, hipMemcpyDeviceToDevice, s), "copy"); else med = grey; }
+        // (The round-5 advisor's note: since the column kernel takes every window this read comes before a single median is queued — a device-to-host round trip with the chain's
+        // stream dry.  Measured in round 6 (profiles/r06_notes.md section 7): letting the first two windows take k_median_u8 while the answer travels costs more than the round trip —
+        // set-up from device images 2.61 against 2.56 ms, the pool the same either way — so the read stays where it is.)
         if (ask_device && ksize >= median_cols_min_ksize()) {
             chk(easy_ev ? hipEventSynchronize(easy_ev) : hipStreamSynchronize(s), "sync");
             const MedianColsGeom g = median_cols_geom(w, h);
