@@ -24,7 +24,7 @@
  *   set-up    POPPY_SETUP_SERIAL, POPPY_SETUP_UPLOAD_BOTH, POPPY_GABOR2_FIRST / _LATE / _AT, POPPY_GABOR_DIRECT, POPPY_ACC_STEPS,
  *             POPPY_MED_SETS / _WAVES, POPPY_MED_COLS_MIN / _MIN_HARD / _FORCE / _ROWS, POPPY_ORB_GUESS / _CAP / _KPCAP (test
  *             forms: short lists that must grow), POPPY_SETUP_TIMING (stderr)
- *   several GPUs  POPPY_HIP_RCCL (path of librccl), POPPY_HIP_SHARD_SETUP, POPPY_HIP_SHARD_WORLD1
+ *   several GPUs  POPPY_HIP_RCCL (path of librccl), POPPY_HIP_SHARD_SETUP, POPPY_HIP_SHARD_WORLD1, POPPY_POOL_SETUPS (pair set-ups side by side per device in a pool: 1 from three contexts on), POPPY_POOL_CHAINS
  * Measurement switches that DO change results (parts of a kernel left out, the Gabor transform without its exactness hand-over:
  * POPPY_MED_COLS_SKIP, POPPY_GABOR_NO_REDO, POPPY_GABOR_BAND, POPPY_DL_SKIP_COPY) and the launch-by-launch A/B of wave priorities
  * (POPPY_STAGGER_AB) exist only in a build made with -DPOPPY_EXPERIMENTS (`python -m poppy_amd.build --experiments` writes

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -612,17 +613,34 @@ int poppy_hip_morph_sharded(const int* devices, int n_devices, const poppy_setti
 struct poppy_hip_pool {
     std::vector<poppy_hip_ctx*> ctx;
     std::vector<int> device_of;
+    // The set-up gate (round 6): at most `setup_gate` contexts of a device run a pair set-up at a time (0: no gate).  A set-up takes the whole GPU whatever runs
+    // beside it; contexts that all start one at once — a batch of as many pairs as contexts — then all render at once, and the copy link idles for the length of
+    // the set-up round; set-ups side by side also slow each other (each takes the whole GPU).  One at a time: a pair's frames stream out while the next pair sets up.
+    int setup_gate = 0, contexts_per_device = 1;
+    std::mutex gate_mu;
+    std::condition_variable gate_cv;
+    std::map<int, int> setups_running;           // per device
 };
 
 poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
                                       char* err, size_t err_len) {
     if (!devices || n_devices < 1 || n_devices > 64 || contexts_per_device < 1 || contexts_per_device > 16) { set_err(err, err_len, "bad arguments"); return nullptr; }
     poppy_hip_pool* p = new poppy_hip_pool();
+    p->contexts_per_device = contexts_per_device;
+    {   // POPPY_POOL_SETUPS: set-ups side by side per device (0 = as many as contexts).  Default from three contexts on: ONE — six contexts, 36 pairs in one call 7.0-7.5k -> 7.8k
+        // frames/s, four contexts 7.0-7.2k -> 7.4k, the bench's batches of six pairs 6.3-6.6k -> 6.7k; two or three at a time: in between (profiles/r06_gate.txt)
+        static const int forced = getenv("POPPY_POOL_SETUPS") ? atoi(getenv("POPPY_POOL_SETUPS")) : -1;
+        p->setup_gate = forced >= 0 ? forced : (contexts_per_device >= 3 ? 1 : 0);
+        if (p->setup_gate >= contexts_per_device) p->setup_gate = 0;
+    }
     for (int d = 0; d < n_devices; ++d)
         for (int k = 0; k < contexts_per_device; ++k) {
             poppy_hip_ctx* c = poppy_hip_create(devices[d], settings);
             if (!c) { set_err(err, err_len, std::string("poppy_hip_create: ") + poppy_hip_create_error()); poppy_hip_pool_destroy(p); return nullptr; }
-            c->setup_serial = contexts_per_device >= 3;           // (pair_setup.cpp: with three set-ups side by side the chains of a pair run one after the other)
+            // (pair_setup.cpp: from three contexts on the chains of a pair run one after the other — six chains on four hardware queues were a lottery, profiles/r05_notes.md
+            // section 6; still the better form behind the set-up gate: profiles/r06_gate.txt; POPPY_POOL_CHAINS=0 / 1 forces side by side / serial)
+            static const int chains_env = getenv("POPPY_POOL_CHAINS") ? atoi(getenv("POPPY_POOL_CHAINS")) : -1;
+            c->setup_serial = chains_env >= 0 ? chains_env != 0 : contexts_per_device >= 3;
             p->ctx.push_back(c); p->device_of.push_back(devices[d]);
         }
     return p;
@@ -663,7 +681,17 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, dou
             } : (poppy_write_cb) nullptr;
             if (rc == POPPY_OK && !inputs_on_device) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
             else if (rc == POPPY_OK) {                              // the same call sequence on images that are already in this GPU's memory
+                const int dev = p->device_of[wk];
+                if (p->setup_gate > 0) {
+                    std::unique_lock<std::mutex> g(p->gate_mu);
+                    p->gate_cv.wait(g, [&] { return p->setups_running[dev] < p->setup_gate; });
+                    ++p->setups_running[dev];
+                }
                 rc = poppy_hip_pair_begin_device(c, a, b, W, H);
+                if (p->setup_gate > 0) {
+                    { std::lock_guard<std::mutex> g(p->gate_mu); --p->setups_running[dev]; }
+                    p->gate_cv.notify_all();
+                }
                 if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_UNSUPPORTED, "no point pairs: the fallback needs the images on the host (poppy_hip_morph)");
                 if (rc == POPPY_OK) rc = poppy_hip_morph_frames(c, phase, cb, &relay);
             }
