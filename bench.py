@@ -535,7 +535,7 @@ def bench_single(args, torch, capi, dev, local):
     # `value` is measured on the pool the LIBRARY hands out through poppy_hip_pool_create_tuned: its start-up check (about one pool in ten comes out 10 - 25 % slower on
     # every step for as long as it lives: DESIGN.md section 5, `step_ms`; up to three pools, a calibration batch each, the fastest kept) is product behaviour, not a pick
     # made by this script.  `value_unselected` is the same timed region on a pool from plain poppy_hip_pool_create — the first pool made, no check.
-    def timed_region(pool_, timing):
+    def timed_region(pool_, timing, ptrs=ptrs):
         for _ in range(args.warmup):
             pool_.morph_pairs_device_counted(ptrs, W, H, -1.0)
         if timing:
@@ -705,6 +705,23 @@ def bench_single(args, torch, capi, dev, local):
             "frame": mid, "equal": bool(np.array_equal(kept.get(mid), want)),
             "what": f"frame {mid} (t = {float(ph480[mid])}) of the {TOTAL}-frame job as handed to a writer vs the oracle's phase-mode frame from the same pair state"}
     out["scaling_baseline_480"]["predicted_speedup"] = predicted_speedups(dt480 / r480 * 1e3, out["pair_setup_ms"], capi.pair_state_bytes(W, H))
+    # the headline's step on photographs (round-5 review): six pairs = the reference's own sample pair (images/amir1.jpg / amir2.jpg, committed as pixels, upscaled in
+    # integers) six times — pairs are independent —, the same pool form, the same number of steps; outside `value`'s timed region
+    try:
+        from poppy_amd import synth as _synth
+        pa, pb = _synth.photo_pair(W, H)
+        tpa, tpb = torch.from_numpy(pa).to(dev), torch.from_numpy(pb).to(dev)
+        pptrs = [(tpa.data_ptr(), tpb.data_ptr())] * PAIRS
+        ppool = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
+        ppool.morph_pairs_device_counted(pptrs, W, H, -1.0)
+        nph, dph, _ = timed_region(ppool, False, pptrs)
+        ppool.close()
+        out["value_photo"] = {"fps": round(nph / dph, 2), "ms_per_step": round(dph / args.steps * 1e3, 3),
+                              "what": f"`value`'s step ({PAIRS} pairs x (set-up + {FRAMES} chained frames + writer), {args.contexts} contexts, a pool from plain poppy_hip_pool_create: compare `value_unselected`) "
+                                      "on the reference's sample photographs instead of the synthetic shapes: their medians stay on k_median_u8 (set-up ~4.0 ms against ~2.6)"}
+        del tpa, tpb
+    except Exception as e:      # (the fixture is data under tests/golden; a tree without it still benches)
+        out["value_photo"] = {"error": str(e)}
     # the headline step once more with the raw pairs copied from pinned host memory inside the step (the reference's morph() takes host images)
     pinned = [(torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory()) for a, b in pairs_host]
     pool2 = capi.Pool([local], contexts_per_device=args.contexts, number_of_frames=FRAMES)
