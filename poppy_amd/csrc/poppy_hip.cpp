@@ -21,6 +21,8 @@
 
 static std::string g_create_error;
 static void free_slot_preps(poppy_hip_ctx* c);
+static void stop_seq_plans(poppy_hip_ctx* c);
+void start_default_seq_plans(poppy_hip_ctx* c);
 static void drop_slot_preps(poppy_hip_ctx* c);
 
 // Streams and hardware queues.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable
@@ -123,6 +125,7 @@ void poppy_hip_destroy(poppy_hip_ctx* c) {
     if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); c->dl_stream = nullptr; }
     for (hipStream_t& st : c->dl_ring) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    stop_seq_plans(c);
     free_slot_preps(c);
     if (c->setup_ev) (void)hipEventDestroy(c->setup_ev);
     if (c->c2_up_ev) (void)hipEventDestroy(c->c2_up_ev);
@@ -273,7 +276,9 @@ int set_points(poppy_hip_ctx* c, const float* p1, const float* p2, int n) {
     c->pts1_0.resize(n); c->pts2.resize(n);
     if (n) { memcpy(c->pts1_0.data(), p1, (size_t)n * 8); memcpy(c->pts2.data(), p2, (size_t)n * 8); }
     c->pts1 = c->pts1_0;
-    return ensure_ring(c, n);
+    const int rc = ensure_ring(c, n);
+    if (rc == POPPY_OK) start_default_seq_plans(c);                // (the previous pair's plans, if a call never took them, are dropped in there)
+    return rc;
 }
 
 int finish_pair_load(poppy_hip_ctx* c) {
@@ -377,12 +382,38 @@ static int render_frame(poppy_hip_ctx* c, double shape, double mask, bool chain)
 // triangulation and matrix work of the frames is independent once each frame's input points are known.
 constexpr int kPlanThrew = -1000;          // rcs[] marker: the planner of that frame threw
 
-static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* mask, int n, bool chain, poppy_write_cb write, void* user) {
-    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
-    if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
-    if (n <= 0) return POPPY_OK;
+// The plans of one multi-frame call, made by the context's planner team.  They live on the heap because the team may be started BEFORE the call that consumes them
+// (round 6): a pair loader starts the plans of the reference's default sequence — number_of_frames chained frames, src/poppy.hpp:177-210 — the moment the point pairs are
+// known, while the set-up's last kernels and copies still run; poppy_hip_morph_frames then finds its first plans ready instead of idling the GPU for the 0.3-0.5 ms the
+// first plan takes (one context, pair after pair: 4 % of a pair).  A call with other frames drops them (the planners stop at their next frame) and makes its own.
+struct SeqPlans {
+    int n = 0, W = 0, H = 0;
+    bool chain = false;
+    std::vector<double> shape;
+    std::vector<P2f> pts1_at_start, pts2;                      // the point sets the plans were made from (a call adopts them only for the same ones)
+    std::vector<std::vector<P2f>> src1;
+    std::vector<FramePlan> plans;
+    std::vector<int> rcs;
+    std::vector<std::atomic<int>> ready;
+    std::atomic<int> next{0};
+    explicit SeqPlans(int n_) : n(n_), src1(n_), plans(n_), rcs(n_, 0), ready(n_) { for (auto& r : ready) r.store(0); }
+};
+static bool same_points(const std::vector<P2f>& a, const std::vector<P2f>& b) {           // bit for bit
+    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(P2f)) == 0);
+}
+static void stop_seq_plans(poppy_hip_ctx* c) {
+    SeqPlans* sp = static_cast<SeqPlans*>(c->seq_plans);
+    if (!sp) return;
+    sp->next.store(sp->n);                                         // the planners stop at their next frame
+    (void)c->planners.wait();
+    delete sp;
+    c->seq_plans = nullptr;
+}
+static SeqPlans* start_seq_plans(poppy_hip_ctx* c, const double* shape, int n, bool chain) {
     const int W = c->W, H = c->H;
-    std::vector<std::vector<P2f>> src1(n);
+    SeqPlans* sp = new SeqPlans(n);
+    sp->W = W; sp->H = H; sp->chain = chain; sp->shape.assign(shape, shape + n); sp->pts1_at_start = c->pts1; sp->pts2 = c->pts2;
+    std::vector<std::vector<P2f>>& src1 = sp->src1;
     src1[0] = c->pts1;
     if (chain)
         for (int j = 0; j + 1 < n; ++j) {                            // morph_points + clip_points of frame j
@@ -397,30 +428,57 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
             }
             clip_points_ref(m, W, H);
         }
-    std::vector<FramePlan> plans(n);
-    std::vector<int> rcs(n, 0);
-    std::vector<std::atomic<int>> ready(n);
-    for (auto& r : ready) r.store(0);
-    std::atomic<int> next{0};
     // planner threads of this call: at most 16, and the contexts alive in this process share the host's threads between them (a pool of 3 contexts
     // x 8 devices would otherwise park ~400 planner threads; the planners of one context keep up with its GPU from ~4 threads: 0.3 ms per plan)
     const int alive = std::max(1, g_live_contexts.load());
     const int share = std::max(4, ((int)std::thread::hardware_concurrency() - 1) / alive);
     const int nthreads = std::max(1, std::min({n, 16, share, (int)std::thread::hardware_concurrency() - 1}));
     const int bin_tw = warp_bin_geometry(W, H) ? warp_bin_tile_width(W, H) : 0;
-    auto worker = [&]() {
+    const size_t bins_cap = c->bins_cap;
+    auto worker = [sp, W, H, bin_tw, bins_cap, chain]() {
         for (;;) {
-            const int j = next.fetch_add(1);
-            if (j >= n) return;
+            const int j = sp->next.fetch_add(1);
+            if (j >= sp->n) return;
             // a planner that throws (std::bad_alloc is the case that can happen) must still publish its frame: the calling thread spins on ready[j]
             try {
-                rcs[j] = plan_frame(W, H, chain ? src1[j] : src1[0], c->pts2, shape[j], plans[j]);
-                if (!rcs[j] && bin_tw) build_tile_bins(plans[j], W, H, bin_tw, 1024 / bin_tw, c->bins_cap);
-            } catch (...) { rcs[j] = kPlanThrew; }
-            ready[j].store(1, std::memory_order_release);
+                sp->rcs[j] = plan_frame(W, H, chain ? sp->src1[j] : sp->src1[0], sp->pts2, sp->shape[j], sp->plans[j]);
+                if (!sp->rcs[j] && bin_tw) build_tile_bins(sp->plans[j], W, H, bin_tw, 1024 / bin_tw, bins_cap);
+            } catch (...) { sp->rcs[j] = kPlanThrew; }
+            sp->ready[j].store(1, std::memory_order_release);
         }
     };
     c->planners.run(nthreads, worker);                            // persistent threads (worker.h): parked between calls
+    c->seq_plans = sp;
+    return sp;
+}
+// a pair loader's speculative start (set_points): the reference's default sequence on the new pair
+void start_default_seq_plans(poppy_hip_ctx* c) {
+    static const bool off = getenv("POPPY_HIP_NO_PLAN_AHEAD") != nullptr;
+    stop_seq_plans(c);
+    const int N = c->cfg.number_of_frames;
+    if (off || N < 2 || c->pts1.empty() || c->debug) return;
+    std::vector<double> ratio(N);
+    for (int j = 0; j < N; ++j) ratio[j] = poppy_frame_ratio(j, N, -1.0);
+    start_seq_plans(c, ratio.data(), N, true);
+}
+
+static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* mask, int n, bool chain, poppy_write_cb write, void* user) {
+    if (!c->pair_ready) return fail(c, POPPY_E_STATE, "no pair loaded");
+    if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
+    if (n <= 0) return POPPY_OK;
+    const int W = c->W, H = c->H;
+    // the plans a pair loader started for exactly these frames on exactly these points, or new ones
+    SeqPlans* sp = static_cast<SeqPlans*>(c->seq_plans);
+    if (!(sp && sp->n == n && sp->chain == chain && sp->W == W && sp->H == H && same_points(sp->pts1_at_start, c->pts1) && same_points(sp->pts2, c->pts2) &&
+          std::equal(shape, shape + n, sp->shape.begin()))) {
+        stop_seq_plans(c);
+        sp = start_seq_plans(c, shape, n, chain);
+    }
+    std::vector<std::vector<P2f>>& src1 = sp->src1;
+    std::vector<FramePlan>& plans = sp->plans;
+    std::vector<int>& rcs = sp->rcs;
+    std::vector<std::atomic<int>>& ready = sp->ready;
+    std::atomic<int>& next = sp->next;
     int rc = POPPY_OK;
     const size_t row = (size_t)W * 3, frame_bytes = row * H;
     static const int ring_pref = getenv("POPPY_HIP_RING") ? std::max(1, atoi(getenv("POPPY_HIP_RING"))) : 3;
@@ -534,6 +592,8 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     drop_slot_preps(c);                    // (a frame prepared ahead and never rendered — an error exit — must not meet a later call)
     next.store(n);                         // on an error: let the workers drain
     if (!c->planners.wait() && rc == POPPY_OK) rc = fail(c, POPPY_E_DEVICE, ("frame planner thread: " + c->planners.error()).c_str());
+    delete sp;
+    c->seq_plans = nullptr;
     if (seq_times)
         fprintf(stderr, "sequence of %d frames: %.2f ms; waiting for plans %.2f, submit_frame %.2f (of which waiting for: the slot's download %.2f, its pinned plan %.2f, "
                 "its last frame %.2f, upload + expansion %.2f), waiting for frames to finish %.2f, waiting for downloads %.2f ms\n",
