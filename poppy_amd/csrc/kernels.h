@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -32,6 +33,16 @@ inline hipError_t copy_rows_async(void* dst, size_t dpitch, const void* src, siz
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
 }
 
+// an integer measurement switch that exists only in a -DPOPPY_EXPERIMENTS build (kernels_prefilter.h: poppy_experiment_env); 0 in the shipped library
+inline int poppy_experiment_env_i(const char* name) {
+#ifdef POPPY_EXPERIMENTS
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 // Wave-priority stagger (pyramid_device.h: stagger_priority): the kernel argument for kernel `bit` of POPPY_STAGGER
 int stagger_flag(int bit);
 

@@ -615,8 +615,10 @@ __device__ __forceinline__ float median_of_cols(const Col3& a, const Col3& b, co
 }
 
 __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ src, uint8_t* __restrict__ out, float* __restrict__ outF,
-                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int SP, int stagger) {
+                                                      int W, int H, float amount_arg, const float* __restrict__ amount_ptr, double norm2_min, int SP, int stagger, int dbg) {
+    // dbg (POPPY_UNSHARP_SKIP, a -DPOPPY_EXPERIMENTS build only; 0 otherwise): phases left out for timing — 1 row pass, 2 column pass, 4 the last phase's arithmetic, 8 the source loads, 16 the stores (wrong frames)
     // SP: pixels per row of src (the blended level 0: PyrLevel::pitch); the frame goes out tight
+    if (dbg == 63) return;                                          // (timing: the launch alone)
     const float amount = amount_ptr ? *amount_ptr : amount_arg;     // per-frame value kept in HBM when the launch is a graph node
     __shared__ __attribute__((aligned(16))) float S[kUSy * kUSs];
     __shared__ __attribute__((aligned(16))) float R[kUSy * kURs];
@@ -629,7 +631,9 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     const int tx0 = tile_x * kUTx, ty0 = tile_y * kUTy;
     // 1. stage: S(r, u(col, c)) = src(reflect(ty0 - 5 + r), reflect(tx0 - 5 + col))
     const bool interior = (SP & 3) == 0 && tx0 >= 8 && tx0 + 38 <= W && ty0 >= 5 && ty0 + kUTy + 5 <= H;
-    if (interior) {
+    if (dbg & 8) {                                              // (timing: no source loads)
+        for (int i = tid; i < kUSy * kUSs; i += 256) S[i] = (float)i * 1e-4f;
+    } else if (interior) {
         const float* base = src + ((size_t)(ty0 - 5) * SP + (tx0 - 5)) * 3 - 1;     // 16-byte aligned: SP % 4 == 0, tx0 % 32 == 0
         for (int i = tid; i < kUSy * 32; i += 256) {
             const int r = i >> 5, v = i & 31;
@@ -646,7 +650,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     }
     __syncthreads();
     // 2. row pass.  R(r, u) = sum_k S(r, u - 12 + 3k) * g[k] for u in [13, 115); a thread takes 6 neighbouring u.
-    for (int i = tid; i < kUSy * 18; i += 256) {
+    for (int i = tid; i < kUSy * 18 && !(dbg & 1); i += 256) {
         const int r = i / 18, m = i - r * 18;
         // volatile: kept as 8-byte reads.  Merged into ds_read2_b64 they take twice the LDS cycles (2 x 4 groups of 16 lanes on a
         // 32-bank map instead of 2 groups of 32 on 64 banks each: MI355X_MICROARCH, LDS)
@@ -671,7 +675,7 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
     static_assert(26 * (kUDy / 2) <= 256, "one item per thread: the results wait in registers for the barrier below");
     {
         const int i = tid;
-        const bool has = i < 26 * (kUDy / 2);
+        const bool has = i < 26 * (kUDy / 2) && !(dbg & 2);
         const int qi = i / 26, t = i - qi * 26;
         const int u0 = 12 + 4 * t, q0 = 2 * qi;
         f4 dd[2];
@@ -703,6 +707,8 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
             const int ly = (tid >> 4) + 16 * it, pi = tid & 15;
             const int x0 = tx0 + 2 * pi, y = ty0 + ly;
             if ((kEdge && x0 >= W) || y >= H) continue;
+            if (dbg & 16) { if (S[tid] == 12345.f) out[tid] = 1; continue; }                     // (timing: no stores)
+            if (dbg & 4) { uint16_t* o16 = (uint16_t*)(out + ((size_t)y * W + x0) * 3); o16[0] = (uint16_t)tid; o16[1] = 0; o16[2] = 0; continue; }
             const bool has1 = !kEdge || x0 + 1 < W;
             const int qm = y > 0 ? ly : ly + 1, qc = ly + 1, qp = y < H - 1 ? ly + 2 : ly + 1;     // D rows
             f2 a[7], b[7], c[7];
@@ -731,10 +737,19 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
                 d1[ch] = median_of_cols(cB, cC, cD);
             }
             float v[6] = {sv[0], sv[1], sv[2], sv[3], sv[4], sv[5]};
-            const double n0 = (double)d0[0] * (double)d0[0] + (double)d0[1] * (double)d0[1] + (double)d0[2] * (double)d0[2];
-            const double n1 = (double)d1[0] * (double)d1[0] + (double)d1[1] * (double)d1[1] + (double)d1[2] * (double)d1[2];
-            if (n0 >= norm2_min) { v[0] = v[0] + amount * d0[0]; v[1] = v[1] + amount * d0[1]; v[2] = v[2] + amount * d0[2]; }
-            if (n1 >= norm2_min) { v[3] = v[3] + amount * d1[0]; v[4] = v[4] + amount * d1[1]; v[5] = v[5] + amount * d1[2]; }
+            // |d|^2 >= norm2_min (the double sum of squares against the smallest double whose square root reaches the threshold).  As in k_unsharp_stream the float sum
+            // decides unless it lies within 1e-6 of the bound (its error is below 3e-7 relative); only a wave that holds such a pixel forms the doubles (round 6: the ten
+            // double-precision operations per thread were a quarter of this phase's arithmetic)
+            const float t2f = (float)norm2_min;
+            const float f0 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2], f1 = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+            bool sh0 = f0 > t2f, sh1 = f1 > t2f;
+            if (__builtin_amdgcn_ballot_w64(fabsf(f0 - t2f) <= t2f * 1e-6f || fabsf(f1 - t2f) <= t2f * 1e-6f) != 0) {
+                const double n0 = (double)d0[0] * (double)d0[0] + (double)d0[1] * (double)d0[1] + (double)d0[2] * (double)d0[2];
+                const double n1 = (double)d1[0] * (double)d1[0] + (double)d1[1] * (double)d1[1] + (double)d1[2] * (double)d1[2];
+                sh0 = n0 >= norm2_min; sh1 = n1 >= norm2_min;
+            }
+            if (sh0) { v[0] = v[0] + amount * d0[0]; v[1] = v[1] + amount * d0[1]; v[2] = v[2] + amount * d0[2]; }
+            if (sh1) { v[3] = v[3] + amount * d1[0]; v[4] = v[4] + amount * d1[1]; v[5] = v[5] + amount * d1[2]; }
             const size_t p = ((size_t)y * W + x0) * 3;
             uint32_t o[6];
             // convertTo(CV_8U, 255): v * 255 + 0; the "+ 0" only turns -0 into +0, which rounds to the same byte
@@ -743,7 +758,15 @@ __global__ void __launch_bounds__(256) k_unsharp_tile(const float* __restrict__ 
             const int nv = has1 ? 6 : 3;
             if (outF)
                 for (int k = 0; k < nv; ++k) outF[p + k] = v[k];
-            if (has1 && !(p & 1)) {                                 // the usual case (even W): three aligned 16-bit stores
+            if (!kEdge && !(W & 3) && !outF) {
+                // tiles inside the image, rows of a multiple of 4 pixels (round 6): two neighbouring lanes hold 12 bytes = three dwords that begin on a dword — the even lane
+                // stores the first two (its six bytes + the neighbour's first two, fetched by a DPP swap inside the lane pair), the odd lane the third.  One store per lane
+                // instead of three 16-bit ones: the stores were 3.9 us of the kernel's 23.5 at 1080p (tools/experiments/unsharp_skip.sh)
+                const uint32_t lo32 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), hi16 = o[4] | (o[5] << 8);
+                const uint32_t nb_lo16 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(lo32 & 0xffffu), 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]: the pair's other lane
+                if (!(pi & 1)) *(uint2*)(out + p) = make_uint2(lo32, hi16 | (nb_lo16 << 16));
+                else *(uint32_t*)(out + p + 2) = (lo32 >> 16) | (hi16 << 16);
+            } else if (has1 && !(p & 1)) {                          // (even W): three aligned 16-bit stores
                 uint16_t* o16 = (uint16_t*)(out + p);
                 o16[0] = (uint16_t)(o[0] | (o[1] << 8)); o16[1] = (uint16_t)(o[2] | (o[3] << 8)); o16[2] = (uint16_t)(o[4] | (o[5] << 8));
             } else {
@@ -777,9 +800,10 @@ void launch_unsharp(const float* src, float* tmpRow, float* diff, uint8_t* out_u
             while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
         }
         static const bool tile_only = getenv("POPPY_UNSHARP_TILE") != nullptr;
+        static const int unsharp_dbg = poppy_experiment_env_i("POPPY_UNSHARP_SKIP");
         if (!tile_only && unsharp_stream_eligible(w, h)) { launch_unsharp_stream(src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, s, done, src_pitch); return; }
         dim3 grid(((w + kUTx - 1) / kUTx) * ((h + kUTy - 1) / kUTy));
-        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, src_pitch, stagger_flag(1));
+        hipExtLaunchKernelGGL(k_unsharp_tile, grid, dim3(256), 0, s, nullptr, done, 0, src, out_u8, out_f32_or_null, w, h, amount, d_amount, x, src_pitch, stagger_flag(1), unsharp_dbg);
         return;
     }
     dim3 ge((w * 3 + 255) / 256, h), gp((w + 255) / 256, h);
