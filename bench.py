@@ -535,7 +535,11 @@ def bench_single(args, torch, capi, dev, local):
     # `value` is measured on the pool the LIBRARY hands out through poppy_hip_pool_create_tuned: its start-up check (about one pool in ten comes out 10 - 25 % slower on
     # every step for as long as it lives: DESIGN.md section 5, `step_ms`; up to three pools, a calibration batch each, the fastest kept) is product behaviour, not a pick
     # made by this script.  `value_unselected` is the same timed region on a pool from plain poppy_hip_pool_create — the first pool made, no check.
-    def timed_region(pool_, timing, ptrs=ptrs):
+    # A step = one batch of PAIRS pairs handed to the pool.  queued (the headline since round 6): the K steps are SUBMITTED one after the other
+    # (poppy_hip_pool_submit_pairs returns at once, as a training step's launches do) and the timed region ends with poppy_hip_pool_wait + synchronize — every frame of
+    # every step handed to the writer; the pool takes the batches up in order, so a step's last pairs render beside the next step's first set-ups.  not queued
+    # (`value_step_synchronous`, the headline's definition up to round 5): every step waits for its own last frame before the next is handed in.
+    def timed_region(pool_, timing, ptrs=ptrs, queued=True):
         for _ in range(args.warmup):
             pool_.morph_pairs_device_counted(ptrs, W, H, -1.0)
         if timing:
@@ -545,8 +549,13 @@ def bench_single(args, torch, capi, dev, local):
         n_, per_step = 0, []
         for _ in range(args.steps):
             ts0 = time.perf_counter()
-            n_ += pool_.morph_pairs_device_counted(ptrs, W, H, -1.0)      # returns after every frame of the batch was handed to the writer
-            per_step.append((time.perf_counter() - ts0) * 1e3)
+            if queued:
+                pool_.submit_pairs_device_counted(ptrs, W, H, -1.0)
+            else:
+                n_ += pool_.morph_pairs_device_counted(ptrs, W, H, -1.0)  # returns after every frame of the batch was handed to the writer
+                per_step.append((time.perf_counter() - ts0) * 1e3)
+        if queued:
+            n_ = pool_.wait()                                             # every frame of every step has been handed to the writer
         torch.cuda.synchronize()
         return n_, time.perf_counter() - t0_, per_step
 
@@ -564,9 +573,10 @@ def bench_single(args, torch, capi, dev, local):
     pool = capi.Pool([local], contexts_per_device=args.contexts, tuned_for=(W, H), number_of_frames=FRAMES)
     pool_selection = {"candidates_ms_per_batch": [round(x, 2) for x in pool.candidates_ms], "kept": pool.kept, "made_by": "poppy_hip_pool_create_tuned",
                       "what": "pools the library made at start-up and timed on its built-in calibration batch (two pairs per context, twice); the fastest is the pool"}
-    written, dt, step_ms = timed_region(pool, True)
+    written, dt, _ = timed_region(pool, True)
     warp_ms, warp_n = next(((ms, c) for nm, ms, c in pool.timing_summary() if nm == "warp"), (0.0, 0))
     pool.set_timing(0)
+    n_sync, dt_sync, step_ms = timed_region(pool, False, queued=False)
     assert written == args.steps * PAIRS * FRAMES, (written, args.steps * PAIRS * FRAMES)
     fps = written / dt
     roof = roofline_of(pool, warp_ms, warp_n, W, H)
@@ -577,12 +587,16 @@ def bench_single(args, torch, capi, dev, local):
         "value": round(fps, 2), "unit": "frames/s", "mpix_per_s": round(fps * P / 1e6, 1),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "value_unselected": round(n_plain / dt_plain, 2),
+        "value_step_synchronous": {"fps": round(n_sync / dt_sync, 2), "ms_per_step": round(dt_sync / args.steps * 1e3, 3),
+                                   "what": "the same pool, the same steps, but every step waits for its own last frame before the next batch is handed in "
+                                           "(poppy_hip_pool_morph_pairs per step): `value`'s definition up to round 5 — the contexts then start every step with a round of "
+                                           "set-ups together; `value` queues the steps (poppy_hip_pool_submit_pairs) and waits once, at the end of the timed region"},
         "pairs_in_one_call": {"fps": round(n_one / dt_one, 2), "pairs": len(ptrs) * args.steps,
                               "what": "the timed region's pairs (steps x pairs per step) handed to the unselected pool in ONE poppy_hip_pool_morph_pairs call instead of one call per step: "
-                                      "informational — what the step structure (six contexts start six set-ups together, then render together) costs; not `value`"},
+                                      "informational — the pool without any step structure; not `value`"},
         "pool_selection": pool_selection,
         "step_ms": {"min": round(min(step_ms), 3), "median": round(sorted(step_ms)[len(step_ms) // 2], 3), "max": round(max(step_ms), 3),
-                    "what": "the timed steps one by one (diagnostic: `value` is all of them over their total time)"},
+                    "what": "the steps of `value_step_synchronous` one by one (diagnostic; the queued steps of `value` have no ends of their own)"},
         "timed_region_s": round(dt, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "scaling_note": "the --gpus N lines shard ONE fixed 480-frame 1080p morph by frame range (total work fixed: strong); the N = 1 point of that series is "
@@ -595,7 +609,7 @@ def bench_single(args, torch, capi, dev, local):
                         "(null: a bench run outside that script — then roofline.from_profiles quotes the committed profiles of another run, its own run_id says which)"},
         "config": {"workload": f"{W}x{H} pairs, {FRAMES}-frame morph each, default chained mode (BASELINE.json configs[1]): per step {PAIRS} pairs x "
                                "(pair set-up from the raw images + 60 chained frames handed to a writer through pinned host memory), pyramid_levels 64",
-                   "pairs_per_step": PAIRS, "contexts": args.contexts, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
+                   "pairs_per_step": PAIRS, "steps_queued": True, "contexts": args.contexts, "frames_per_pair": FRAMES, "mode": "chain", "includes": ["pair set-up", "frame loop", "writer hand-off (D2H)"],
                    "parallelism": "1 GPU"},
         "roofline": roof,
     }
@@ -744,7 +758,7 @@ def bench_single(args, torch, capi, dev, local):
             da.copy_(ha, non_blocking=True); db.copy_(hb, non_blocking=True)
         torch.cuda.synchronize()
     out["h2d"] = {"value_incl_h2d": round(kh / dth, 1), "h2d_ms_per_pair": round((time.perf_counter() - t1) / rh / PAIRS * 1e3, 3),
-                  "what": "`value`'s step with the raw pairs (2 x %.1f MB each) copied host -> device inside the step, serially before the pool starts; the timed region of `value` starts with them resident in HBM" % (P * 3 / 1e6)}
+                  "what": "the step of `value_step_synchronous` (compare with that figure) with the raw pairs (2 x %.1f MB each) copied host -> device inside the step, serially before the pool starts; the timed region of `value` starts with them resident in HBM" % (P * 3 / 1e6)}
     pool2.close()
     out["config"]["workload"] += (f"; the {PAIRS} pairs of a step are rendered by a pool of {args.contexts} contexts (pooled headline); the same step on ONE context, "
                                   f"pair after pair, runs at sequential_fps = {out['sequential_fps']} frames/s")

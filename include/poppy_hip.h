@@ -375,6 +375,14 @@ poppy_hip_pool* poppy_hip_pool_create_tuned(const int* devices, int n_devices, i
 void poppy_hip_pool_destroy(poppy_hip_pool* pool);
 int poppy_hip_pool_morph_pairs(poppy_hip_pool* pool, int n_pairs, int width, int height, double phase, int inputs_on_device,
                                poppy_pair_source_cb source, poppy_write_pair_cb write, void* user, char* err, size_t err_len);
+/* The same batch without waiting for it: poppy_hip_pool_submit_pairs queues it and returns, poppy_hip_pool_wait returns when every pair submitted so far has been
+ * rendered and written (the first failure's code and message; the pairs queued behind a failure are dropped).  Batches are taken up in order, pair by pair, by
+ * whichever context is free, so the last pairs of one batch render beside the first set-ups of the next — the contexts of a pool fed this way never start a round of
+ * set-ups together (the reference's CLI loop over pairs, src/poppy.cpp:266-328, fed by a service instead of a directory listing).  `source`, `write` and `user` must
+ * stay valid until the wait.  Do not mix with a poppy_hip_pool_morph_pairs call in flight; poppy_hip_pool_destroy renders what is still queued first.        */
+int poppy_hip_pool_submit_pairs(poppy_hip_pool* pool, int n_pairs, int width, int height, double phase, int inputs_on_device,
+                                poppy_pair_source_cb source, poppy_write_pair_cb write, void* user);
+int poppy_hip_pool_wait(poppy_hip_pool* pool, char* err, size_t err_len);
 /* poppy_hip_set_timing / poppy_hip_timing_summary / poppy_hip_warp_counts over all contexts of a pool */
 int poppy_hip_pool_set_timing(poppy_hip_pool* pool, int on);
 int poppy_hip_pool_timing_summary(poppy_hip_pool* pool, const char** names, float* total_ms, int* launches, int max);

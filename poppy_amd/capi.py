@@ -33,7 +33,7 @@ SYMBOLS = [
     "poppy_procrustes", "poppy_perspective_from4", "poppy_hip_pair_corrected2", "poppy_hip_debug_fetch", "poppy_hip_debug_triangles", "poppy_plan_frame",
     "poppy_hip_timing_summary", "poppy_hip_set_timing", "poppy_hip_render_many",
     "poppy_hip_orb_describe", "poppy_hip_hamming_match",
-    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_comm_info", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
+    "poppy_sink_open", "poppy_sink_write", "poppy_sink_close", "poppy_hip_render_phases", "poppy_hip_pool_set_timing", "poppy_hip_pool_timing_summary", "poppy_hip_pool_warp_counts", "poppy_hip_pool_create", "poppy_hip_pool_create_tuned", "poppy_hip_pool_destroy", "poppy_hip_pool_morph_pairs", "poppy_hip_pool_submit_pairs", "poppy_hip_pool_wait", "poppy_count_pair_frames_cb", "poppy_hip_warp_counts", "poppy_hip_time_last_warp", "poppy_hip_mask_rider", "poppy_hip_pool_mask_rider", "poppy_hip_comm_id", "poppy_hip_comm_init", "poppy_hip_comm_free", "poppy_hip_comm_info", "poppy_hip_pair_broadcast", "poppy_hip_comm_max",
     "poppy_hip_pair_begin_sharded", "poppy_hip_sharded_setups", "poppy_hip_pair_begin_sharded_local", "poppy_hip_pair_state_bytes", "poppy_hip_pair_export_device", "poppy_hip_pair_import_device", "poppy_hip_morph_sharded", "poppy_hip_morph_pairs",
     "poppy_dft_plan", "poppy_hip_pair_begin_device", "poppy_count_frames_cb", "poppy_hip_morph", "poppy_hip_pair_distance", "poppy_printed_morph_distance", "poppy_hypotf_selfcheck",
     "poppy_hip_orb_detect", "poppy_hip_foreground", "poppy_hip_median_blur", "poppy_match_points", "poppy_hip_pair_begin_prefiltered", "poppy_hip_pair_begin", "poppy_hip_pair_begin_info", "poppy_hip_orb_input", "poppy_hip_gabor_field", "poppy_hip_set_gabor_direct", "poppy_hip_set_setup_chains", "poppy_hip_gabor_doubt", "poppy_radial_gradient", "poppy_radial_mask", "poppy_gabor_tables", "poppy_pyr_tail_plan", "poppy_hip_blur_margin", "poppy_hip_pair_points",
@@ -129,6 +129,8 @@ def lib():
         L.poppy_hip_pool_timing_summary.argtypes = [vp, vp, vp, vp, i]
         L.poppy_hip_pool_warp_counts.argtypes = [vp, vp, vp, vp]
         L.poppy_hip_pool_morph_pairs.argtypes = [vp, i, i, i, d, i, vp, vp, vp, vp, sz]
+        L.poppy_hip_pool_submit_pairs.argtypes = [vp, i, i, i, d, i, vp, vp, vp]
+        L.poppy_hip_pool_wait.argtypes = [vp, vp, sz]
         L.poppy_hip_comm_id.argtypes = [vp]
         L.poppy_hip_comm_init.argtypes = [vp, i, i, vp]
         L.poppy_hip_comm_free.argtypes = [vp]
@@ -432,6 +434,55 @@ class Pool:
         if rc:
             raise PoppyError(f"poppy_hip_pool_morph_pairs: {rc}: {err.value.decode()}")
         return n.value
+
+    # ---- batches without waiting for them (poppy_hip_pool_submit_pairs / poppy_hip_pool_wait) ----
+    def submit_pairs_device_counted(self, ptr_pairs, w, h, phase=-1.0):
+        """Queues the batch and returns; wait() returns the frames written by every batch submitted since the last wait()."""
+        ptr_pairs = list(ptr_pairs)
+        def src(user, p, device, pa, sa, pb, sb):
+            pa[0] = ptr_pairs[p][0]; sa[0] = w * 3
+            pb[0] = ptr_pairs[p][1]; sb[0] = w * 3
+            return 0
+        fs = PAIR_SOURCE_CB(src)
+        if not hasattr(self, "_pending"):
+            self._pending, self._count = [], C.c_longlong(0)
+        self._pending.append((fs, ptr_pairs))                     # the callbacks stay alive until the wait
+        rc = lib().poppy_hip_pool_submit_pairs(self.h, len(ptr_pairs), w, h, phase, 1, C.cast(fs, C.c_void_p),
+                                               C.cast(lib().poppy_count_pair_frames_cb, C.c_void_p), C.cast(C.byref(self._count), C.c_void_p))
+        if rc:
+            raise PoppyError(f"poppy_hip_pool_submit_pairs: {rc}")
+
+    def submit_pairs(self, pairs, write, phase=-1.0, inputs_on_device=False, w=None, h=None):
+        """pairs: list of (bgr1, bgr2) host arrays — or (pointer 1, pointer 2) device pointers with inputs_on_device, w, h; write(pair, frame, view) is called
+        from the pool's threads.  Returns at once; wait() returns when everything submitted has been written."""
+        if not inputs_on_device:
+            pairs = [(np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)) for a, b in pairs]
+            h, w = pairs[0][0].shape[:2]
+        def src(user, p, device, pa, sa, pb, sb):
+            pa[0] = pairs[p][0] if inputs_on_device else pairs[p][0].ctypes.data; sa[0] = w * 3
+            pb[0] = pairs[p][1] if inputs_on_device else pairs[p][1].ctypes.data; sb[0] = w * 3
+            return 0
+        def wr(user, p, j, ptr, ww, hh, stride):
+            write(p, j, np.ctypeslib.as_array(ptr, shape=(hh, stride))[:, :ww * 3].reshape(hh, ww, 3))
+        fs, fw = PAIR_SOURCE_CB(src), WRITE_PAIR_CB(wr)
+        if not hasattr(self, "_pending"):
+            self._pending, self._count = [], C.c_longlong(0)
+        self._pending.append((fs, fw, pairs))
+        rc = lib().poppy_hip_pool_submit_pairs(self.h, len(pairs), w, h, phase, 1 if inputs_on_device else 0, C.cast(fs, C.c_void_p), C.cast(fw, C.c_void_p), None)
+        if rc:
+            raise PoppyError(f"poppy_hip_pool_submit_pairs: {rc}")
+
+    def wait(self):
+        """Every batch submitted so far has been rendered and written; returns the frames the counting writer saw since the last wait()."""
+        err = C.create_string_buffer(512)
+        rc = lib().poppy_hip_pool_wait(self.h, err, 512)
+        n = 0
+        if hasattr(self, "_pending"):
+            n, self._count.value = self._count.value, 0
+            self._pending.clear()
+        if rc:
+            raise PoppyError(f"poppy_hip_pool_wait: {rc}: {err.value.decode()}")
+        return n
 
 
 def dft_plan(n):

@@ -19,7 +19,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -620,6 +622,21 @@ struct poppy_hip_pool {
     std::mutex gate_mu;
     std::condition_variable gate_cv;
     std::map<int, int> setups_running;           // per device
+    // Batches handed in without waiting for them (poppy_hip_pool_submit_pairs / poppy_hip_pool_wait): one persistent feeder thread per context takes pairs off the
+    // queue's first batch, so a batch's last pairs render beside the next batch's first set-ups — the contexts never start a round of set-ups together.
+    struct Batch {
+        int n_pairs = 0, W = 0, H = 0, inputs_on_device = 0, taken = 0;
+        double phase = -1.0;
+        poppy_pair_source_cb source = nullptr; poppy_write_pair_cb write = nullptr; void* user = nullptr;
+    };
+    std::mutex q_mu;
+    std::condition_variable q_cv, q_idle;
+    std::deque<std::shared_ptr<Batch>> queue;    // batches with pairs nobody has taken yet
+    long long outstanding = 0;                   // pairs submitted and not finished
+    int async_rc = POPPY_OK;                     // the first failure since the last poppy_hip_pool_wait (the pairs behind it are dropped)
+    std::string async_err;
+    std::vector<std::thread> feeders;
+    bool quit = false;
 };
 
 poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
@@ -648,8 +665,49 @@ poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int con
 
 void poppy_hip_pool_destroy(poppy_hip_pool* p) {
     if (!p) return;
+    if (!p->feeders.empty()) {                                     // batches still queued are rendered first (their writers expect every frame)
+        {
+            std::unique_lock<std::mutex> lk(p->q_mu);
+            p->q_idle.wait(lk, [&] { return p->outstanding == 0; });
+            p->quit = true;
+        }
+        p->q_cv.notify_all();
+        for (std::thread& t : p->feeders) t.join();
+    }
     for (poppy_hip_ctx* c : p->ctx) poppy_hip_destroy(c);
     delete p;
+}
+
+// one pair of a batch on context wk: the pair source, the set-up (behind the pool's gate for device-resident images), the frames
+static int pool_render_pair(poppy_hip_pool* p, int wk, int pi, int W, int H, double phase, int inputs_on_device,
+                            poppy_pair_source_cb source, poppy_write_pair_cb write, void* user) {
+    poppy_hip_ctx* c = p->ctx[wk];
+    struct Relay { poppy_write_pair_cb write; void* user; int pair; int frame; };
+    const uint8_t *a = nullptr, *b = nullptr; size_t sa = 0, sb = 0;
+    int rc = source(user, pi, p->device_of[wk], &a, &sa, &b, &sb) == 0 ? POPPY_OK : POPPY_E_ARG;
+    if (rc != POPPY_OK) c->err = "the pair source failed";
+    Relay relay{write, user, pi, 0};
+    poppy_write_cb cb = write ? +[](void* u, const uint8_t* bgr, int w, int h, size_t stride) {
+        Relay* r = (Relay*)u;
+        r->write(r->user, r->pair, r->frame++, bgr, w, h, stride);
+    } : (poppy_write_cb) nullptr;
+    if (rc == POPPY_OK && !inputs_on_device) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
+    else if (rc == POPPY_OK) {                              // the same call sequence on images that are already in this GPU's memory
+        const int dev = p->device_of[wk];
+        if (p->setup_gate > 0) {
+            std::unique_lock<std::mutex> g(p->gate_mu);
+            p->gate_cv.wait(g, [&] { return p->setups_running[dev] < p->setup_gate; });
+            ++p->setups_running[dev];
+        }
+        rc = poppy_hip_pair_begin_device(c, a, b, W, H);
+        if (p->setup_gate > 0) {
+            { std::lock_guard<std::mutex> g(p->gate_mu); --p->setups_running[dev]; }
+            p->gate_cv.notify_all();
+        }
+        if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_UNSUPPORTED, "no point pairs: the fallback needs the images on the host (poppy_hip_morph)");
+        if (rc == POPPY_OK) rc = poppy_hip_morph_frames(c, phase, cb, &relay);
+    }
+    return rc;
 }
 
 int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, double phase, int inputs_on_device,
@@ -665,36 +723,12 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, dou
     std::atomic<int> next{0}, failed{POPPY_OK};
     std::mutex mu;
     std::string first_err;
-    struct Relay { poppy_write_pair_cb write; void* user; int pair; int frame; };
     auto work = [&](int wk) {
         poppy_hip_ctx* c = p->ctx[wk];
         for (;;) {
             const int pi = next.fetch_add(1);
             if (pi >= n_pairs || failed.load() != POPPY_OK) break;
-            const uint8_t *a = nullptr, *b = nullptr; size_t sa = 0, sb = 0;
-            int rc = source(user, pi, p->device_of[wk], &a, &sa, &b, &sb) == 0 ? POPPY_OK : POPPY_E_ARG;
-            if (rc != POPPY_OK) c->err = "the pair source failed";
-            Relay relay{write, user, pi, 0};
-            poppy_write_cb cb = write ? +[](void* u, const uint8_t* bgr, int w, int h, size_t stride) {
-                Relay* r = (Relay*)u;
-                r->write(r->user, r->pair, r->frame++, bgr, w, h, stride);
-            } : (poppy_write_cb) nullptr;
-            if (rc == POPPY_OK && !inputs_on_device) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
-            else if (rc == POPPY_OK) {                              // the same call sequence on images that are already in this GPU's memory
-                const int dev = p->device_of[wk];
-                if (p->setup_gate > 0) {
-                    std::unique_lock<std::mutex> g(p->gate_mu);
-                    p->gate_cv.wait(g, [&] { return p->setups_running[dev] < p->setup_gate; });
-                    ++p->setups_running[dev];
-                }
-                rc = poppy_hip_pair_begin_device(c, a, b, W, H);
-                if (p->setup_gate > 0) {
-                    { std::lock_guard<std::mutex> g(p->gate_mu); --p->setups_running[dev]; }
-                    p->gate_cv.notify_all();
-                }
-                if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_UNSUPPORTED, "no point pairs: the fallback needs the images on the host (poppy_hip_morph)");
-                if (rc == POPPY_OK) rc = poppy_hip_morph_frames(c, phase, cb, &relay);
-            }
+            const int rc = pool_render_pair(p, wk, pi, W, H, phase, inputs_on_device, source, write, user);
             if (rc != POPPY_OK && rc != POPPY_E_NOMATCH) {          // a pair without matches got its fallback frames: not an error of the batch
                 std::lock_guard<std::mutex> g(mu);
                 if (first_err.empty()) first_err = "pair " + std::to_string(pi) + ": " + poppy_hip_last_error(c);
@@ -710,6 +744,67 @@ int poppy_hip_pool_morph_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, dou
     for (auto& t : th) t.join();
     if (failed.load() != POPPY_OK) set_err(err, err_len, first_err);
     return failed.load();
+}
+
+// The asynchronous form of poppy_hip_pool_morph_pairs: the batch is queued and the call returns; poppy_hip_pool_wait returns when every pair submitted so far has
+// been rendered and handed to its writer.  Batches are taken up in submission order, pair by pair, by whichever context is free — a batch's last pairs run beside the
+// next batch's first set-ups.  `source`, `write` and `user` must stay valid until the wait; they are called from the pool's threads (as in the synchronous form).
+// After a failure the pairs still queued are dropped and the wait reports the first error.  Not to be mixed with a poppy_hip_pool_morph_pairs call in flight.
+static void pool_feeder(poppy_hip_pool* p, int wk) {
+    for (;;) {
+        std::shared_ptr<poppy_hip_pool::Batch> b;
+        int pi = 0;
+        bool drop = false;
+        {
+            std::unique_lock<std::mutex> lk(p->q_mu);
+            p->q_cv.wait(lk, [&] { return p->quit || !p->queue.empty(); });
+            if (p->queue.empty()) return;                           // (quit)
+            b = p->queue.front();
+            pi = b->taken++;
+            if (b->taken >= b->n_pairs) p->queue.pop_front();
+            drop = p->async_rc != POPPY_OK;
+        }
+        int rc = POPPY_OK;
+        if (!drop) rc = pool_render_pair(p, wk, pi, b->W, b->H, b->phase, b->inputs_on_device, b->source, b->write, b->user);
+        {
+            std::lock_guard<std::mutex> lk(p->q_mu);
+            if (rc != POPPY_OK && rc != POPPY_E_NOMATCH && p->async_rc == POPPY_OK) {
+                p->async_rc = rc;
+                p->async_err = "pair " + std::to_string(pi) + ": " + poppy_hip_last_error(p->ctx[wk]);
+            }
+            if (--p->outstanding == 0) p->q_idle.notify_all();
+        }
+    }
+}
+
+int poppy_hip_pool_submit_pairs(poppy_hip_pool* p, int n_pairs, int W, int H, double phase, int inputs_on_device,
+                                poppy_pair_source_cb source, poppy_write_pair_cb write, void* user) {
+    if (!p || n_pairs < 0 || !source || W <= 0 || H <= 0) return POPPY_E_ARG;
+    if (!p->ctx.empty() && p->ctx[0]->cfg.enable_auto_align && n_pairs > 1) return POPPY_E_UNSUPPORTED;     // (see poppy_hip_pool_morph_pairs)
+    if (n_pairs == 0) return POPPY_OK;
+    auto b = std::make_shared<poppy_hip_pool::Batch>();
+    b->n_pairs = n_pairs; b->W = W; b->H = H; b->phase = phase; b->inputs_on_device = inputs_on_device;
+    b->source = source; b->write = write; b->user = user;
+    {
+        std::lock_guard<std::mutex> lk(p->q_mu);
+        if (p->feeders.empty())
+            for (int k = 0; k < (int)p->ctx.size(); ++k) p->feeders.emplace_back(pool_feeder, p, k);
+        p->outstanding += n_pairs;
+        p->queue.push_back(std::move(b));
+    }
+    p->q_cv.notify_all();
+    return POPPY_OK;
+}
+
+int poppy_hip_pool_wait(poppy_hip_pool* p, char* err, size_t err_len) {
+    if (!p) { set_err(err, err_len, "bad arguments"); return POPPY_E_ARG; }
+    std::unique_lock<std::mutex> lk(p->q_mu);
+    p->q_idle.wait(lk, [&] { return p->outstanding == 0; });
+    const int rc = p->async_rc;
+    if (rc != POPPY_OK) set_err(err, err_len, p->async_err);
+    p->async_rc = POPPY_OK;
+    p->async_err.clear();
+    return rc;
 }
 
 // A pool whose contexts came out well.  The contexts of a pool get their streams, hardware queues and buffers from the runtime when they are made, and about

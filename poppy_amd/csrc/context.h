@@ -70,6 +70,7 @@ struct poppy_hip_ctx {
     void* slot_prep_store = nullptr;     // per slot: the frame prepared there (poppy_hip.cpp: SlotPrep)
     unsigned long long frame_seq = 0;    // submit_frame calls so far (a slot prepared ahead names the call it is for)
     void* seq_plans = nullptr;           // the plans of a multi-frame call in the making (poppy_hip.cpp: SeqPlans), possibly started ahead by a pair loader
+    bool plan_ahead_credit = true;       // pair loaders start the default sequence's plans (false after a pair whose plans nobody took, until a multi-frame call comes again)
     hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
     const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"
     hipEvent_t cur1_ready = nullptr;     // producer of cur1 when it is a slot's output, else null

@@ -215,7 +215,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     static const bool stage_times = getenv("POPPY_SETUP_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    double ms_upload = 0, ms_chains = 0, ms_detect = 0, ms_match = 0;
+    double ms_upload = 0, ms_chains = 0, ms_detect = 0, ms_match = 0, ms_chain_end[2] = {0, 0}, ms_joined = 0;
     std::vector<uint8_t> g[2];
     if (ratio >= 0.f) { g[0].resize(P); g[1].resize(P); }
     const uint8_t* g_dev[2] = {nullptr, nullptr};
@@ -329,6 +329,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (rcs[i ^ 1]) return;                                   // the other chain failed (its error is reported)
         const int nf = (int)(c->cfg.max_keypoints * (255.0 / std::max(d[0], d[1])));
         if (orb.detect_finish(nf, st, i ? k2 : k1) < 0) { errs[i] = "orb_detect: " + orb.err; rcs[i] = POPPY_E_DEVICE; }
+        ms_chain_end[i] = since(t_begin);
     };
     if (serial_chains) {
         const double t0 = since(t_begin);
@@ -342,6 +343,7 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
         if (!c->setup_worker.wait()) { c->err = "pair set-up helper thread: " + c->setup_worker.error(); return POPPY_E_DEVICE; }
     }
     c->foreground_b.medians_done = nullptr;
+    ms_joined = since(t_begin);
     if (!align_first) HIPCHK(c, hipStreamSynchronize(c->copy_stream));                // gabor2 is in place
     for (int i = 0; i < 2; ++i) if (rcs[i].load()) { c->err = errs[i]; return rcs[i].load(); }
     ms_chains = since(t_begin);
@@ -414,13 +416,17 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
             HIPCHK(c, hipMemcpyAsync(c->gabor2, gab, P * 12, hipMemcpyDeviceToDevice, c->stream));
         }
         int m = 0;
+        const double ms_m0 = since(t_begin);
         rc = match_points_with(&c->setup_worker, p1.data(), p2.data(), (int)n, W, H, c->cfg.match_tolerance, o1.data(), o2.data(), &m, &c->initial_morph_dist);
         if (rc) return fail(c, rc, "poppy_match_points failed");
+        const double ms_m1 = since(t_begin);
         rc = set_points(c, o1.data(), o2.data(), m); if (rc) return rc;
+        if (stage_times) fprintf(stderr, "  match stage: points out of the keypoints %.3f, matcher %.3f, set_points %.3f ms (cumulative)\n", ms_m0, ms_m1, since(t_begin));
     }
     ms_match = since(t_begin);
     rc = finish_pair_load(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stage_times) fprintf(stderr, "  chains: image 1 through %.3f, image 2 through %.3f, both joined %.3f, gabor2 in place %.3f ms\n", ms_chain_end[0], ms_chain_end[1], ms_joined, ms_chains);
     if (stage_times)
         fprintf(stderr, "pair set-up %dx%d: upload %.3f, chains %.3f, detect %.3f, match %.3f, finish %.3f ms (cumulative); before them (drain + queueing the raw pair's copies) %.3f ms\n", W, H, ms_upload, ms_chains,
                 ms_detect, ms_match, since(t_begin), std::chrono::duration<double, std::milli>(t_begin - t_enter).count());

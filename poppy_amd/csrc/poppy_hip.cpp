@@ -388,7 +388,7 @@ constexpr int kPlanThrew = -1000;          // rcs[] marker: the planner of that 
 // first plan takes (one context, pair after pair: 4 % of a pair).  A call with other frames drops them (the planners stop at their next frame) and makes its own.
 struct SeqPlans {
     int n = 0, W = 0, H = 0;
-    bool chain = false;
+    bool chain = false, abandoned = false;                     // abandoned: told to stop before every frame was planned (never adopted)
     std::vector<double> shape;
     std::vector<P2f> pts1_at_start, pts2;                      // the point sets the plans were made from (a call adopts them only for the same ones)
     std::vector<std::vector<P2f>> src1;
@@ -454,7 +454,17 @@ static SeqPlans* start_seq_plans(poppy_hip_ctx* c, const double* shape, int n, b
 // a pair loader's speculative start (set_points): the reference's default sequence on the new pair
 void start_default_seq_plans(poppy_hip_ctx* c) {
     static const bool off = getenv("POPPY_HIP_NO_PLAN_AHEAD") != nullptr;
+    if (SeqPlans* old = static_cast<SeqPlans*>(c->seq_plans)) {
+        // The previous pair's plans were never taken: this caller loads pairs without rendering the default sequence in between (a set-up timing loop, a caller
+        // of single frames).  Planning ahead for it only burns host threads beside its next set-up (0.3 ms per set-up in such a loop), and waiting for planners in
+        // mid-frame cost another 0.2 ms: they are told to stop and left to finish, and no plans are started for a pair until a multi-frame call has been seen again.
+        c->plan_ahead_credit = false;
+        old->abandoned = true;
+        old->next.store(old->n);
+        if (!c->planners.idle()) return;
+    }
     stop_seq_plans(c);
+    if (!c->plan_ahead_credit) return;
     const int N = c->cfg.number_of_frames;
     if (off || N < 2 || c->pts1.empty() || c->debug) return;
     std::vector<double> ratio(N);
@@ -467,9 +477,10 @@ static int render_sequence(poppy_hip_ctx* c, const double* shape, const double* 
     if (c->pts1.empty()) return fail(c, POPPY_E_NOMATCH, "no point pairs (use poppy_hip_dissolve)");
     if (n <= 0) return POPPY_OK;
     const int W = c->W, H = c->H;
+    if (n >= 2) c->plan_ahead_credit = true;                       // a caller of sequences: the next pair loader plans ahead again (start_default_seq_plans)
     // the plans a pair loader started for exactly these frames on exactly these points, or new ones
     SeqPlans* sp = static_cast<SeqPlans*>(c->seq_plans);
-    if (!(sp && sp->n == n && sp->chain == chain && sp->W == W && sp->H == H && same_points(sp->pts1_at_start, c->pts1) && same_points(sp->pts2, c->pts2) &&
+    if (!(sp && !sp->abandoned && sp->n == n && sp->chain == chain && sp->W == W && sp->H == H && same_points(sp->pts1_at_start, c->pts1) && same_points(sp->pts2, c->pts2) &&
           std::equal(shape, shape + n, sp->shape.begin()))) {
         stop_seq_plans(c);
         sp = start_seq_plans(c, shape, n, chain);

@@ -97,6 +97,8 @@ public:
         lk.unlock();
         cv_.notify_all();
     }
+    // no member is inside a job
+    bool idle() { std::lock_guard<std::mutex> lk(m_); return pending_ == 0; }
     // false = a member's job threw (error()): see Worker::wait
     bool wait() {
         std::unique_lock<std::mutex> lk(m_);

@@ -397,6 +397,50 @@ def test_morph_pairs_on_three_contexts():
             G.check(case, f"frame{j}", f)
 
 
+def test_pool_batches_queued_without_waiting():
+    """poppy_hip_pool_submit_pairs / poppy_hip_pool_wait: three batches (2 + 3 + 1 pairs) queued back to back on a pool of three contexts, then one wait — the batches
+    overlap (a batch's last pair renders beside the next batch's set-ups); every frame of every pair as the real reference's; a second round on the same pool after
+    the wait; then a batch whose pair source fails: the wait reports it, and the pool still renders afterwards."""
+    import threading
+    from poppy_amd import capi
+    case = "a_256x256_chain"
+    inp = G.astage_inputs(case)
+    n = int(inp["cfg"][0])
+    pool = capi.Pool([0], contexts_per_device=3, number_of_frames=n)
+    lock = threading.Lock()
+    try:
+        for rnd in range(2):
+            got = {}
+            def writer(b):
+                def w(pair, j, view):
+                    f = view.copy()
+                    with lock:
+                        got.setdefault((b, pair), {})[j] = f
+                return w
+            for b, k in enumerate((2, 3, 1)):
+                pool.submit_pairs([(inp["img1"], inp["img2"])] * k, writer(b))
+            pool.wait()
+            assert sorted(got) == [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 0)], sorted(got)
+            for key, frames in got.items():
+                assert sorted(frames) == list(range(n)), (key, sorted(frames))
+                for j in range(n):
+                    G.check(case, f"frame{j}", frames[j])
+        # a failing pair source: reported by the wait, nothing hangs, the pool is usable afterwards
+        import ctypes as C
+        bad = capi.PAIR_SOURCE_CB(lambda user, p, device, pa, sa, pb, sb: 1)
+        rc = capi.lib().poppy_hip_pool_submit_pairs(pool.h, 4, 256, 256, -1.0, 0, C.cast(bad, C.c_void_p), None, None)
+        assert rc == 0
+        with pytest.raises(capi.PoppyError, match="pair source"):
+            pool.wait()
+        got = {}
+        pool.submit_pairs([(inp["img1"], inp["img2"])], lambda pair, j, view: got.setdefault(j, view.copy()))
+        pool.wait()
+        assert sorted(got) == list(range(n))
+        G.check(case, f"frame{n - 1}", got[n - 1])
+    finally:
+        pool.close()
+
+
 def test_tuned_pool_and_communicator_info():
     """poppy_hip_pool_create_tuned makes candidate pools, times the built-in calibration batch on each and hands out one of them, which then renders device-resident
     pairs like any pool; poppy_hip_comm_info without a communicator reports -1 for what RCCL would say, and the world of one after comm_init."""
