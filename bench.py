@@ -931,9 +931,9 @@ def bench_sharded(args, torch, dist, capi, sharding, dev, local, rank, world, re
     fence()
     t2 = time.perf_counter()
     reps = max(1, args.steps // 4)
-    nfr = 0
-    for _ in range(reps):
-        nfr += pool.morph_pairs_device_counted(ptrs, W, H, -1.0)
+    for _ in range(reps):                                          # queued, as the --gpus 1 line's `value` is: one wait at the end
+        pool.submit_pairs_device_counted(ptrs, W, H, -1.0)
+    nfr = pool.wait()
     fence()
     dt_p = link.max_time(time.perf_counter() - t2)
     pool.close()

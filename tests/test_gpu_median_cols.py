@@ -87,7 +87,9 @@ def test_exactly_64_and_65_values_per_tile(ctx):
 
 
 def test_1080p_chain_of_medians_on_photograph_and_shapes(ctx):
-    """the progressive chain of Extractor::foreground (median 9 of the grey image, 17 of that, ...) at 1080p: every link, forms 2 and 1 agree"""
+    """the progressive chain of Extractor::foreground (median 9 of the grey image, 17 of that, ...) at 1080p: every link, forms 2 and 1 agree.
+    A CONSISTENCY check between the library's two kernels (the oracle's median takes minutes at this size), not parity evidence by itself: both forms
+    are compared with the oracle at the sizes it finishes in seconds by the tests beside this one, and form 1 at 1080p by test_gpu_prefilter.py."""
     from poppy_amd import synth
     for name, bgr in (("shapes", synth.gen(1920, 1080, 1234)), ("photo", synth.photo_pair(1920, 1080)[0])):
         cur = np.ascontiguousarray(bgr[:, :, 1])

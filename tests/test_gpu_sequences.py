@@ -131,7 +131,8 @@ def test_cfg3_4k_phase_mode_frame():
 def test_cfg3_4k_sequence_in_flight_equals_single_frames():
     """configs[2] as bench.py runs it: 3840x2160 phase-mode frames of one pair, several in flight, handed to a writer through the pinned ring.
     Every delivered frame must equal the frame rendered on its own (the streaming unsharp kernel, the 128 x 8 warp tiles and the id bytes are
-    what a 4K frame takes); the frame at t = 0.5 is the reference's own (fixture a_3840x2160_phase)."""
+    what a 4K frame takes); the frame at t = 0.5 is the reference's own (fixture a_3840x2160_phase).  The frame-against-itself part is a CONSISTENCY check of
+    the in-flight machinery (slots, ring, streams), not parity evidence: the parity of 4K frames is the fixture frame here and test_cfg3_4k_frames_against_the_oracle."""
     case = "a_3840x2160_phase"
     inp = G.astage_inputs(case)
     c = _ctx(number_of_frames=1)
