@@ -763,6 +763,21 @@ def bench_single(args, torch, capi, dev, local):
         for (da, db), (ha, hb) in zip(pairs_dev, pinned):
             da.copy_(ha, non_blocking=True); db.copy_(hb, non_blocking=True)
         torch.cuda.synchronize()
+    # the headline itself from HOST images: the queued steps of `value`, but every pair handed to the pool as two pinned host images (poppy_hip_morph per pair: the
+    # set-up uploads them on its own streams, beside other pairs' frames — the link is full duplex — and behind the same set-up gate)
+    hptrs = [(ha.data_ptr(), hb.data_ptr()) for ha, hb in pinned]
+    pool2.submit_pairs_device_counted(hptrs, W, H, -1.0, on_device=False); pool2.wait()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        pool2.submit_pairs_device_counted(hptrs, W, H, -1.0, on_device=False)
+    nhost = pool2.wait()
+    torch.cuda.synchronize()
+    dthost = time.perf_counter() - t1
+    assert nhost == args.steps * PAIRS * FRAMES, (nhost, args.steps * PAIRS * FRAMES)
+    out["value_from_host_images"] = {"fps": round(nhost / dthost, 2), "ms_per_step": round(dthost / args.steps * 1e3, 3),
+                                     "what": f"`value`'s timed region (the same {args.steps} queued steps of {PAIRS} pairs on a pool from plain poppy_hip_pool_create: compare `value_unselected`) with every pair "
+                                             "handed over as two images in pinned HOST memory, as the reference's morph() is: the uploads (2 x %.1f MB per pair) are inside, on the set-ups' own streams" % (P * 3 / 1e6)}
     out["h2d"] = {"value_incl_h2d": round(kh / dth, 1), "h2d_ms_per_pair": round((time.perf_counter() - t1) / rh / PAIRS * 1e3, 3),
                   "what": "the step of `value_step_synchronous` (compare with that figure) with the raw pairs (2 x %.1f MB each) copied host -> device inside the step, serially before the pool starts; the timed region of `value` starts with them resident in HBM" % (P * 3 / 1e6)}
     pool2.close()

@@ -436,8 +436,9 @@ class Pool:
         return n.value
 
     # ---- batches without waiting for them (poppy_hip_pool_submit_pairs / poppy_hip_pool_wait) ----
-    def submit_pairs_device_counted(self, ptr_pairs, w, h, phase=-1.0):
-        """Queues the batch and returns; wait() returns the frames written by every batch submitted since the last wait()."""
+    def submit_pairs_device_counted(self, ptr_pairs, w, h, phase=-1.0, on_device=True):
+        """Queues the batch and returns; wait() returns the frames written by every batch submitted since the last wait().  on_device=False: the pointers are
+        HOST pointers (tight rows; pinned memory if the uploads are to overlap anything) and every pair goes through poppy_hip_morph."""
         ptr_pairs = list(ptr_pairs)
         def src(user, p, device, pa, sa, pb, sb):
             pa[0] = ptr_pairs[p][0]; sa[0] = w * 3
@@ -447,7 +448,7 @@ class Pool:
         if not hasattr(self, "_pending"):
             self._pending, self._count = [], C.c_longlong(0)
         self._pending.append((fs, ptr_pairs))                     # the callbacks stay alive until the wait
-        rc = lib().poppy_hip_pool_submit_pairs(self.h, len(ptr_pairs), w, h, phase, 1, C.cast(fs, C.c_void_p),
+        rc = lib().poppy_hip_pool_submit_pairs(self.h, len(ptr_pairs), w, h, phase, 1 if on_device else 0, C.cast(fs, C.c_void_p),
                                                C.cast(lib().poppy_count_pair_frames_cb, C.c_void_p), C.cast(C.byref(self._count), C.c_void_p))
         if rc:
             raise PoppyError(f"poppy_hip_pool_submit_pairs: {rc}")

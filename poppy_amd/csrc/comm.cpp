@@ -639,6 +639,8 @@ struct poppy_hip_pool {
     bool quit = false;
 };
 
+static void pool_setup_hook(void* user, poppy_hip_ctx* c, int begin);
+
 poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int contexts_per_device, const poppy_settings* settings,
                                       char* err, size_t err_len) {
     if (!devices || n_devices < 1 || n_devices > 64 || contexts_per_device < 1 || contexts_per_device > 16) { set_err(err, err_len, "bad arguments"); return nullptr; }
@@ -658,6 +660,7 @@ poppy_hip_pool* poppy_hip_pool_create(const int* devices, int n_devices, int con
             // section 6; still the better form behind the set-up gate: profiles/r06_gate.txt; POPPY_POOL_CHAINS=0 / 1 forces side by side / serial)
             static const int chains_env = getenv("POPPY_POOL_CHAINS") ? atoi(getenv("POPPY_POOL_CHAINS")) : -1;
             c->setup_serial = chains_env >= 0 ? chains_env != 0 : contexts_per_device >= 3;
+            if (p->setup_gate > 0) { c->setup_hook = pool_setup_hook; c->setup_hook_user = p; }
             p->ctx.push_back(c); p->device_of.push_back(devices[d]);
         }
     return p;
@@ -678,7 +681,22 @@ void poppy_hip_pool_destroy(poppy_hip_pool* p) {
     delete p;
 }
 
-// one pair of a batch on context wk: the pair source, the set-up (behind the pool's gate for device-resident images), the frames
+// The set-up gate: every pair set-up of a pool's contexts — from host images (poppy_hip_morph) or from resident ones (poppy_hip_pair_begin_device) — passes through here
+// (context.h: setup_hook, called by pair_setup.cpp at the set-up's beginning and end)
+static void pool_setup_hook(void* user, poppy_hip_ctx* c, int begin) {
+    poppy_hip_pool* p = static_cast<poppy_hip_pool*>(user);
+    const int dev = c->device;
+    if (begin) {
+        std::unique_lock<std::mutex> g(p->gate_mu);
+        p->gate_cv.wait(g, [&] { return p->setups_running[dev] < p->setup_gate; });
+        ++p->setups_running[dev];
+    } else {
+        { std::lock_guard<std::mutex> g(p->gate_mu); --p->setups_running[dev]; }
+        p->gate_cv.notify_all();
+    }
+}
+
+// one pair of a batch on context wk: the pair source, the set-up (behind the pool's gate), the frames
 static int pool_render_pair(poppy_hip_pool* p, int wk, int pi, int W, int H, double phase, int inputs_on_device,
                             poppy_pair_source_cb source, poppy_write_pair_cb write, void* user) {
     poppy_hip_ctx* c = p->ctx[wk];
@@ -693,17 +711,7 @@ static int pool_render_pair(poppy_hip_pool* p, int wk, int pi, int W, int H, dou
     } : (poppy_write_cb) nullptr;
     if (rc == POPPY_OK && !inputs_on_device) rc = poppy_hip_morph(c, a, sa, b, sb, W, H, phase, 0, cb, &relay, nullptr);
     else if (rc == POPPY_OK) {                              // the same call sequence on images that are already in this GPU's memory
-        const int dev = p->device_of[wk];
-        if (p->setup_gate > 0) {
-            std::unique_lock<std::mutex> g(p->gate_mu);
-            p->gate_cv.wait(g, [&] { return p->setups_running[dev] < p->setup_gate; });
-            ++p->setups_running[dev];
-        }
-        rc = poppy_hip_pair_begin_device(c, a, b, W, H);
-        if (p->setup_gate > 0) {
-            { std::lock_guard<std::mutex> g(p->gate_mu); --p->setups_running[dev]; }
-            p->gate_cv.notify_all();
-        }
+        rc = poppy_hip_pair_begin_device(c, a, b, W, H);           // (behind the pool's set-up gate: pool_setup_hook)
         if (rc == POPPY_OK && c->pts1_0.empty()) rc = fail(c, POPPY_E_UNSUPPORTED, "no point pairs: the fallback needs the images on the host (poppy_hip_morph)");
         if (rc == POPPY_OK) rc = poppy_hip_morph_frames(c, phase, cb, &relay);
     }

@@ -70,6 +70,9 @@ struct poppy_hip_ctx {
     void* slot_prep_store = nullptr;     // per slot: the frame prepared there (poppy_hip.cpp: SlotPrep)
     unsigned long long frame_seq = 0;    // submit_frame calls so far (a slot prepared ahead names the call it is for)
     void* seq_plans = nullptr;           // the plans of a multi-frame call in the making (poppy_hip.cpp: SeqPlans), possibly started ahead by a pair loader
+    // called at the beginning (1) and at the end (0) of every pair set-up from raw images (pair_setup.cpp: pair_begin_impl): a pool's set-up gate (comm.cpp)
+    void (*setup_hook)(void* user, poppy_hip_ctx* c, int begin) = nullptr;
+    void* setup_hook_user = nullptr;
     bool plan_ahead_credit = true;       // pair loaders start the default sequence's plans (false after a pair whose plans nobody took, until a multi-frame call comes again)
     hipEvent_t inputs_ready = nullptr;   // c1 / c2 / m2 written (recorded on `stream` by the pair loaders)
     const uint8_t* cur1 = nullptr;       // what the next frame warps as "corrected1"

@@ -185,6 +185,11 @@ static int pair_begin_impl(poppy_hip_ctx* c, const uint8_t* bgr1, size_t s1, con
     if (!c) return POPPY_E_ARG;
     if (!bgr1 || !bgr2 || W <= 0 || H <= 0 || s1 < (size_t)W * 3 || s2 < (size_t)W * 3) return fail(c, POPPY_E_ARG, "bad image arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    struct SetupHook {                                            // a pool lets one context per device set a pair up at a time (comm.cpp: the set-up gate)
+        poppy_hip_ctx* c;
+        explicit SetupHook(poppy_hip_ctx* c_) : c(c_) { if (c->setup_hook) c->setup_hook(c->setup_hook_user, c, 1); }
+        ~SetupHook() { if (c->setup_hook) c->setup_hook(c->setup_hook_user, c, 0); }
+    } setup_hook(c);
     const auto t_enter = std::chrono::steady_clock::now();
     int rc = alloc_pair(c, W, H); if (rc) return rc;
     c->pair_ready = false;
