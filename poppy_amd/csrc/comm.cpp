@@ -773,12 +773,18 @@ static void pool_feeder(poppy_hip_pool* p, int wk) {
             drop = p->async_rc != POPPY_OK;
         }
         int rc = POPPY_OK;
-        if (!drop) rc = pool_render_pair(p, wk, pi, b->W, b->H, b->phase, b->inputs_on_device, b->source, b->write, b->user);
+        std::string thrown;
+        if (!drop) {
+            // (an exception on a pool thread — std::bad_alloc is the one that can happen — must reach the waiter as a status: nobody else would decrement `outstanding`)
+            try { rc = pool_render_pair(p, wk, pi, b->W, b->H, b->phase, b->inputs_on_device, b->source, b->write, b->user); }
+            catch (const std::exception& e) { rc = POPPY_E_DEVICE; thrown = e.what(); }
+            catch (...) { rc = POPPY_E_DEVICE; thrown = "unknown exception"; }
+        }
         {
             std::lock_guard<std::mutex> lk(p->q_mu);
             if (rc != POPPY_OK && rc != POPPY_E_NOMATCH && p->async_rc == POPPY_OK) {
                 p->async_rc = rc;
-                p->async_err = "pair " + std::to_string(pi) + ": " + poppy_hip_last_error(p->ctx[wk]);
+                p->async_err = "pair " + std::to_string(pi) + ": " + (thrown.empty() ? std::string(poppy_hip_last_error(p->ctx[wk])) : "exception on a pool thread: " + thrown);
             }
             if (--p->outstanding == 0) p->q_idle.notify_all();
         }
