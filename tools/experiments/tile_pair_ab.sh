@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6: k_tile_expand_pair (two tiles per workgroup, the second tile's chain of loads trailing the first's) against k_tile_expand: exactness on the fixtures with the
 # pair form forced for every geometry, then kernel-trace averages at 4K and 1080p, chained and phase mode.   gpurun -- bash tools/experiments/tile_pair_ab.sh
+# (needs profiles/r06_tile_pair.patch applied: the kernel and its POPPY_TILE_EXPAND_PAIR switch were removed after this measurement)
 cd "$GRAFT_REPO_ROOT"
 echo "forced pair form: $(POPPY_TILE_EXPAND_PAIR=1 python3 -m pytest tests/test_gpu_fused_warp.py tests/test_gpu_odd_widths.py tests/test_gpu_bstage.py tests/test_gpu_sequences.py -x -q -m gpu 2>&1 | grep -E 'passed|failed|rror' | tail -1)"
 echo "default:          $(python3 -m pytest tests/test_gpu_fused_warp.py tests/test_gpu_odd_widths.py -x -q -m gpu 2>&1 | grep -E 'passed|failed|rror' | tail -1)"
